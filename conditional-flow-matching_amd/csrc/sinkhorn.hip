@@ -1,0 +1,393 @@
+// sinkhorn.hip — K5: log-domain Sinkhorn iteration for gfx950.
+//
+// Replaces pot.sinkhorn(a, b, M, reg) (torchcfm/optimal_transport.py:51,87) in
+// its stable log-domain form, POT loop semantics (u0 = 0; column update then
+// row update; marginal check every `check_every` iterations; stopThr on the L2
+// violation of the column marginal; numItermax).
+//
+// One iteration = two streaming passes over M (2*4*B0*B1 algorithmic bytes):
+//   sk_col_pass      lane owns 4 adjacent columns, walks a strip of rows with an
+//                    online (max,sum) LSE -> no cross-lane traffic, 1 KiB
+//                    contiguous per wave load; strips combined by
+//   sk_col_finalize  (per-column merge of the strip partials, new v, and — for
+//                    free — the marginal error of the PREVIOUS iteration:
+//                    colsum_j = b_j * exp(v_old_j - v_new_j));
+//   sk_row_pass      one wave per row, v staged in LDS (fp64), wave shuffle
+//                    reduction of the per-lane (max,sum) pairs.
+// The exponent (u_i + v_j - M_ij/reg) cancels three O(100/reg) numbers to O(1):
+// it is formed in fp64 (the chip is HBM-bound here; fp64 VALU is free), only
+// exp() itself runs in fp32.  Log-scalings u, v live in fp64 in the workspace.
+//
+// Convergence is decided on the device (no host sync): every kernel of the
+// pre-enqueued sequence reads the state block and exits if `done` is set.
+#include "cfm_common.h"
+
+#define SK_NEG (-1.0e300)
+#define SK_NCHUNK_MAX 64
+
+struct SkState {
+    int done;        // set once converged
+    int iters_done;  // POT's ii+1 at break, or max_iter
+    int vfinal;      // which v buffer holds the final v
+    int pad;
+    double err2[2];  // sum of squared marginal violations (ping-pong)
+    double last_err;
+};
+
+struct SkWs {
+    SkState* st;
+    double* u;
+    double* v[2];
+    double* pm;  // [nchunk][B1]
+    double* ps;  // [nchunk][B1]
+};
+
+static inline int sk_nchunk(int B0, int B1) {
+    int tiles = (B1 + 255) / 256;
+    int n = (1024 + tiles - 1) / tiles;  // aim for ~1024 workgroups
+    if (n > SK_NCHUNK_MAX) n = SK_NCHUNK_MAX;
+    int maxn = (B0 + 31) / 32;           // at least 32 rows per strip
+    if (n > maxn) n = maxn;
+    if (n < 1) n = 1;
+    return n;
+}
+
+static inline size_t sk_ws_bytes(int B0, int B1) {
+    size_t nchunk = sk_nchunk(B0, B1);
+    return 256 + sizeof(double) * ((size_t)B0 + 2 * (size_t)B1 + 2 * nchunk * (size_t)B1) + 64;
+}
+
+static inline SkWs sk_carve(void* ws, int B0, int B1) {
+    SkWs w;
+    char* p = (char*)ws;
+    w.st = (SkState*)p; p += 256;
+    w.u = (double*)p; p += sizeof(double) * (size_t)B0;
+    w.v[0] = (double*)p; p += sizeof(double) * (size_t)B1;
+    w.v[1] = (double*)p; p += sizeof(double) * (size_t)B1;
+    size_t nchunk = sk_nchunk(B0, B1);
+    w.pm = (double*)p; p += sizeof(double) * nchunk * (size_t)B1;
+    w.ps = (double*)p;
+    return w;
+}
+
+extern "C" size_t cfm_sk_ws_bytes_internal(int B0, int B1) { return sk_ws_bytes(B0, B1); }
+
+__global__ void sk_init(SkState* st, double* u, double* v0, double* v1, int B0, int B1,
+                        int max_iter) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B0) u[i] = 0.0;
+    if (i < B1) { v0[i] = 0.0; v1[i] = 0.0; }
+    if (i == 0) {
+        st->done = 0; st->iters_done = max_iter; st->vfinal = (max_iter - 1) & 1; st->pad = 0;
+        st->err2[0] = 0.0; st->err2[1] = 0.0; st->last_err = 1.0;
+    }
+}
+
+__device__ __forceinline__ float4 sk_load4(const float* __restrict__ row, int j, int B1, bool vec) {
+    if (vec) return *reinterpret_cast<const float4*>(row + j);
+    float4 r;
+    r.x = (j + 0 < B1) ? row[j + 0] : 0.f;
+    r.y = (j + 1 < B1) ? row[j + 1] : 0.f;
+    r.z = (j + 2 < B1) ? row[j + 2] : 0.f;
+    r.w = (j + 3 < B1) ? row[j + 3] : 0.f;
+    return r;
+}
+
+// Column pass: partial LSE_i(u_i - M_ij/reg) over a strip of rows.
+__global__ __launch_bounds__(256) void sk_col_pass(const float* __restrict__ M, int B0, int B1,
+                                                   double inv_reg, const SkState* __restrict__ st,
+                                                   const double* __restrict__ u,
+                                                   double* __restrict__ pm,
+                                                   double* __restrict__ ps, int rows_per_chunk,
+                                                   int vec) {
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x * 256 + lane * 4;
+    const int chunk = blockIdx.y;
+    const int r_beg = chunk * rows_per_chunk;
+    const int r_end = min(B0, r_beg + rows_per_chunk);
+    const bool active = j < B1;
+    const bool v4 = vec && (j + 3 < B1);
+
+    double m[4] = {SK_NEG, SK_NEG, SK_NEG, SK_NEG};
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+
+    constexpr int U = 8;
+    for (int r0 = r_beg + wv * U; r0 < r_end; r0 += 4 * U) {
+        float4 c[U];
+        double ui[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int r = r0 + k;
+            const bool ok = active && r < r_end;
+            c[k] = ok ? sk_load4(M + (size_t)r * B1, j, B1, v4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ui[k] = (r < r_end) ? u[r] : SK_NEG;  // wave-uniform
+        }
+        double x[U][4];
+        double mx[4] = {m[0], m[1], m[2], m[3]};
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            x[k][0] = fma(-(double)c[k].x, inv_reg, ui[k]);
+            x[k][1] = fma(-(double)c[k].y, inv_reg, ui[k]);
+            x[k][2] = fma(-(double)c[k].z, inv_reg, ui[k]);
+            x[k][3] = fma(-(double)c[k].w, inv_reg, ui[k]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mx[q] = fmax(mx[q], x[k][q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = s[q] * __expf((float)(m[q] - mx[q]));
+#pragma unroll
+            for (int k = 0; k < U; ++k) acc += __expf((float)(x[k][q] - mx[q]));
+            s[q] = acc;
+            m[q] = mx[q];
+        }
+    }
+    // merge the 4 waves of the workgroup (same columns, different rows)
+    __shared__ double sm[4][256];
+    __shared__ float ss[4][256];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sm[wv][lane * 4 + q] = m[q]; ss[wv][lane * 4 + q] = s[q]; }
+    __syncthreads();
+    const int c = threadIdx.x;  // one column per thread
+    const int jc = blockIdx.x * 256 + c;
+    if (jc < B1) {
+        double mm = fmax(fmax(sm[0][c], sm[1][c]), fmax(sm[2][c], sm[3][c]));
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tot += (double)ss[w][c] * exp(sm[w][c] - mm);
+        pm[(size_t)chunk * B1 + jc] = mm;
+        ps[(size_t)chunk * B1 + jc] = tot;
+    }
+}
+
+// Merge strip partials -> v_new; accumulate the previous iteration's marginal
+// error when that iteration was a check iteration.
+__global__ __launch_bounds__(256) void sk_col_finalize(int B1, int nchunk, double logb, double b,
+                                                       SkState* __restrict__ st,
+                                                       const double* __restrict__ pm,
+                                                       const double* __restrict__ ps,
+                                                       const double* __restrict__ v_old,
+                                                       double* __restrict__ v_new, int check,
+                                                       int slot) {
+    if (st->done) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    double e2 = 0.0;
+    if (j < B1) {
+        double mm = SK_NEG;
+        for (int c = 0; c < nchunk; ++c) mm = fmax(mm, pm[(size_t)c * B1 + j]);
+        double tot = 0.0;
+        for (int c = 0; c < nchunk; ++c) tot += ps[(size_t)c * B1 + j] * exp(pm[(size_t)c * B1 + j] - mm);
+        const double vn = logb - (mm + log(tot));
+        v_new[j] = vn;
+        if (check) {
+            const double e = b * exp(v_old[j] - vn) - b;
+            e2 = e * e;
+        }
+    }
+    if (check) {
+        e2 = wave_sum_d(e2);
+        __shared__ double red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e2;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&st->err2[slot], red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// Row pass: u_i = log a - LSE_j(v_j - M_ij/reg); also the convergence decision
+// for the previous iteration (every workgroup derives it from the same data).
+__global__ __launch_bounds__(256) void sk_row_pass(const float* __restrict__ M, int B0, int B1,
+                                                   double inv_reg, double loga,
+                                                   SkState* __restrict__ st,
+                                                   const double* __restrict__ v,
+                                                   double* __restrict__ u, int rows_per_wg,
+                                                   int check, int slot, double stop_thr, int ii,
+                                                   int vec, int v_in_lds) {
+    if (st->done) return;
+    if (check) {
+        const double err = sqrt(st->err2[slot]);
+        if (err < stop_thr) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                st->last_err = err;
+                st->iters_done = ii;          // iterations 0..ii-1 ran; POT broke at ii-1
+                st->vfinal = (ii - 1) & 1;
+                __threadfence();
+                st->done = 1;
+            }
+            return;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->last_err = err;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->err2[slot ^ 1] = 0.0;  // next accumulation slot
+
+    extern __shared__ __attribute__((aligned(16))) double vs[];
+    if (v_in_lds) {
+        for (int j = threadIdx.x; j < B1; j += 256) vs[j] = v[j];
+        __syncthreads();
+    }
+    const double* vv = v_in_lds ? vs : v;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r_beg = blockIdx.x * rows_per_wg;
+    const int r_end = min(B0, r_beg + rows_per_wg);
+    for (int r = r_beg + wv; r < r_end; r += 4) {
+        const float* row = M + (size_t)r * B1;
+        double m = SK_NEG;
+        float s = 0.f;
+        constexpr int U = 4;
+        for (int j0 = lane * 4; j0 < B1; j0 += 256 * U) {
+            float4 c[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int j = j0 + 256 * k;
+                c[k] = (j < B1) ? sk_load4(row, j, B1, vec && (j + 3 < B1)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            double x[U][4];
+            double mx = m;
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int j = j0 + 256 * k;
+                const float cc[4] = {c[k].x, c[k].y, c[k].z, c[k].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x[k][q] = (j + q < B1) ? fma(-(double)cc[q], inv_reg, vv[j + q]) : SK_NEG;
+                    mx = fmax(mx, x[k][q]);
+                }
+            }
+            float acc = s * __expf((float)(m - mx));
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += __expf((float)(x[k][q] - mx));
+            s = acc;
+            m = mx;
+        }
+        const double mm = wave_max_d(m);
+        const double tot = wave_sum_d((double)s * exp(m - mm));
+        if (lane == 0) u[r] = loga - (mm + log(tot));
+    }
+}
+
+__global__ void sk_finish(SkState* st, const double* u, const double* v0, const double* v1,
+                          int B0, int B1, double reg, float* f, float* g, int* iters_done,
+                          float* last_err, int pending_check, int slot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double* v = st->vfinal ? v1 : v0;
+    if (i < B0 && f) f[i] = (float)(reg * u[i]);
+    if (i < B1 && g) g[i] = (float)(reg * v[i]);
+    if (i == 0) {
+        double le = st->last_err;
+        if (!st->done && pending_check) { le = sqrt(st->err2[slot]); st->last_err = le; }
+        if (iters_done) *iters_done = st->iters_done;
+        if (last_err) *last_err = (float)le;
+    }
+}
+
+extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, int max_iter,
+                                    float stop_thr, int check_every, float* f, float* g,
+                                    int* iters_done, float* last_err, void* ws, void* stream) {
+    if (!M || !ws || B0 <= 0 || B1 <= 0 || !(reg > 0.f) || max_iter < 0 || check_every <= 0)
+        return CFM_EINVAL;
+    if (((uintptr_t)ws & 15) != 0) return CFM_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    SkWs w = sk_carve(ws, B0, B1);
+    const int nchunk = sk_nchunk(B0, B1);
+    const int rows_per_chunk = (B0 + nchunk - 1) / nchunk;
+    const int col_tiles = (B1 + 255) / 256;
+    const int vec = ((B1 & 3) == 0) && (((uintptr_t)M & 15) == 0);
+    const double inv_reg = 1.0 / (double)reg;
+    const double a = 1.0 / B0, b = 1.0 / B1;
+    const double loga = log(a), logb = log(b);
+    const int rows_per_wg = 8;
+    const int row_wgs = (B0 + rows_per_wg - 1) / rows_per_wg;
+    const int v_in_lds = ((size_t)B1 * 8 <= 128 * 1024) ? 1 : 0;
+    const size_t lds = v_in_lds ? (size_t)B1 * 8 : 0;
+
+    int n = B0 > B1 ? B0 : B1;
+    hipLaunchKernelGGL(sk_init, dim3((n + 255) / 256), dim3(256), 0, s, w.st, w.u, w.v[0], w.v[1],
+                       B0, B1, max_iter);
+    // iteration ii: v^(ii) -> v[ii&1];  error of iteration ii-1 is measured by
+    // the column pass of iteration ii and decided at the start of its row pass.
+    for (int ii = 0; ii <= max_iter; ++ii) {
+        const int check = (ii >= 1) && (((ii - 1) % check_every) == 0);
+        const int slot = ii & 1;
+        const bool trailing = (ii == max_iter);
+        if (trailing && !check) break;  // nothing left to measure
+        hipLaunchKernelGGL(sk_col_pass, dim3(col_tiles, nchunk), dim3(256), 0, s, M, B0, B1, inv_reg,
+                           w.st, w.u, w.pm, w.ps, rows_per_chunk, vec);
+        hipLaunchKernelGGL(sk_col_finalize, dim3(col_tiles), dim3(256), 0, s, B1, nchunk, logb, b,
+                           w.st, w.pm, w.ps, w.v[(ii + 1) & 1], w.v[ii & 1], check, slot);
+        if (trailing) break;
+        hipLaunchKernelGGL(sk_row_pass, dim3(row_wgs), dim3(256), lds, s, M, B0, B1, inv_reg, loga,
+                           w.st, w.v[ii & 1], w.u, rows_per_wg, check, slot, (double)stop_thr, ii,
+                           vec, v_in_lds);
+    }
+    const int pending = (max_iter >= 1) && (((max_iter - 1) % check_every) == 0);
+    hipLaunchKernelGGL(sk_finish, dim3((n + 255) / 256), dim3(256), 0, s, w.st, w.u, w.v[0], w.v[1],
+                       B0, B1, (double)reg, f, g, iters_done, last_err, pending, max_iter & 1);
+    return cfm_status();
+}
+
+__global__ void sk_copy_potentials(const SkState* st, const double* u, const double* v0,
+                                   const double* v1, int B0, int B1, double* uo, double* vo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double* v = st->vfinal ? v1 : v0;
+    if (i < B0 && uo) uo[i] = u[i];
+    if (i < B1 && vo) vo[i] = v[i];
+}
+
+extern "C" int cfm_sinkhorn_potentials_f64(const void* ws, int B0, int B1, double* u, double* v,
+                                           void* stream) {
+    if (!ws || B0 <= 0 || B1 <= 0) return CFM_EINVAL;
+    SkWs w = sk_carve((void*)ws, B0, B1);
+    int n = B0 > B1 ? B0 : B1;
+    hipLaunchKernelGGL(sk_copy_potentials, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       w.st, w.u, w.v[0], w.v[1], B0, B1, u, v);
+    return cfm_status();
+}
+
+// Dense fp64 plan and <pi, M>.
+__global__ __launch_bounds__(256) void sk_plan_f64(const float* __restrict__ M, int B0, int B1,
+                                                   double inv_reg, const SkState* st,
+                                                   const double* __restrict__ u,
+                                                   const double* __restrict__ v0,
+                                                   const double* __restrict__ v1,
+                                                   double* __restrict__ pi,
+                                                   double* __restrict__ cost_out) {
+    const double* v = st->vfinal ? v1 : v0;
+    const size_t n = (size_t)B0 * B1;
+    double acc = 0.0;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const int i = (int)(k / B1), j = (int)(k - (size_t)i * B1);
+        const double c = (double)M[k];
+        const double p = exp(u[i] + v[j] - c * inv_reg);
+        if (pi) pi[k] = p;
+        acc += p * c;
+    }
+    if (cost_out) {
+        acc = wave_sum_d(acc);
+        __shared__ double red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(cost_out, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+extern "C" int cfm_sinkhorn_plan_f64(const float* M, int B0, int B1, float reg, const void* ws,
+                                     double* pi, void* stream) {
+    if (!M || !ws || !pi || B0 <= 0 || B1 <= 0 || !(reg > 0.f)) return CFM_EINVAL;
+    SkWs w = sk_carve((void*)ws, B0, B1);
+    hipLaunchKernelGGL(sk_plan_f64, dim3(2048), dim3(256), 0, (hipStream_t)stream, M, B0, B1,
+                       1.0 / (double)reg, w.st, w.u, w.v[0], w.v[1], pi, (double*)nullptr);
+    return cfm_status();
+}
+
+extern "C" int cfm_sinkhorn_cost_f64(const float* M, int B0, int B1, float reg, const void* ws,
+                                     double* out, void* stream) {
+    if (!M || !ws || !out || B0 <= 0 || B1 <= 0 || !(reg > 0.f)) return CFM_EINVAL;
+    SkWs w = sk_carve((void*)ws, B0, B1);
+    int rc = cfm_hip(hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream));
+    if (rc) return rc;
+    hipLaunchKernelGGL(sk_plan_f64, dim3(2048), dim3(256), 0, (hipStream_t)stream, M, B0, B1,
+                       1.0 / (double)reg, w.st, w.u, w.v[0], w.v[1], (double*)nullptr, out);
+    return cfm_status();
+}

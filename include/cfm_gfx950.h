@@ -1,0 +1,201 @@
+/*
+ * cfm_gfx950.h — C ABI of libcfm_gfx950.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the minibatch-OT coupling + CFM sampling hot path of
+ * TorchCFM (atong01/conditional-flow-matching).  The reference has no FFI of
+ * its own (it is pure Python); each entry point below replaces the third-party
+ * native routine or eager-op chain that the cited reference line executes.
+ * Citations are relative to the reference repository root.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (contiguous,
+ *     row-major) unless the parameter is documented "host";
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the
+ *     call returns without synchronising, EXCEPT cfm_assign_exact_f32 and
+ *     cfm_ode_*_mlp_f32 whose control flow is data dependent: they pump their
+ *     step kernels on `stream` and poll a few bytes of device state, so they
+ *     return only when the result is resident in the output buffers;
+ *   - no entry point allocates or frees device memory: scratch comes from the
+ *     caller through `ws` (size from cfm_workspace_bytes);
+ *   - return value: 0 = ok, <0 = invalid argument (CFM_E*), >0 = hipError_t;
+ *   - no exceptions cross the boundary, no global state except a lazily
+ *     initialised device-properties cache.
+ */
+#ifndef CFM_GFX950_H
+#define CFM_GFX950_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFM_ABI_VERSION 1
+
+/* error codes (negative) */
+#define CFM_EINVAL   (-1)  /* bad shape / null pointer / unsupported size      */
+#define CFM_EALIGN   (-2)  /* pointer not aligned as documented                */
+#define CFM_ENOCONV  (-3)  /* solver hit its step cap without a certificate    */
+#define CFM_ETIMEOUT (-4)  /* device state machine made no progress            */
+
+/* ops for cfm_workspace_bytes */
+#define CFM_OP_SINKHORN      1
+#define CFM_OP_ASSIGN        2
+#define CFM_OP_SAMPLE_DENSE  3
+#define CFM_OP_MLP           4
+#define CFM_OP_ODE           5
+
+/* variants for cfm_sample_xt_ut_f32 (reference class in parentheses) */
+#define CFM_VARIANT_ICFM   0  /* ConditionalFlowMatcher / ExactOT...          */
+#define CFM_VARIANT_SB     1  /* SchrodingerBridgeConditionalFlowMatcher      */
+#define CFM_VARIANT_TARGET 2  /* TargetConditionalFlowMatcher                 */
+#define CFM_VARIANT_VP     3  /* VariancePreservingConditionalFlowMatcher     */
+
+int cfm_abi_version(void);
+
+/* Bytes of device scratch an op needs for the given problem (0 on bad op). */
+size_t cfm_workspace_bytes(int op, int B0, int B1, int d);
+
+/* K1 — squared-Euclidean cost matrix  M[i,j] = sum_k (x0[i,k]-x1[j,k])^2.
+ * Replaces  torch.cdist(x0, x1) ** 2       torchcfm/optimal_transport.py:84
+ * (also :176, :297 with power 1 -> see cfm_euclid_cost_f32).
+ * If opt_max != NULL it receives max(M) (one float; for normalize_cost, :85-86).
+ * x0 [B0,d], x1 [B1,d], M [B0,B1], fp32. */
+int cfm_sqeuclid_cost_f32(const float* x0, const float* x1, int B0, int B1, int d,
+                          float* M, float* opt_max, void* stream);
+
+/* M[i] *= 1/(*maxval)   — `M / M.max()`     torchcfm/optimal_transport.py:86 */
+int cfm_scale_inv_f32(float* M, size_t n, const float* maxval, void* stream);
+
+/* In-place sqrt — Euclidean (power=1) cost for wasserstein(), :297-299. */
+int cfm_sqrt_inplace_f32(float* M, size_t n, void* stream);
+
+/* K5 — log-domain Sinkhorn with POT loop semantics (uniform marginals).
+ * Replaces  pot.sinkhorn(a, b, M, reg)      torchcfm/optimal_transport.py:51,87
+ * in its numerically stable form (POT method="sinkhorn_log"): u0 = 0,
+ *   v = log b - LSE_i(-M/reg + u),  u = log a - LSE_j(-M/reg + v),
+ * marginal check every `check_every` iterations (ii % check_every == 0):
+ * err = || sum_i exp(-M/reg + u + v) - b ||_2 ; stop when err < stop_thr or
+ * after max_iter iterations.  Outputs the potentials f = reg*u [B0],
+ * g = reg*v [B1] (fp32), *iters_done, *last_err (device scalars).
+ * ws: cfm_workspace_bytes(CFM_OP_SINKHORN,B0,B1,0) bytes, 16-byte aligned;
+ * it keeps the fp64 potentials (see cfm_sinkhorn_potentials_f64). */
+int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, int max_iter,
+                         float stop_thr, int check_every, float* f, float* g,
+                         int* iters_done, float* last_err, void* ws, void* stream);
+
+/* Copy the fp64 log-scalings u [B0], v [B1] left in `ws` by the last
+ * cfm_sinkhorn_log_f32 call on it. */
+int cfm_sinkhorn_potentials_f64(const void* ws, int B0, int B1, double* u, double* v,
+                                void* stream);
+
+/* Dense plan  pi[i,j] = exp(u_i + v_j - M[i,j]/reg)  in fp64 from the fp64
+ * log-scalings in `ws`  — what get_map() hands back to Python,
+ * torchcfm/optimal_transport.py:87 (return value of pot.sinkhorn). */
+int cfm_sinkhorn_plan_f64(const float* M, int B0, int B1, float reg, const void* ws,
+                          double* pi, void* stream);
+
+/* sum_ij pi_ij * M_ij — pot.sinkhorn2 value, torchcfm/optimal_transport.py:288.
+ * out: one double. */
+int cfm_sinkhorn_cost_f64(const float* M, int B0, int B1, float reg, const void* ws,
+                          double* out, void* stream);
+
+/* K4 — exact optimal assignment for uniform, equal-size marginals.
+ * Replaces  pot.emd(a, b, M)                torchcfm/optimal_transport.py:49,87
+ * and       scipy.optimize.linear_sum_assignment(M)                    :179.
+ * M [B,B] fp32.  perm[i] = column matched to row i (int32 [B]).
+ * *certified (device int) = 1 iff the fp64 dual certificate holds
+ * (complementary slackness + dual feasibility to 1e-10*max|M|);
+ * *total_cost (device double) = sum_i M[i,perm[i]];
+ * stats (device int32[8], may be NULL): {auction_rounds, arr_rounds,
+ *  free_rows_after_arr, sap_batches, sap_row_scans, total_row_scans, steps, 0}.
+ * ws: cfm_workspace_bytes(CFM_OP_ASSIGN,B,B,0) bytes. */
+int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,
+                         double* total_cost, int* stats, void* ws, void* stream);
+
+/* K6 (exact path) — draw n index pairs from the permutation plan.
+ * Replaces sample_map()                      torchcfm/optimal_transport.py:116-121
+ * for pi = P_perm / B:  np.random.choice over the flattened plan consumes n
+ * uniforms u01 (drawn by the caller from np.random) and returns, per draw,
+ * the first flat index whose cdf exceeds u:  i = floor(u*B) (cdf steps k/B),
+ * j = perm[i].  u01: device double[n];  i,j: device int64[n]. */
+int cfm_plan_sample_perm(const int* perm, const double* u01, int B, int n,
+                         int64_t* i, int64_t* j, void* stream);
+
+/* K6 (entropic path) — draw n index pairs from the dense Sinkhorn plan without
+ * materialising it: fp64 row sums of exp(u_i+v_j-M_ij/reg), row scan, inverse
+ * cdf in flattened (row-major) order, same searchsorted(side="right")
+ * semantics as np.random.choice              torchcfm/optimal_transport.py:116-121.
+ * ws: cfm_workspace_bytes(CFM_OP_SAMPLE_DENSE,B0,B1,0); `sk_ws` is the Sinkhorn
+ * workspace holding u,v. */
+int cfm_plan_sample_dense(const float* M, int B0, int B1, float reg, const void* sk_ws,
+                          const double* u01, int n, int64_t* i, int64_t* j, void* ws,
+                          void* stream);
+
+/* Same draw from an explicit fp64 plan pi [B0,B1] (API path sample_map(pi,...)
+ * with a caller-supplied plan; entries of `pi` may be zeroed between calls to
+ * implement replace=False exactly as numpy does). */
+int cfm_plan_sample_pi_f64(const double* pi, int B0, int B1, const double* u01, int n,
+                           int64_t* i, int64_t* j, void* ws, void* stream);
+
+/* K7+K8 — fused gather + probability-path sample + conditional flow.
+ * Replaces x0[i], x1[j]                      torchcfm/optimal_transport.py:145
+ * and the eager chain of                     torchcfm/conditional_flow_matching.py
+ *   :82-83,126-129,153-154 (ICFM/OT), :446,474-478 (SB),
+ *   :349-350,368,393-394 (Target), :588-589,617-618 (VP)
+ * with the reference's operation order and no FMA contraction (bit-equal to
+ * eager fp32).  i, j may be NULL (identity).  t [B], eps [B,d] (eps may be
+ * NULL only when sigma terms vanish is NOT assumed: pass eps always).
+ * VP: c0 = cos(pi/2 t), c1 = sin(pi/2 t) are passed in ([B] each, computed by
+ * the caller's tensor library so they match its libm bit for bit); NULL for
+ * the other variants.  `sigma` is the Python-side value (double): the kernel
+ * uses (float)sigma and, for TARGET, (float)(1.0 - sigma) exactly as eager
+ * PyTorch casts Python scalars.  Outputs xt, ut [B,d]; x0g, x1g (may be NULL)
+ * receive the gathered pairs. */
+int cfm_sample_xt_ut_f32(int variant, const float* x0, const float* x1,
+                         const int64_t* i, const int64_t* j, const float* t,
+                         const float* eps, double sigma, const float* c0,
+                         const float* c1, int B, int d, float* xt, float* ut,
+                         float* x0g, float* x1g, void* stream);
+
+/* Row gather  out[b,:] = src[idx[b],:]  (labels y0[i], y1[j]; :215-218).
+ * elem_bytes = bytes per row. */
+int cfm_gather_rows(const void* src, const int64_t* idx, int n, size_t row_bytes,
+                    void* out, void* stream);
+
+/* K10 — MLP vector field  Linear-SELU x3 + Linear  with the time column folded
+ * in.  Replaces MLP.forward + torch_wrapper.forward
+ *   torchcfm/models/models.py:10-21, torchcfm/utils.py:51-52.
+ * x [B,d]; t: device float, either one scalar (t_per_row=0) or [B]
+ * (t_per_row=1), or NULL when the net is not time varying;
+ * W[l] [out_l, in_l] row-major (torch.nn.Linear layout), b[l] [out_l];
+ * dims[n_layers+1] (host) = {d(+1 if time varying), w, ..., out};
+ * W, b: host arrays of device pointers.  out [B, dims[n_layers]].
+ * ws: cfm_workspace_bytes(CFM_OP_MLP, B, max width, 0). */
+int cfm_mlp_forward_f32(const float* x, const float* t, int t_per_row,
+                        const float* const* W, const float* const* b,
+                        const int* dims, int n_layers, int B, float* out, void* ws,
+                        void* stream);
+
+/* K11 — ODE solve of dx/dt = MLP([x, t]) on a time grid (torchdyn-style).
+ * Replaces NeuralODE(torch_wrapper(model), solver=...).trajectory(x, t_span)
+ *   call sites: examples/2D_tutorials/Flow_matching_tutorial.ipynb cells 11/16,
+ *   examples/images/cifar10/utils_cifar.py:63-68.
+ * t_span: host float[n_t].  traj: device [n_t,B,d].
+ * euler: fixed steps on t_span.  dopri5: adaptive Dormand-Prince 5(4), one
+ * global RMS error norm over the batch, every t_span point is a step end.
+ * n_steps/nfe: host ints (accepted+rejected steps, function evaluations). */
+int cfm_ode_euler_mlp_f32(const float* const* W, const float* const* b, const int* dims,
+                          int n_layers, const float* x0, int B, const float* t_span,
+                          int n_t, float* traj, int* nfe, void* ws, void* stream);
+int cfm_ode_dopri5_mlp_f32(const float* const* W, const float* const* b, const int* dims,
+                           int n_layers, const float* x0, int B, const float* t_span,
+                           int n_t, float atol, float rtol, float* traj, int* n_steps,
+                           int* nfe, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFM_GFX950_H */
+
