@@ -46,23 +46,23 @@ __device__ __forceinline__ RowCoef row_coef(float t, float sigma_f, float oms_f,
 
 template <int VARIANT>
 __device__ __forceinline__ void point(const RowCoef& r, float oms_f, float a0, float a1, float e,
-                                      float& xt, float& ut) {
+                                      bool have_xt, float xin, float& xt, float& ut) {
     const float HALF_PI = 1.5707963267948966f;
     if (VARIANT == CFM_VARIANT_ICFM) {
         const float mu = __fadd_rn(__fmul_rn(r.c1, a1), __fmul_rn(r.c0, a0));
-        xt = __fadd_rn(mu, __fmul_rn(r.sig, e));
+        xt = have_xt ? xin : __fadd_rn(mu, __fmul_rn(r.sig, e));
         ut = __fsub_rn(a1, a0);
     } else if (VARIANT == CFM_VARIANT_SB) {
         const float mu = __fadd_rn(__fmul_rn(r.c1, a1), __fmul_rn(r.c0, a0));
-        xt = __fadd_rn(mu, __fmul_rn(r.sig, e));
+        xt = have_xt ? xin : __fadd_rn(mu, __fmul_rn(r.sig, e));
         ut = __fsub_rn(__fadd_rn(__fmul_rn(r.a, __fsub_rn(xt, mu)), a1), a0);
     } else if (VARIANT == CFM_VARIANT_TARGET) {
         const float mu = __fmul_rn(r.c1, a1);
-        xt = __fadd_rn(mu, __fmul_rn(r.sig, e));
+        xt = have_xt ? xin : __fadd_rn(mu, __fmul_rn(r.sig, e));
         ut = __fdiv_rn(__fsub_rn(a1, __fmul_rn(oms_f, xt)), r.a);
     } else {
         const float mu = __fadd_rn(__fmul_rn(r.c0, a0), __fmul_rn(r.c1, a1));
-        xt = __fadd_rn(mu, __fmul_rn(r.sig, e));
+        xt = have_xt ? xin : __fadd_rn(mu, __fmul_rn(r.sig, e));
         ut = __fmul_rn(HALF_PI, __fsub_rn(__fmul_rn(r.c0, a1), __fmul_rn(r.c1, a0)));
     }
 }
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void xt_ut_kernel(const float* __restrict__ x0
                                                     const float* __restrict__ t,
                                                     const float* __restrict__ eps, float sigma_f,
                                                     float oms_f, const float* __restrict__ c0p,
-                                                    const float* __restrict__ c1p, int B, int d,
+                                                    const float* __restrict__ c1p,
+                                                    const float* __restrict__ xt_in, int B, int d,
                                                     float* __restrict__ xt, float* __restrict__ ut,
                                                     float* __restrict__ x0g,
                                                     float* __restrict__ x1g) {
@@ -92,21 +93,25 @@ __global__ __launch_bounds__(256) void xt_ut_kernel(const float* __restrict__ x0
         if (VEC) {
             const float4 a0 = *reinterpret_cast<const float4*>(x0 + r0 * d + k);
             const float4 a1 = *reinterpret_cast<const float4*>(x1 + r1 * d + k);
-            const float4 e = *reinterpret_cast<const float4*>(eps + o);
+            const float4 e = eps ? *reinterpret_cast<const float4*>(eps + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool hx = xt_in != nullptr;
+            const float4 xi = hx ? *reinterpret_cast<const float4*>(xt_in + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 vx, vu;
-            point<VARIANT>(rc, oms_f, a0.x, a1.x, e.x, vx.x, vu.x);
-            point<VARIANT>(rc, oms_f, a0.y, a1.y, e.y, vx.y, vu.y);
-            point<VARIANT>(rc, oms_f, a0.z, a1.z, e.z, vx.z, vu.z);
-            point<VARIANT>(rc, oms_f, a0.w, a1.w, e.w, vx.w, vu.w);
-            *reinterpret_cast<float4*>(xt + o) = vx;
+            point<VARIANT>(rc, oms_f, a0.x, a1.x, e.x, hx, xi.x, vx.x, vu.x);
+            point<VARIANT>(rc, oms_f, a0.y, a1.y, e.y, hx, xi.y, vx.y, vu.y);
+            point<VARIANT>(rc, oms_f, a0.z, a1.z, e.z, hx, xi.z, vx.z, vu.z);
+            point<VARIANT>(rc, oms_f, a0.w, a1.w, e.w, hx, xi.w, vx.w, vu.w);
+            if (xt) *reinterpret_cast<float4*>(xt + o) = vx;
             *reinterpret_cast<float4*>(ut + o) = vu;
             if (x0g) *reinterpret_cast<float4*>(x0g + o) = a0;
             if (x1g) *reinterpret_cast<float4*>(x1g + o) = a1;
         } else {
-            const float a0 = x0[r0 * d + k], a1 = x1[r1 * d + k], e = eps[o];
+            const float a0 = x0[r0 * d + k], a1 = x1[r1 * d + k], e = eps ? eps[o] : 0.f;
+            const bool hx = xt_in != nullptr;
             float vx, vu;
-            point<VARIANT>(rc, oms_f, a0, a1, e, vx, vu);
-            xt[o] = vx; ut[o] = vu;
+            point<VARIANT>(rc, oms_f, a0, a1, e, hx, hx ? xt_in[o] : 0.f, vx, vu);
+            if (xt) xt[o] = vx;
+            ut[o] = vu;
             if (x0g) x0g[o] = a0;
             if (x1g) x1g[o] = a1;
         }
@@ -116,17 +121,18 @@ __global__ __launch_bounds__(256) void xt_ut_kernel(const float* __restrict__ x0
 template <int VARIANT>
 static void launch_xt_ut(bool vec, int blocks, hipStream_t s, const float* x0, const float* x1,
                          const int64_t* i, const int64_t* j, const float* t, const float* eps,
-                         float sf, float of, const float* c0, const float* c1, int B, int d, float* xt,
+                         float sf, float of, const float* c0, const float* c1, const float* xin, int B, int d, float* xt,
                          float* ut, float* x0g, float* x1g) {
-    if (vec) hipLaunchKernelGGL((xt_ut_kernel<VARIANT, true>), dim3(blocks), dim3(256), 0, s, x0, x1, i, j, t, eps, sf, of, c0, c1, B, d, xt, ut, x0g, x1g);
-    else     hipLaunchKernelGGL((xt_ut_kernel<VARIANT, false>), dim3(blocks), dim3(256), 0, s, x0, x1, i, j, t, eps, sf, of, c0, c1, B, d, xt, ut, x0g, x1g);
+    if (vec) hipLaunchKernelGGL((xt_ut_kernel<VARIANT, true>), dim3(blocks), dim3(256), 0, s, x0, x1, i, j, t, eps, sf, of, c0, c1, xin, B, d, xt, ut, x0g, x1g);
+    else     hipLaunchKernelGGL((xt_ut_kernel<VARIANT, false>), dim3(blocks), dim3(256), 0, s, x0, x1, i, j, t, eps, sf, of, c0, c1, xin, B, d, xt, ut, x0g, x1g);
 }
 
 extern "C" int cfm_sample_xt_ut_f32(int variant, const float* x0, const float* x1, const int64_t* i,
                                     const int64_t* j, const float* t, const float* eps, double sigma,
-                                    const float* c0, const float* c1, int B, int d, float* xt,
-                                    float* ut, float* x0g, float* x1g, void* stream) {
-    if (!x0 || !x1 || !t || !eps || !xt || !ut || B < 0 || d <= 0) return CFM_EINVAL;
+                                    const float* c0, const float* c1, const float* xin, int B, int d,
+                                    float* xt, float* ut, float* x0g, float* x1g, void* stream) {
+    if (!x0 || !x1 || !t || !ut || B < 0 || d <= 0) return CFM_EINVAL;
+    if (!xin && (!eps || !xt)) return CFM_EINVAL;
     if (variant < 0 || variant > 3) return CFM_EINVAL;
     if (variant == CFM_VARIANT_VP && (!c0 || !c1)) return CFM_EINVAL;
     if (B == 0) return 0;
@@ -134,15 +140,15 @@ extern "C" int cfm_sample_xt_ut_f32(int variant, const float* x0, const float* x
     const float sf = (float)sigma;
     const float of = (float)(1.0 - sigma);
     auto al = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
-    const bool vec = (d % 4 == 0) && al(x0) && al(x1) && al(eps) && al(xt) && al(ut) && al(x0g) && al(x1g);
+    const bool vec = (d % 4 == 0) && al(x0) && al(x1) && al(eps) && al(xt) && al(ut) && al(x0g) && al(x1g) && al(xin);
     const size_t total = (size_t)B * (size_t)(vec ? d / 4 : d);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     switch (variant) {
-        case CFM_VARIANT_ICFM:   launch_xt_ut<CFM_VARIANT_ICFM>(vec, blocks, s, x0, x1, i, j, t, eps, sf, of, c0, c1, B, d, xt, ut, x0g, x1g); break;
-        case CFM_VARIANT_SB:     launch_xt_ut<CFM_VARIANT_SB>(vec, blocks, s, x0, x1, i, j, t, eps, sf, of, c0, c1, B, d, xt, ut, x0g, x1g); break;
-        case CFM_VARIANT_TARGET: launch_xt_ut<CFM_VARIANT_TARGET>(vec, blocks, s, x0, x1, i, j, t, eps, sf, of, c0, c1, B, d, xt, ut, x0g, x1g); break;
-        default:                 launch_xt_ut<CFM_VARIANT_VP>(vec, blocks, s, x0, x1, i, j, t, eps, sf, of, c0, c1, B, d, xt, ut, x0g, x1g); break;
+        case CFM_VARIANT_ICFM:   launch_xt_ut<CFM_VARIANT_ICFM>(vec, blocks, s, x0, x1, i, j, t, eps, sf, of, c0, c1, xin, B, d, xt, ut, x0g, x1g); break;
+        case CFM_VARIANT_SB:     launch_xt_ut<CFM_VARIANT_SB>(vec, blocks, s, x0, x1, i, j, t, eps, sf, of, c0, c1, xin, B, d, xt, ut, x0g, x1g); break;
+        case CFM_VARIANT_TARGET: launch_xt_ut<CFM_VARIANT_TARGET>(vec, blocks, s, x0, x1, i, j, t, eps, sf, of, c0, c1, xin, B, d, xt, ut, x0g, x1g); break;
+        default:                 launch_xt_ut<CFM_VARIANT_VP>(vec, blocks, s, x0, x1, i, j, t, eps, sf, of, c0, c1, xin, B, d, xt, ut, x0g, x1g); break;
     }
     return cfm_status();
 }

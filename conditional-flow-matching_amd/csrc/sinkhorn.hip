@@ -299,7 +299,17 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, i
     const double loga = log(a), logb = log(b);
     const int rows_per_wg = 8;
     const int row_wgs = (B0 + rows_per_wg - 1) / rows_per_wg;
-    const int v_in_lds = ((size_t)B1 * 8 <= 128 * 1024) ? 1 : 0;
+    int v_in_lds = ((size_t)B1 * 8 <= 128 * 1024) ? 1 : 0;
+    if (v_in_lds && (size_t)B1 * 8 > 48 * 1024) {
+        static int raised = 0;   // dynamic LDS above the 64 KiB default needs the attribute
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)sk_row_pass,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            raised = (e == hipSuccess) ? 1 : -1;
+            (void)hipGetLastError();
+        }
+        if (raised < 0) v_in_lds = 0;
+    }
     const size_t lds = v_in_lds ? (size_t)B1 * 8 : 0;
 
     int n = B0 > B1 ? B0 : B1;
@@ -307,6 +317,11 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, i
                        B0, B1, max_iter);
     // iteration ii: v^(ii) -> v[ii&1];  error of iteration ii-1 is measured by
     // the column pass of iteration ii and decided at the start of its row pass.
+    // Short runs are enqueued in one go (no host sync); for very long caps
+    // (wasserstein() passes numItermax=1e7) the host polls `done` every 512
+    // iterations so the queue stays bounded.
+    const bool poll = max_iter > 4096;
+    int host_done = 0;
     for (int ii = 0; ii <= max_iter; ++ii) {
         const int check = (ii >= 1) && (((ii - 1) % check_every) == 0);
         const int slot = ii & 1;
@@ -320,6 +335,13 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, i
         hipLaunchKernelGGL(sk_row_pass, dim3(row_wgs), dim3(256), lds, s, M, B0, B1, inv_reg, loga,
                            w.st, w.v[ii & 1], w.u, rows_per_wg, check, slot, (double)stop_thr, ii,
                            vec, v_in_lds);
+        if (poll && (ii & 511) == 511) {
+            int rc = cfm_hip(hipMemcpyAsync(&host_done, &w.st->done, sizeof(int), hipMemcpyDeviceToHost, s));
+            if (rc) return rc;
+            rc = cfm_hip(hipStreamSynchronize(s));
+            if (rc) return rc;
+            if (host_done) break;
+        }
     }
     const int pending = (max_iter >= 1) && (((max_iter - 1) % check_every) == 0);
     hipLaunchKernelGGL(sk_finish, dim3((n + 255) / 256), dim3(256), 0, s, w.st, w.u, w.v[0], w.v[1],

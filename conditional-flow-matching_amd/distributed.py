@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, no collective inside the path.
+
+The reference's DDP script solves OT on each rank's local batch only
+(examples/images/cifar10/train_cifar10_ddp.py:74,92,167-169); the only exchange the north
+star names is one all-gather of the final samples over xGMI (RCCL).  ``backend="nccl"`` is
+RCCL on ROCm; ``gloo`` is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, local, world
+
+
+def shard_seed(base, rank):
+    """Each rank draws its own minibatch: seed 1000 + rank style."""
+    return int(base) + int(rank)
+
+
+def all_gather_samples(x):
+    """[B,d] per rank -> [world*B, d] on every rank (single collective; identity at world=1)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    x = x.contiguous()
+    out = torch.empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
+                      device=x.device)
+    dist.all_gather_into_tensor(out, x)
+    return out
+
+
+def max_over_ranks(value, device=None):
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    dev = device or (torch.device("cuda", torch.cuda.current_device())
+                     if dist.get_backend() == "nccl" else torch.device("cpu"))
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,104 @@
+"""MLP vector field — drop-in for ``torchcfm.models.MLP`` (ref: torchcfm/models/models.py:4-21).
+
+Same module tree (``self.net = Sequential(Linear, SELU, Linear, SELU, Linear, SELU,
+Linear)``) so reference ``state_dict``s load unchanged.  Training (autograd) goes
+through PyTorch-ROCm as the north star prescribes; the inference forward —
+what the ODE solve evaluates hundreds of times — runs on the fp32-MFMA HIP
+kernels (``cfm_mlp_forward_f32``).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+class MLP(torch.nn.Module):
+    def __init__(self, dim, out_dim=None, w=64, time_varying=False):
+        super().__init__()
+        self.time_varying = time_varying
+        if out_dim is None:
+            out_dim = dim
+        self.net = torch.nn.Sequential(
+            torch.nn.Linear(dim + (1 if time_varying else 0), w),
+            torch.nn.SELU(),
+            torch.nn.Linear(w, w),
+            torch.nn.SELU(),
+            torch.nn.Linear(w, w),
+            torch.nn.SELU(),
+            torch.nn.Linear(w, out_dim),
+        )
+
+    # ---- HIP path -----------------------------------------------------------
+    def _linears(self):
+        return [m for m in self.net if isinstance(m, torch.nn.Linear)]
+
+    def hip_params(self, device=None):
+        """(W_ptrs, b_ptrs, dims, keepalive) as ctypes arrays for the C ABI."""
+        dev = device or _lib.require_gpu()
+        lins = self._linears()
+        Ws = [_lib.to_dev_f32(l.weight, dev) for l in lins]
+        bs = [_lib.to_dev_f32(l.bias, dev) for l in lins]
+        n = len(lins)
+        Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in Ws])
+        bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs])
+        dims = (ctypes.c_int * (n + 1))(*([lins[0].in_features] + [l.out_features for l in lins]))
+        return Wp, bp, dims, (Ws, bs)
+
+    @torch.no_grad()
+    def forward_hip(self, x, t=None):
+        """Inference forward on the HIP kernels.
+
+        x: [B, dim] (the time column NOT concatenated) with ``t`` a 0-dim / [B] tensor or
+        float when the net is time varying; or x: [B, dim(+1)] with t=None (reference layout,
+        time already in the last column — then the net is evaluated as a plain MLP).
+        """
+        lib = _lib.load()
+        dev = _lib.require_gpu()
+        Wp, bp, dims, keep = self.hip_params(dev)
+        n = len(dims) - 1
+        xd = _lib.to_dev_f32(x, dev)
+        B = xd.shape[0]
+        td, per_row = None, 0
+        if t is not None:
+            tt = torch.as_tensor(t, dtype=torch.float32)
+            per_row = 1 if tt.numel() == B and tt.dim() > 0 and B > 1 else 0
+            td = _lib.to_dev_f32(tt.reshape(-1), dev)
+            if xd.shape[1] != dims[0] - 1:
+                raise ValueError("x must not contain the time column when t is given")
+        else:
+            if xd.shape[1] != dims[0]:
+                raise ValueError(f"expected {dims[0]} input features, got {xd.shape[1]}")
+        if t is None:
+            # plain MLP over the full input: describe it to the kernel as "no time column"
+            use_dims = dims
+        else:
+            use_dims = dims
+        maxw = max(dims[1:n]) if n > 1 else 1
+        ws = _lib.workspace(_lib.OP_MLP, B, maxw, 0, dev)
+        out = torch.empty((B, dims[n]), dtype=torch.float32, device=dev)
+        check(lib.cfm_mlp_forward_f32(ptr(xd), ptr(td), per_row, Wp, bp, use_dims, n, B, ptr(out),
+                                      ptr(ws), stream_ptr()), "cfm_mlp_forward_f32")
+        return out.to(x.device)
+
+    def forward(self, x):
+        # ref:20-21.  Autograd path = PyTorch-ROCm; no-grad inference = HIP kernels.
+        if torch.is_grad_enabled() or not torch.cuda.is_available():
+            if not x.is_cuda and not torch.is_grad_enabled():
+                _lib.require_gpu()  # raises: no silent CPU inference path
+            return self.net(x)
+        return self.forward_hip(x)
+
+
+class GradModel(torch.nn.Module):
+    """Action-matching helper (ref: torchcfm/models/models.py:24-32); autograd only."""
+
+    def __init__(self, action):
+        super().__init__()
+        self.action = action
+
+    def forward(self, x):
+        x = x.requires_grad_(True)
+        grad = torch.autograd.grad(torch.sum(self.action(x)), x, create_graph=True)[0]
+        return grad[:, :-1]

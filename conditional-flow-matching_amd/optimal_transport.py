@@ -1,0 +1,394 @@
+"""MI355X-native minibatch OT coupling — drop-in for ``torchcfm.optimal_transport``.
+
+Same class / method names, arguments, return types and error behaviour as the
+reference (``/root/reference/torchcfm/optimal_transport.py``, cited per method as
+``ref:LINE``); every numerical step runs in the gfx950 HIP kernels behind the C
+ABI (``include/cfm_gfx950.h``).  What changes underneath:
+
+* the cost matrix never leaves HBM (ref:87 copies it to the host every step);
+* ``method="exact"`` is solved by the device auction + shortest-augmenting-path
+  solver (``cfm_assign_exact_f32``) instead of POT's network simplex (ref:49);
+* ``method="sinkhorn"`` runs the log-domain iteration (``cfm_sinkhorn_log_f32``)
+  instead of POT's kernel-space Sinkhorn-Knopp (ref:51) — same loop semantics,
+  no underflow, so the uniform-plan fallback (ref:93-96) only triggers on NaNs;
+* ``sample_plan`` never materialises the B x B plan: the host draws the same
+  ``np.random`` uniforms ``np.random.choice`` would consume (ref:118-120) and the
+  device does the inverse-cdf lookup (``cfm_plan_sample_perm`` / ``_dense``).
+
+CPU tensors are accepted (they are moved to the GPU and the results moved back)
+so the reference's own tests run unchanged; without a GPU every call raises.
+"""
+import math
+import warnings
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CfmBackendError, check, ptr, stream_ptr
+
+_SINKHORN_MAX_ITER = 1000      # POT ot.sinkhorn default numItermax
+_SINKHORN_STOP_THR = 1e-9      # POT default stopThr
+_SINKHORN_CHECK_EVERY = 10     # POT checks the marginal every 10 iterations
+
+
+def _flatten2(x):
+    return x.reshape(x.shape[0], -1) if x.dim() > 2 else x
+
+
+# --------------------------------------------------------------------------- device steps
+def cost_matrix(x0, x1, squared=True, normalize=False):
+    """[B0,B1] fp32 cost on the GPU (ref:80-86).  x0/x1: device fp32 [B,d]."""
+    lib = _lib.load()
+    B0, B1, d = x0.shape[0], x1.shape[0], x0.shape[1]
+    if x1.shape[1] != d:
+        raise ValueError("x0 and x1 must have the same feature size")
+    M = torch.empty((B0, B1), dtype=torch.float32, device=x0.device)
+    mx = torch.empty(1, dtype=torch.float32, device=x0.device) if normalize else None
+    check(lib.cfm_sqeuclid_cost_f32(ptr(x0), ptr(x1), B0, B1, d, ptr(M), ptr(mx), stream_ptr()),
+          "cfm_sqeuclid_cost_f32")
+    if not squared:
+        check(lib.cfm_sqrt_inplace_f32(ptr(M), M.numel(), stream_ptr()), "cfm_sqrt_inplace_f32")
+        if normalize:  # max of the un-squared cost
+            mx = torch.sqrt(mx)
+    if normalize:
+        check(lib.cfm_scale_inv_f32(ptr(M), M.numel(), ptr(mx), stream_ptr()), "cfm_scale_inv_f32")
+    return M
+
+
+def assign_exact(M, return_info=False):
+    """Optimal permutation of a square fp32 cost matrix on the GPU (int32 [B])."""
+    lib = _lib.load()
+    B = M.shape[0]
+    if M.shape[1] != B:
+        raise NotImplementedError(
+            "exact OT on the gfx950 backend needs equal batch sizes (uniform marginals -> "
+            f"assignment problem); got {tuple(M.shape)}")
+    dev = M.device
+    perm = torch.empty(B, dtype=torch.int32, device=dev)
+    cert = torch.zeros(1, dtype=torch.int32, device=dev)
+    tot = torch.zeros(1, dtype=torch.float64, device=dev)
+    stats = torch.zeros(8, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
+    check(lib.cfm_assign_exact_f32(ptr(M), B, ptr(perm), ptr(cert), ptr(tot), ptr(stats), ptr(ws),
+                                   stream_ptr()), "cfm_assign_exact_f32")
+    info = None
+    if B > 0:
+        c, s, t = cert.cpu(), stats.cpu(), tot.cpu()
+        if int(c[0]) != 1:
+            raise CfmBackendError("exact assignment finished without an optimality certificate")
+        info = {"certified": True, "total_cost": float(t[0]), "stats": s.tolist()}
+    return (perm, info) if return_info else perm
+
+
+class SinkhornResult:
+    __slots__ = ("f", "g", "iters", "err", "ws", "reg", "M")
+
+
+def sinkhorn_log(M, reg, max_iter=_SINKHORN_MAX_ITER, stop_thr=_SINKHORN_STOP_THR,
+                 check_every=_SINKHORN_CHECK_EVERY):
+    """Log-domain Sinkhorn on the GPU; potentials stay resident (fp64) in the workspace."""
+    lib = _lib.load()
+    B0, B1 = M.shape
+    dev = M.device
+    r = SinkhornResult()
+    r.f = torch.empty(B0, dtype=torch.float32, device=dev)
+    r.g = torch.empty(B1, dtype=torch.float32, device=dev)
+    r.iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    r.err = torch.zeros(1, dtype=torch.float32, device=dev)
+    r.ws = _lib.workspace(_lib.OP_SINKHORN, B0, B1, 0, dev)
+    r.reg, r.M = float(reg), M
+    check(lib.cfm_sinkhorn_log_f32(ptr(M), B0, B1, float(reg), int(max_iter), float(stop_thr),
+                                   int(check_every), ptr(r.f), ptr(r.g), ptr(r.iters), ptr(r.err),
+                                   ptr(r.ws), stream_ptr()), "cfm_sinkhorn_log_f32")
+    return r
+
+
+def sinkhorn_plan(r):
+    lib = _lib.load()
+    B0, B1 = r.M.shape
+    pi = torch.empty((B0, B1), dtype=torch.float64, device=r.M.device)
+    check(lib.cfm_sinkhorn_plan_f64(ptr(r.M), B0, B1, r.reg, ptr(r.ws), ptr(pi), stream_ptr()),
+          "cfm_sinkhorn_plan_f64")
+    return pi
+
+
+def _u01_to_device(u, dev):
+    return torch.from_numpy(np.ascontiguousarray(u, dtype=np.float64)).to(dev)
+
+
+def sample_perm(perm, u01, B):
+    lib = _lib.load()
+    n = u01.numel()
+    i = torch.empty(n, dtype=torch.int64, device=perm.device)
+    j = torch.empty(n, dtype=torch.int64, device=perm.device)
+    check(lib.cfm_plan_sample_perm(ptr(perm), ptr(u01), B, n, ptr(i), ptr(j), stream_ptr()),
+          "cfm_plan_sample_perm")
+    return i, j
+
+
+def sample_dense(r, u01):
+    lib = _lib.load()
+    B0, B1 = r.M.shape
+    n = u01.numel()
+    dev = r.M.device
+    i = torch.empty(n, dtype=torch.int64, device=dev)
+    j = torch.empty(n, dtype=torch.int64, device=dev)
+    ws = _lib.workspace(_lib.OP_SAMPLE_DENSE, B0, B1, 0, dev)
+    check(lib.cfm_plan_sample_dense(ptr(r.M), B0, B1, r.reg, ptr(r.ws), ptr(u01), n, ptr(i), ptr(j),
+                                    ptr(ws), stream_ptr()), "cfm_plan_sample_dense")
+    return i, j
+
+
+def sample_pi(pi_dev, u01):
+    lib = _lib.load()
+    B0, B1 = pi_dev.shape
+    n = u01.numel()
+    dev = pi_dev.device
+    i = torch.empty(n, dtype=torch.int64, device=dev)
+    j = torch.empty(n, dtype=torch.int64, device=dev)
+    ws = _lib.workspace(_lib.OP_SAMPLE_DENSE, B0, B1, 0, dev)
+    check(lib.cfm_plan_sample_pi_f64(ptr(pi_dev), B0, B1, ptr(u01), n, ptr(i), ptr(j), ptr(ws),
+                                     stream_ptr()), "cfm_plan_sample_pi_f64")
+    return i, j
+
+
+def gather_rows(src, idx):
+    """src[idx] along dim 0 on the GPU (src: contiguous device tensor, idx: device int64)."""
+    lib = _lib.load()
+    src = src.contiguous()
+    n = idx.numel()
+    out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    row_bytes = src.element_size() * int(np.prod(src.shape[1:], dtype=np.int64)) if src.dim() > 1 \
+        else src.element_size()
+    check(lib.cfm_gather_rows(ptr(src), ptr(idx), n, row_bytes, ptr(out), stream_ptr()),
+          "cfm_gather_rows")
+    return out
+
+
+# --------------------------------------------------------------------------- public API
+class OTPlanSampler:
+    """OTPlanSampler implements sampling coordinates according to an OT plan (wrt squared
+    Euclidean cost) with different implementations of the plan calculation (ref:11-13)."""
+
+    def __init__(
+        self,
+        method: str,
+        reg: float = 0.05,
+        reg_m: float = 1.0,
+        normalize_cost: bool = False,
+        num_threads: Union[int, str] = 1,
+        warn: bool = True,
+    ) -> None:
+        # ref:15-61.  num_threads is accepted for signature compatibility (the device
+        # solver has no host thread pool).
+        if method not in ("exact", "sinkhorn", "unbalanced", "partial"):
+            raise ValueError(f"Unknown method: {method}")
+        self.method = method
+        self.reg = reg
+        self.reg_m = reg_m
+        self.normalize_cost = normalize_cost
+        self.num_threads = num_threads
+        self.warn = warn
+        self._last = None  # diagnostics of the most recent solve
+
+    # ---- device-resident solve (no host plan) ----
+    def _prepare(self, x0, x1):
+        dev = _lib.require_gpu()
+        a = _lib.to_dev_f32(_flatten2(x0), dev)
+        b = _lib.to_dev_f32(_flatten2(x1), dev)
+        M = cost_matrix(a, b, squared=True, normalize=self.normalize_cost)
+        return dev, M
+
+    def _solve(self, x0, x1):
+        """-> ("perm", perm) or ("dense", SinkhornResult)."""
+        if self.method in ("unbalanced", "partial"):
+            raise NotImplementedError(
+                f"OTPlanSampler(method={self.method!r}) is not built on the gfx950 backend yet "
+                "(SURVEY.md §8(f) rank 4); use 'exact' or 'sinkhorn'.")
+        dev, M = self._prepare(x0, x1)
+        if self.method == "exact":
+            perm, info = assign_exact(M, return_info=True)
+            self._last = info
+            return "perm", perm, M
+        r = sinkhorn_log(M, self.reg)
+        self._last = r
+        return "dense", r, M
+
+    def get_map(self, x0, x1):
+        """Compute the OT plan between a source and a target minibatch (ref:63-97).
+
+        Returns a NumPy float64 array of shape (bs, bs), like the reference.
+        """
+        kind, sol, M = self._solve(x0, x1)
+        if kind == "perm":
+            B = M.shape[0]
+            p = np.zeros((B, B), dtype=np.float64)
+            p[np.arange(B), sol.cpu().numpy().astype(np.int64)] = 1.0 / B
+        else:
+            p = sinkhorn_plan(sol).cpu().numpy()
+        if not np.all(np.isfinite(p)):   # ref:88-92
+            print("ERROR: p is not finite")
+            print(p)
+            print("Cost mean, max", M.mean(), M.max())
+            print(x0, x1)
+        if np.abs(p.sum()) < 1e-8:       # ref:93-96
+            if self.warn:
+                warnings.warn("Numerical errors in OT plan, reverting to uniform plan.")
+            p = np.ones_like(p) / p.size
+        return p
+
+    def sample_map(self, pi, batch_size, replace=True):
+        r"""Draw source and target samples from pi $(x,z) \sim \pi$ (ref:99-121).
+
+        ``pi`` is a NumPy plan; the uniforms come from the global ``np.random`` state exactly
+        as ``np.random.choice(..., p=p, size=batch_size, replace=replace)`` consumes them; the
+        cdf search runs on the GPU.
+        """
+        dev = _lib.require_gpu()
+        pi = np.asarray(pi)
+        B0, B1 = pi.shape
+        pi_dev = torch.from_numpy(np.ascontiguousarray(pi, dtype=np.float64)).to(dev)
+        if replace:
+            u = _u01_to_device(np.random.random_sample(batch_size), dev)
+            i, j = sample_pi(pi_dev, u)
+            return i.cpu().numpy(), j.cpu().numpy()
+        # replace=False: numpy's rejection loop (legacy RandomState.choice), cdf on the device
+        if batch_size > int(np.count_nonzero(pi > 0)):
+            raise ValueError("Fewer non-zero entries in p than size")
+        lib = _lib.load()
+        pi_dev = pi_dev.clone()
+        found = np.zeros(batch_size, dtype=np.int64)
+        n_uniq = 0
+        while n_uniq < batch_size:
+            x = np.random.random_sample(batch_size - n_uniq)
+            if n_uniq > 0:
+                fl = torch.from_numpy(found[:n_uniq].copy()).to(dev)
+                check(lib.cfm_plan_zero_entries_f64(ptr(pi_dev), ptr(fl), n_uniq, stream_ptr()),
+                      "cfm_plan_zero_entries_f64")
+            i, j = sample_pi(pi_dev, _u01_to_device(x, dev))
+            new = (i * B1 + j).cpu().numpy()
+            _, unique_indices = np.unique(new, return_index=True)
+            unique_indices.sort()
+            new = new.take(unique_indices)
+            found[n_uniq:n_uniq + new.size] = new
+            n_uniq += new.size
+        return np.divmod(found, B1)
+
+    def _sample_indices(self, x0, x1, replace=True):
+        """Device int64 index pairs drawn from the plan of (x0, x1), plus the device copies."""
+        n = x0.shape[0]
+        if not replace:
+            pi = self.get_map(x0, x1)
+            i, j = self.sample_map(pi, n, replace=False)
+            dev = _lib.require_gpu()
+            return torch.from_numpy(i).to(dev), torch.from_numpy(j).to(dev)
+        kind, sol, M = self._solve(x0, x1)
+        dev = M.device
+        if kind == "dense":
+            # NaN guard of get_map (ref:88-96): a non-finite potential -> uniform plan
+            fin = bool(torch.isfinite(sol.f).all() and torch.isfinite(sol.g).all())
+            u = _u01_to_device(np.random.random_sample(n), dev)
+            if not fin:
+                if self.warn:
+                    warnings.warn("Numerical errors in OT plan, reverting to uniform plan.")
+                flat = torch.clamp((u * (M.shape[0] * M.shape[1])).floor().long(), max=M.numel() - 1)
+                return flat // M.shape[1], flat % M.shape[1]
+            return sample_dense(sol, u)
+        u = _u01_to_device(np.random.random_sample(n), dev)
+        return sample_perm(sol, u, M.shape[0])
+
+    def sample_plan(self, x0, x1, replace=True):
+        r"""Compute the OT plan and draw source and target samples from it (ref:123-145)."""
+        i, j = self._sample_indices(x0, x1, replace=replace)
+        dev = i.device
+        g0 = gather_rows(x0.detach().to(dev), i).to(x0.device)
+        g1 = gather_rows(x1.detach().to(dev), j).to(x1.device)
+        return g0, g1
+
+    def sample_plan_with_scipy(self, x0, x1):
+        r"""Deterministic OT pairing: keeps x0's order and returns x1[perm] (ref:147-182).
+
+        The reference calls scipy.optimize.linear_sum_assignment on the host; here the same
+        permutation comes from the device solver.
+        """
+        x0f, x1f = _flatten2(x0), _flatten2(x1)
+        dev = _lib.require_gpu()
+        a, b = _lib.to_dev_f32(x0f, dev), _lib.to_dev_f32(x1f, dev)
+        M = cost_matrix(a, b, squared=True, normalize=self.normalize_cost)
+        perm = assign_exact(M).long()
+        return x0f, gather_rows(x1f.detach().to(dev), perm).to(x1.device)
+
+    def sample_plan_with_labels(self, x0, x1, y0=None, y1=None, replace=True):
+        r"""As sample_plan, also gathering the labels (ref:184-219)."""
+        i, j = self._sample_indices(x0, x1, replace=replace)
+        dev = i.device
+        return (
+            gather_rows(x0.detach().to(dev), i).to(x0.device),
+            gather_rows(x1.detach().to(dev), j).to(x1.device),
+            gather_rows(y0.detach().to(dev), i).to(y0.device) if y0 is not None else None,
+            gather_rows(y1.detach().to(dev), j).to(y1.device) if y1 is not None else None,
+        )
+
+    def sample_trajectory(self, X):
+        """OT trajectories across consecutive time slices (ref:221-251).
+
+        One plan per pair of slices (device solve); the per-row draws consume the global
+        ``np.random`` stream exactly like the reference's per-row ``np.random.choice(p=pi[i])``.
+        """
+        times = X.shape[1]
+        dev = _lib.require_gpu()
+        indices = [np.arange(X.shape[0])]
+        for t in range(times - 1):
+            pi = self.get_map(X[:, t], X[:, t + 1])
+            B1 = pi.shape[1]
+            rows = indices[-1]
+            # row-conditional plan: pi[i] / pi[i].sum(); one uniform per row, in row order
+            u = np.random.random_sample(len(rows))
+            sub = np.ascontiguousarray(pi[rows])
+            sub = sub / sub.sum(axis=1, keepdims=True)
+            # flattened cdf trick: row r occupies [r, r+1) after adding r to its cdf
+            flat_u = (np.arange(len(rows)) + u) / len(rows)
+            pi_dev = torch.from_numpy(sub / len(rows)).to(dev)
+            _, j = sample_pi(pi_dev, _u01_to_device(flat_u, dev))
+            indices.append(j.cpu().numpy())
+        to_return = []
+        for t in range(times):
+            to_return.append(np.asarray(X[:, t].cpu())[indices[t]])
+        return np.stack(to_return, axis=1)
+
+
+def wasserstein(
+    x0: torch.Tensor,
+    x1: torch.Tensor,
+    method: Optional[str] = None,
+    reg: float = 0.05,
+    power: int = 2,
+    **kwargs,
+) -> float:
+    """Wasserstein-1/2 distance between two minibatches (ref:254-303)."""
+    assert power == 1 or power == 2
+    if method == "exact" or method is None:
+        exact = True
+    elif method == "sinkhorn":
+        exact = False
+    else:
+        raise ValueError(f"Unknown method: {method}")
+    dev = _lib.require_gpu()
+    a = _lib.to_dev_f32(_flatten2(x0), dev)
+    b = _lib.to_dev_f32(_flatten2(x1), dev)
+    M = cost_matrix(a, b, squared=(power == 2))
+    if exact:
+        perm, info = assign_exact(M, return_info=True)
+        ret = info["total_cost"] / M.shape[0]
+    else:
+        lib = _lib.load()
+        r = sinkhorn_log(M, reg, max_iter=int(kwargs.get("numItermax", int(1e7))))  # ref:300
+        out = torch.zeros(1, dtype=torch.float64, device=dev)
+        check(lib.cfm_sinkhorn_cost_f64(ptr(M), M.shape[0], M.shape[1], float(reg), ptr(r.ws), ptr(out),
+                                        stream_ptr()), "cfm_sinkhorn_cost_f64")
+        ret = float(out.cpu()[0])
+    if power == 2:
+        ret = math.sqrt(ret)
+    return ret

@@ -1,0 +1,77 @@
+"""Glue + toy data — counterpart of ``torchcfm/utils.py`` (ref lines cited inline)."""
+import math
+
+import numpy as np
+import torch
+
+
+def eight_normal_sample(n, dim, scale=1, var=1):
+    """ref: torchcfm/utils.py:11-32 (same RNG consumption: MVN noise, then multinomial)."""
+    m = torch.distributions.multivariate_normal.MultivariateNormal(
+        torch.zeros(dim), math.sqrt(var) * torch.eye(dim)
+    )
+    centers = [
+        (1, 0), (-1, 0), (0, 1), (0, -1),
+        (1.0 / np.sqrt(2), 1.0 / np.sqrt(2)), (1.0 / np.sqrt(2), -1.0 / np.sqrt(2)),
+        (-1.0 / np.sqrt(2), 1.0 / np.sqrt(2)), (-1.0 / np.sqrt(2), -1.0 / np.sqrt(2)),
+    ]
+    centers = torch.tensor(centers) * scale
+    noise = m.sample((n,))
+    multi = torch.multinomial(torch.ones(8), n, replacement=True)
+    return centers[multi] + noise
+
+
+def generate_moons(n_samples=100, noise=1e-4):
+    """torchdyn.datasets.generate_moons restated: two half circles plus
+    one uniform jitter value per row from the global np.random stream."""
+    n_out = n_samples // 2
+    n_in = n_samples - n_out
+    outer_x = np.cos(np.linspace(0, np.pi, n_out))
+    outer_y = np.sin(np.linspace(0, np.pi, n_out))
+    inner_x = 1 - np.cos(np.linspace(0, np.pi, n_in))
+    inner_y = 1 - np.sin(np.linspace(0, np.pi, n_in)) - 0.5
+    X = np.vstack([np.append(outer_x, inner_x), np.append(outer_y, inner_y)]).T
+    y = np.hstack([np.zeros(n_out, dtype=np.int64), np.ones(n_in, dtype=np.int64)])
+    if noise is not None:
+        X += np.random.rand(n_samples, 1) * noise
+    return torch.Tensor(X), torch.LongTensor(y)
+
+
+def sample_moons(n):
+    """ref: torchcfm/utils.py:35-37."""
+    x0, _ = generate_moons(n, noise=0.2)
+    return x0 * 3 - 1
+
+
+def sample_8gaussians(n):
+    """ref: torchcfm/utils.py:40-41."""
+    return eight_normal_sample(n, 2, scale=5, var=0.1).float()
+
+
+class torch_wrapper(torch.nn.Module):
+    """Wraps model to torchdyn compatible format (ref: torchcfm/utils.py:44-52)."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, t, x, *args, **kwargs):
+        from .models import MLP
+        if isinstance(self.model, MLP) and self.model.time_varying and not torch.is_grad_enabled() \
+                and torch.cuda.is_available():
+            return self.model.forward_hip(x, t)   # time column folded into the GEMM epilogue
+        return self.model(torch.cat([x, t.repeat(x.shape[0])[:, None]], 1))
+
+
+def plot_trajectories(traj):
+    """ref: torchcfm/utils.py:55-65 (matplotlib imported lazily)."""
+    import matplotlib.pyplot as plt
+    n = 2000
+    plt.figure(figsize=(6, 6))
+    plt.scatter(traj[0, :n, 0], traj[0, :n, 1], s=10, alpha=0.8, c="black")
+    plt.scatter(traj[:, :n, 0], traj[:, :n, 1], s=0.2, alpha=0.2, c="olive")
+    plt.scatter(traj[-1, :n, 0], traj[-1, :n, 1], s=4, alpha=1, c="blue")
+    plt.legend(["Prior sample z(S)", "Flow", "z(0)"])
+    plt.xticks([])
+    plt.yticks([])
+    plt.show()

@@ -152,12 +152,14 @@ int cfm_plan_sample_pi_f64(const double* pi, int B0, int B1, const double* u01, 
  * the other variants.  `sigma` is the Python-side value (double): the kernel
  * uses (float)sigma and, for TARGET, (float)(1.0 - sigma) exactly as eager
  * PyTorch casts Python scalars.  Outputs xt, ut [B,d]; x0g, x1g (may be NULL)
- * receive the gathered pairs. */
+ * receive the gathered pairs.  xt_in (may be NULL): use this xt instead of
+ * sampling one (compute_conditional_flow(x0, x1, t, xt) with a caller's xt);
+ * xt may then be NULL. */
 int cfm_sample_xt_ut_f32(int variant, const float* x0, const float* x1,
                          const int64_t* i, const int64_t* j, const float* t,
                          const float* eps, double sigma, const float* c0,
-                         const float* c1, int B, int d, float* xt, float* ut,
-                         float* x0g, float* x1g, void* stream);
+                         const float* c1, const float* xt_in, int B, int d, float* xt,
+                         float* ut, float* x0g, float* x1g, void* stream);
 
 /* Row gather  out[b,:] = src[idx[b],:]  (labels y0[i], y1[j]; :215-218).
  * elem_bytes = bytes per row. */

@@ -1,0 +1,400 @@
+"""ORACLE — CPU restatement of the reference algorithm for the OT-coupling + CFM-sampling
+hot path.  TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg as the checker; never by the product path
+(conditional-flow-matching_amd/ must not import this file).
+
+Every function cites the reference lines it follows (paths relative to the reference repo
+root, /root/reference in the build container).  Third-party pieces absent from the
+reference tree are restated from their published algorithm:
+  * POT (``ot``; unpinned in setup.py:14) — emd -> exact LSAP (equal uniform marginals =>
+    permutation plan; SciPy's linear_sum_assignment is the solver the reference itself
+    calls at optimal_transport.py:170,179), sinkhorn_knopp / sinkhorn_log loops
+    (SURVEY.md Appendix A.2);
+  * NumPy legacy RandomState.choice (Appendix A.3);
+  * torchdyn >= 1.0.6 NeuralODE / dopri5 (Appendix A.4) — "torchdyn-style dopri5".
+
+Pinning status: the closed forms, RNG order and wrapper semantics are
+pinned against the reference's own code, imported from /root/reference with the ``ot``
+stand-in, through tests/golden/*.npz (tests/golden/make_golden.py).  The numeric values
+of POT's solvers and torchdyn's integrator cannot be pinned here (neither library is in
+the image): exact-OT parity is pinned to SciPy's LSAP optimum instead; Sinkhorn and ODE
+parity are "parity unpinned" against the third-party code and pinned only to this
+restatement.
+"""
+import math
+import warnings
+
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+
+
+# ----------------------------------------------------------------------------- data
+def eight_gaussians(n, seed):
+    """8 Gaussians, scale 5, var 0.1 (ref: torchcfm/utils.py:11-32,40-41) — seeded generator."""
+    g = torch.Generator().manual_seed(seed)
+    s = 1.0 / math.sqrt(2.0)
+    centers = torch.tensor([(1, 0), (-1, 0), (0, 1), (0, -1), (s, s), (s, -s), (-s, s), (-s, -s)],
+                           dtype=torch.float32) * 5
+    noise = torch.randn(n, 2, generator=g) * math.sqrt(math.sqrt(0.1))
+    idx = torch.randint(0, 8, (n,), generator=g)
+    return (centers[idx] + noise).float()
+
+
+def two_moons(n, seed):
+    """torchdyn generate_moons(n, noise=0.2) * 3 - 1 (ref: torchcfm/utils.py:35-37; A.4)."""
+    rng = np.random.RandomState(seed)
+    n_out = n // 2
+    n_in = n - n_out
+    to, ti = np.linspace(0, np.pi, n_out), np.linspace(0, np.pi, n_in)
+    X = np.vstack([np.c_[np.cos(to), np.sin(to)], np.c_[1 - np.cos(ti), 0.5 - np.sin(ti)]])
+    X += rng.rand(n, 1) * 0.2
+    return torch.from_numpy(X.astype(np.float32)) * 3 - 1
+
+
+def mnist_like(n, seed):
+    """Synthetic MNIST-shaped target (no dataset in the image): clip(0.35*randn + mu_k, -1, 1)
+    with 10 fixed class means in [-1,1]^784."""
+    g = torch.Generator().manual_seed(seed)
+    mu = torch.rand(10, 784, generator=g) * 2 - 1
+    k = torch.randint(0, 10, (n,), generator=g)
+    return torch.clamp(0.35 * torch.randn(n, 784, generator=g) + mu[k], -1, 1)
+
+
+def gaussian_source(n, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, d, generator=g)
+
+
+def pca_like_pair(n, d, seed):
+    """C5: randn*s0 vs rotated randn*s1 + m with an EB-PCA-like spectrum s_k ~ k^-1/2."""
+    g = torch.Generator().manual_seed(seed)
+    s = torch.arange(1, d + 1, dtype=torch.float32).rsqrt() * 3
+    x0 = torch.randn(n, d, generator=g) * s
+    Q, _ = torch.linalg.qr(torch.randn(d, d, generator=g))
+    x1 = (torch.randn(n, d, generator=g) * s * 1.2) @ Q + 0.5 * torch.randn(1, d, generator=g)
+    return x0.contiguous(), x1.contiguous()
+
+
+def config_inputs(name, B=None, rank=0):
+    """Seeded synthetic inputs of the BASELINE configs."""
+    if name == "C1":
+        B = B or 256
+        return eight_gaussians(B, 0 + rank), two_moons(B, 0 + rank)
+    if name == "C2":
+        B = B or 4096
+        return eight_gaussians(B, 0 + rank), two_moons(B, 0 + rank)
+    if name in ("C3", "C4"):
+        B = B or 4096
+        return gaussian_source(B, 784, 1000 + rank), mnist_like(B, 2000 + rank)
+    if name == "C5":
+        B = B or 8192
+        return pca_like_pair(B, 50, 2024 + rank)
+    raise ValueError(name)
+
+
+# ----------------------------------------------------------------------------- cost (K1)
+def sqeuclid_cost_f64(x0, x1):
+    """sum_k (x0_ik - x1_jk)^2 in float64 (ref: torch.cdist(x0,x1)**2, optimal_transport.py:84)."""
+    a = np.asarray(x0, dtype=np.float64).reshape(len(x0), -1)
+    b = np.asarray(x1, dtype=np.float64).reshape(len(x1), -1)
+    if a.shape[1] <= 16:
+        return ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+    M = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * (a @ b.T)
+    return np.maximum(M, 0.0)
+
+
+def ref_cost_f32(x0, x1):
+    """The reference's own fp32 matrix: torch.cdist(x0, x1) ** 2 on CPU (optimal_transport.py:84)."""
+    a = torch.as_tensor(x0).reshape(len(x0), -1)
+    b = torch.as_tensor(x1).reshape(len(x1), -1)
+    return (torch.cdist(a, b) ** 2).numpy()
+
+
+# ----------------------------------------------------------------------------- exact OT (K4)
+def exact_perm(M):
+    """Optimal permutation of a square cost matrix given as fp32 values (solved in float64),
+    i.e. the support of pot.emd(unif, unif, M) (optimal_transport.py:49,87) and exactly
+    scipy.optimize.linear_sum_assignment(M) of :179."""
+    r, c = linear_sum_assignment(np.asarray(M, dtype=np.float64))
+    assert np.array_equal(r, np.arange(len(r)))
+    return c.astype(np.int64)
+
+
+def perm_plan(perm):
+    """pot.emd's plan for uniform equal marginals: 1/B on the optimal permutation."""
+    B = len(perm)
+    G = np.zeros((B, B), dtype=np.float64)
+    G[np.arange(B), perm] = 1.0 / B
+    return G
+
+
+def assignment_cost(M, perm):
+    M = np.asarray(M, dtype=np.float64)
+    return float(M[np.arange(len(perm)), perm].sum())
+
+
+# ----------------------------------------------------------------------------- sampling (K6)
+def choice_flat(p_flat, u):
+    """np.random.choice(len(p), p=p, size=len(u)) given its uniforms (A.3):
+    cdf = p.cumsum(); cdf /= cdf[-1]; idx = cdf.searchsorted(u, side='right')."""
+    cdf = np.cumsum(p_flat)
+    cdf /= cdf[-1]
+    return cdf.searchsorted(u, side="right")
+
+
+def sample_map_given_u(pi, u):
+    """OTPlanSampler.sample_map with replace=True (optimal_transport.py:116-121) for given
+    uniforms u (what np.random.choice would draw with np.random.random_sample(len(u)))."""
+    p = pi.flatten()
+    p = p / p.sum()
+    return np.divmod(choice_flat(p, u), pi.shape[1])
+
+
+def sample_perm_given_u(perm, u):
+    """O(B) restatement for a permutation plan: only the B non-zeros matter."""
+    B = len(perm)
+    p = np.full(B, 1.0 / B)
+    p = p / p.sum()
+    i = choice_flat(p, u)
+    return i.astype(np.int64), np.asarray(perm)[i].astype(np.int64)
+
+
+# ----------------------------------------------------------------------------- Sinkhorn (K5)
+def _lse(X, axis):
+    m = X.max(axis=axis, keepdims=True)
+    return (m + np.log(np.exp(X - m).sum(axis=axis, keepdims=True))).squeeze(axis)
+
+
+def sinkhorn_log(M, reg, numItermax=1000, stopThr=1e-9, check_every=10):
+    """POT ot.bregman.sinkhorn_log loop (A.2) in float64, uniform marginals.
+    Returns (u, v, n_iter, err): log-scalings with plan = exp(-M/reg + u_i + v_j)."""
+    M = np.asarray(M, dtype=np.float64)
+    n, m = M.shape
+    loga, logb = math.log(1.0 / n), math.log(1.0 / m)
+    Mr = -M / reg
+    u = np.zeros(n)
+    v = np.zeros(m)
+    err, it = 1.0, numItermax
+    for ii in range(numItermax):
+        v = logb - _lse(Mr + u[:, None], 0)
+        u = loga - _lse(Mr + v[None, :], 1)
+        if ii % check_every == 0:
+            tmp2 = np.exp(Mr + u[:, None] + v[None, :]).sum(0)
+            err = float(np.linalg.norm(tmp2 - 1.0 / m))
+            if err < stopThr:
+                it = ii + 1
+                break
+    return u, v, it, err
+
+
+def sinkhorn_plan(M, reg, u, v):
+    M = np.asarray(M, dtype=np.float64)
+    return np.exp(-M / reg + u[:, None] + v[None, :])
+
+
+def sinkhorn_knopp(M, reg, numItermax=1000, stopThr=1e-9):
+    """POT ot.sinkhorn default (method='sinkhorn' -> sinkhorn_knopp), A.2, uniform marginals.
+    M arrives as float32 values (optimal_transport.py:87)."""
+    M = np.asarray(M)
+    n, m = M.shape
+    a = np.full(n, 1.0 / n)
+    b = np.full(m, 1.0 / m)
+    u = np.ones(n, dtype=M.dtype) / n
+    v = np.ones(m, dtype=M.dtype) / m
+    K = np.exp(M / (-reg))
+    Kp = (1.0 / a).reshape(-1, 1) * K
+    for ii in range(numItermax):
+        uprev, vprev = u, v
+        KtU = K.T @ u
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v = b / KtU
+            u = 1.0 / (Kp @ v)
+        if (np.any(KtU == 0) or np.any(np.isnan(u)) or np.any(np.isnan(v))
+                or np.any(np.isinf(u)) or np.any(np.isinf(v))):
+            warnings.warn("Warning: numerical errors at iteration %d" % ii)
+            u, v = uprev, vprev
+            break
+        if ii % 10 == 0:
+            tmp2 = np.einsum("i,ij,j->j", u, K, v)
+            if np.linalg.norm(tmp2 - b) < stopThr:
+                break
+    return u.reshape(-1, 1) * K * v.reshape(1, -1)
+
+
+# ----------------------------------------------------------------------------- xt / ut (K8)
+def pad_t_like_x(t, x):
+    if isinstance(t, (float, int)):
+        return t
+    return t.reshape(-1, *([1] * (x.dim() - 1)))
+
+
+def xt_ut(method, x0, x1, t, eps, sigma):
+    """Closed forms in eager fp32, reference operation order
+    (conditional_flow_matching.py:82-83,126-129,153-154 | :446,474-478 | :349-350,368,393-394
+    | :588-589,617-618).  method in {icfm, sb, target, vp}."""
+    tp = pad_t_like_x(t, x0)
+    if method == "icfm":
+        mu = tp * x1 + (1 - tp) * x0
+        xt = mu + sigma * eps
+        ut = x1 - x0
+    elif method == "sb":
+        sig_t = pad_t_like_x(sigma * torch.sqrt(t * (1 - t)), x0)
+        mu = tp * x1 + (1 - tp) * x0
+        xt = mu + sig_t * eps
+        ratio = (1 - 2 * tp) / (2 * tp * (1 - tp) + 1e-8)
+        ut = ratio * (xt - mu) + x1 - x0
+    elif method == "target":
+        mu = tp * x1
+        sig_t = pad_t_like_x(1 - (1 - sigma) * t, x0)
+        xt = mu + sig_t * eps
+        ut = (x1 - (1 - sigma) * xt) / (1 - (1 - sigma) * tp)
+    elif method == "vp":
+        mu = torch.cos(math.pi / 2 * tp) * x0 + torch.sin(math.pi / 2 * tp) * x1
+        xt = mu + sigma * eps
+        ut = math.pi / 2 * (torch.cos(math.pi / 2 * tp) * x1 - torch.sin(math.pi / 2 * tp) * x0)
+    else:
+        raise ValueError(method)
+    return xt, ut
+
+
+# ----------------------------------------------------------------------------- whole step
+def ot_cfm_step(x0, x1, sigma=0.0, method="exact", reg=0.05, M=None):
+    """OTPlanSampler(method).sample_plan + ConditionalFlowMatcher.sample_location_and_conditional_flow
+    (optimal_transport.py:123-145; conditional_flow_matching.py:159-199,241-272) on CPU tensors,
+    consuming np.random / torch RNG in the reference order.  `M` overrides the cost matrix."""
+    B = x0.shape[0]
+    if M is None:
+        M = ref_cost_f32(x0, x1)
+    if method == "exact":
+        perm = exact_perm(M)
+        u = np.random.random_sample(B)
+        i, j = sample_perm_given_u(perm, u)
+    else:
+        uu, vv, _, _ = sinkhorn_log(M, reg)
+        pi = sinkhorn_plan(M, reg, uu, vv)
+        u = np.random.random_sample(B)
+        i, j = sample_map_given_u(pi, u)
+    a0, a1 = x0[i], x1[j]
+    t = torch.rand(B).type_as(x0)
+    eps = torch.randn_like(a0)
+    xt, ut = xt_ut("icfm" if method == "exact" else "sb", a0, a1, t, eps, sigma)
+    return t, xt, ut, eps, (i, j)
+
+
+# ----------------------------------------------------------------------------- MLP (K10)
+SELU_SCALE = 1.0507009873554804934193349852946
+SELU_ALPHA = 1.6732632423543772848170429916717
+
+
+def mlp_forward_f64(weights, biases, x, t=None):
+    """MLP.forward through torch_wrapper (models.py:10-21, utils.py:51-52) in float64.
+    weights[l]: [out,in] arrays.  t: None, scalar or [B]."""
+    h = np.asarray(x, dtype=np.float64)
+    if t is not None:
+        tt = np.broadcast_to(np.asarray(t, dtype=np.float64).reshape(-1, 1), (h.shape[0], 1))
+        h = np.concatenate([h, tt], 1)
+    n = len(weights)
+    for l, (W, b) in enumerate(zip(weights, biases)):
+        h = h @ np.asarray(W, dtype=np.float64).T + np.asarray(b, dtype=np.float64)
+        if l != n - 1:
+            h = SELU_SCALE * np.where(h > 0, h, SELU_ALPHA * np.expm1(h))
+    return h
+
+
+# ----------------------------------------------------------------------------- ODE (K11)
+DP_C = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+DP_A = [
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+DP_BSOL = [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0]
+DP_BALT = [1951 / 21600, 0, 22642 / 50085, 451 / 720, -12231 / 42400, 649 / 6300, 1 / 60]
+
+
+def euler_trajectory(f, x, t_span):
+    """torchdyn fixed-step Euler on t_span (A.4): x <- x + dt f(t, x).  f works in float64."""
+    ts = np.asarray(t_span, dtype=np.float32)
+    x = np.asarray(x, dtype=np.float64)
+    sol = [x]
+    for k in range(len(ts) - 1):
+        dt = float(np.float32(ts[k + 1] - ts[k]))
+        x = x + dt * f(float(ts[k]), x)
+        sol.append(x)
+    return np.stack(sol)
+
+
+def _hn(x):
+    return math.sqrt(float(np.mean(np.square(x))))
+
+
+def dopri5_trajectory(f, x, t_span, atol, rtol, return_log=False):
+    """torchdyn-style adaptive Dormand-Prince 5(4): Hairer init_step, FSAL,
+    global RMS error norm over the batch, every t_span point is a step end, adapt_step with
+    safety 0.9 / min 0.2 / max 10 / order 5.  State in float64, the scalar controller (t, dt,
+    error ratio) in float32 exactly like conditional-flow-matching_amd/csrc/ode.hip."""
+    f32 = np.float32
+    ts = np.asarray(t_span, dtype=np.float32)
+    x = np.asarray(x, dtype=np.float64)
+    atol, rtol = float(f32(atol)), float(f32(rtol))
+    sol = [x]
+    nfe = 0
+
+    def ev(t, y):
+        nonlocal nfe
+        nfe += 1
+        return f(float(t), y)
+
+    t, T = f32(ts[0]), f32(ts[-1])
+    k1 = ev(t, x)
+    scale = atol + np.abs(x) * rtol
+    d0, d1 = f32(_hn(x / scale)), f32(_hn(k1 / scale))
+    h0 = f32(1e-6) if (d0 < f32(1e-5) or d1 < f32(1e-5)) else f32(f32(0.01) * d0 / d1)
+    f1 = ev(f32(t + h0), x + float(h0) * k1)
+    d2 = f32(f32(_hn((f1 - k1) / scale)) / h0)
+    if d1 <= f32(1e-15) and d2 <= f32(1e-15):
+        h1 = max(f32(1e-6), f32(h0 * f32(1e-3)))
+    else:
+        h1 = f32(np.power(f32(f32(0.01) / max(d1, d2)), f32(1.0) / f32(6.0)))
+    dt = f32(min(f32(f32(100) * h0), h1))
+    ckpt, steps, log = 1, 0, []
+    while t < T:
+        if f32(t + dt) > T:
+            dt = f32(T - t)
+        dt_old, flag = dt, False
+        if ckpt < len(ts) and f32(t + dt) > ts[ckpt]:
+            dt_old, flag, dt = dt, True, f32(ts[ckpt] - t)
+        lands = ckpt < len(ts) and (flag or f32(t + dt) == ts[ckpt])
+        ks = [k1]
+        y = x
+        for s in range(6):
+            y = x + float(dt) * sum(float(f32(a)) * k for a, k in zip(DP_A[s], ks))
+            ks.append(ev(f32(t + f32(DP_C[s]) * dt), y))
+        x_new = y
+        err = float(dt) * sum(float(f32(bs - ba)) * k for bs, ba, k in zip(DP_BSOL, DP_BALT, ks))
+        ratio = f32(_hn(err / (atol + rtol * np.maximum(np.abs(x), np.abs(x_new)))))
+        steps += 1
+        accept = ratio <= f32(1)
+        log.append((float(t), float(dt), float(ratio), bool(accept)))
+        if accept:
+            if lands:
+                t = f32(ts[ckpt]); sol.append(x_new); ckpt += 1
+            else:
+                t = f32(t + dt)
+            x, k1 = x_new, ks[6]
+        if flag:
+            dt = f32(dt_old - dt)
+        if ratio == 0:
+            factor = f32(10)
+        else:
+            minf = f32(1.0) if ratio < f32(1) else f32(0.2)
+            factor = min(f32(10), max(f32(f32(0.9) / np.power(ratio, f32(0.2))), minf))
+        dt = f32(dt * factor)
+        if not dt > f32(1e-12):
+            dt = f32(1e-12)
+    out = np.stack(sol)
+    return (out, {"steps": steps, "nfe": nfe, "log": log}) if return_log else out

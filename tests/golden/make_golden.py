@@ -1,0 +1,158 @@
+"""Generate the golden fixtures in this directory.
+
+Runs in the BUILD container only: it imports the UNMODIFIED reference from /root/reference
+(oracle/ref_import.py puts the POT stand-in on the path) and records its outputs on seeded
+inputs.  The fixtures travel to the GPU box; /root/reference does not.
+
+    python tests/golden/make_golden.py
+
+Fixture provenance
+  fm_cases.npz        reference classes (torchcfm/conditional_flow_matching.py) — real reference
+                      arithmetic for t/xt/ut/eps; OT pairs through the stand-in (SciPy LSAP /
+                      restated Sinkhorn-Knopp).
+  ot_cases.npz        reference OTPlanSampler.get_map / sample_plan / wasserstein (wrapper code
+                      real, solver = stand-in).
+  sinkhorn_cases.npz  oracle float64 log-domain Sinkhorn (POT loop semantics) + restated Knopp.
+  ode_cases.npz       oracle torchdyn-style euler / dopri5 on a seeded MLP field.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import cfm_oracle as oracle  # noqa: E402
+import ref_import  # noqa: E402
+
+SEED = 1994
+
+
+def fm_cases(cfm):
+    out = {}
+    names = []
+    B = 64
+    specs = [
+        ("i_cfm", lambda s: cfm.ConditionalFlowMatcher(sigma=s)),
+        ("exact_ot_cfm", lambda s: cfm.ExactOptimalTransportConditionalFlowMatcher(sigma=s)),
+        ("t_cfm", lambda s: cfm.TargetConditionalFlowMatcher(sigma=s)),
+        ("vp_cfm", lambda s: cfm.VariancePreservingConditionalFlowMatcher(sigma=s)),
+        ("sb_cfm_exact", lambda s: cfm.SchrodingerBridgeConditionalFlowMatcher(sigma=s, ot_method="exact")),
+        ("sb_cfm_sinkhorn", lambda s: cfm.SchrodingerBridgeConditionalFlowMatcher(sigma=s, ot_method="sinkhorn")),
+    ]
+    for mname, ctor in specs:
+        for sigma in ([0.0, 5e-4, 0.5, 1.5, 0, 1] if "sb" not in mname else [0.5, 1.5, 1]):
+            if mname == "sb_cfm_sinkhorn" and sigma < 1.0:
+                continue  # Knopp only alive for reg = 2 sigma^2 >~ 1 on this data
+            for shape in ([2], [1, 2], [3, 4, 5]):
+                if shape == [3, 4, 5] and sigma != 0.5 and not (mname.startswith('sb') and sigma == 1.5):
+                    continue  # keep the fixture small: the 3-D shape once per method
+                g = torch.Generator().manual_seed(zlib.crc32(f"{mname}|{sigma!r}|{shape}".encode()) % (2**31))
+                x0 = torch.randn(B, *shape, generator=g)
+                x1 = torch.randn(B, *shape, generator=g)
+                fm = ctor(sigma)
+                torch.manual_seed(SEED)
+                np.random.seed(SEED)
+                t, xt, ut, eps = fm.sample_location_and_conditional_flow(x0, x1, return_noise=True)
+                key = f"{mname}|{sigma!r}|{'x'.join(map(str, shape))}"
+                names.append(key)
+                for k, v in (("x0", x0), ("x1", x1), ("t", t), ("xt", xt), ("ut", ut), ("eps", eps)):
+                    out[f"{key}|{k}"] = v.numpy()
+    out["names"] = np.array(names)
+    return out
+
+
+def ot_cases(ot):
+    out = {}
+    B = 128
+    torch.manual_seed(1980)
+    np.random.seed(1980)
+    x0 = torch.randn(B, 2, 2, 2)
+    x1 = torch.randn(B, 2, 2, 2)
+    s = ot.OTPlanSampler(method="exact")
+    pi = s.get_map(x0, x1)
+    torch.manual_seed(1980)
+    np.random.seed(1980)
+    sx0, sx1 = s.sample_plan(x0, x1, replace=True)
+    np.random.seed(7)
+    i, j = s.sample_map(pi, B, replace=True)
+    np.random.seed(7)
+    i2, j2 = s.sample_map(pi, B, replace=False)
+    y0 = torch.arange(B).reshape(B, 1)
+    y1 = torch.arange(B).reshape(B, 1) + 1000
+    np.random.seed(11)
+    lx0, lx1, ly0, ly1 = s.sample_plan_with_labels(x0, x1, y0, y1)
+    px0, px1 = s.sample_plan_with_scipy(x0, x1)
+    out.update(x0=x0.numpy(), x1=x1.numpy(), perm=np.argmax(pi, 1), pi_nnz_value=pi.max(),
+               sx0=sx0.numpy(), sx1=sx1.numpy(), map_i=i, map_j=j, map_i_norep=i2, map_j_norep=j2,
+               ly0=ly0.numpy(), ly1=ly1.numpy(), lx0=lx0.numpy(), lx1=lx1.numpy(),
+               scipy_x1=px1.numpy())
+    out["W2_exact"] = ot.wasserstein(x0, x1, "exact")
+    out["W1_exact"] = ot.wasserstein(x0, x1, "exact", power=1)
+    out["W2_sinkhorn_reg1"] = ot.wasserstein(x0, x1, "sinkhorn", reg=1.0)
+    # Sinkhorn sampler in the regime where Knopp is alive
+    s2 = ot.OTPlanSampler(method="sinkhorn", reg=2.0)
+    pik = s2.get_map(x0, x1)
+    np.random.seed(5)
+    ki, kj = s2.sample_map(pik, B)
+    out.update(sk_i=ki, sk_j=kj, sk_rowsum=pik.sum(1), sk_colsum=pik.sum(0))
+    # 8gaussians -> moons B=256 (config C1) permutation + cost
+    a, b = oracle.config_inputs("C1")
+    M = oracle.ref_cost_f32(a, b)
+    perm = oracle.exact_perm(M)
+    out.update(c1_x0=a.numpy(), c1_x1=b.numpy(), c1_perm=perm, c1_cost=oracle.assignment_cost(M, perm))
+    return out
+
+
+def sinkhorn_cases():
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(96, 3, generator=g)
+    x1 = torch.randn(80, 3, generator=g) + 0.5
+    M = oracle.ref_cost_f32(x0, x1)
+    out["M"] = M
+    for reg, iters in ((0.05, 25), (0.5, 40)):
+        u, v, it, err = oracle.sinkhorn_log(M, reg, numItermax=iters, stopThr=0.0)
+        out[f"u_{reg}"] = u; out[f"v_{reg}"] = v; out[f"it_{reg}"] = it; out[f"err_{reg}"] = err
+    u, v, it, err = oracle.sinkhorn_log(M, 2.0)          # converges -> iteration count pinned
+    out["u_conv"] = u; out["v_conv"] = v; out["it_conv"] = it; out["err_conv"] = err
+    out["knopp_conv"] = oracle.sinkhorn_knopp(M, 2.0)
+    return out
+
+
+def ode_cases():
+    out = {}
+    torch.manual_seed(0)
+    d, w, B = 2, 64, 64
+    lins = [torch.nn.Linear(d + 1, w), torch.nn.Linear(w, w), torch.nn.Linear(w, w), torch.nn.Linear(w, d)]
+    Ws = [l.weight.detach().numpy().copy() for l in lins]
+    bs = [l.bias.detach().numpy().copy() for l in lins]
+    for k, (W, b) in enumerate(zip(Ws, bs)):
+        out[f"W{k}"] = W; out[f"b{k}"] = b
+    x = oracle.eight_gaussians(B, 5).numpy()
+    f = lambda t, y: oracle.mlp_forward_f64(Ws, bs, y, t)
+    ts = np.linspace(0, 1, 11).astype(np.float32)
+    out["x"] = x; out["t_span"] = ts
+    out["euler"] = oracle.euler_trajectory(f, x, ts)
+    traj, info = oracle.dopri5_trajectory(f, x, ts, 1e-4, 1e-4, return_log=True)
+    out["dopri5"] = traj; out["dopri5_steps"] = info["steps"]; out["dopri5_nfe"] = info["nfe"]
+    out["mlp_out"] = oracle.mlp_forward_f64(Ws, bs, x, 0.3)
+    return out
+
+
+def main():
+    cfm, ot = ref_import.import_reference()
+    np.savez_compressed(os.path.join(HERE, "fm_cases.npz"), **fm_cases(cfm))
+    np.savez_compressed(os.path.join(HERE, "ot_cases.npz"), **ot_cases(ot))
+    np.savez_compressed(os.path.join(HERE, "sinkhorn_cases.npz"), **sinkhorn_cases())
+    np.savez_compressed(os.path.join(HERE, "ode_cases.npz"), **ode_cases())
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,53 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/cfm_gfx950.h declares (no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "cfm_gfx950.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cfm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared()
+    for must in ("cfm_sqeuclid_cost_f32", "cfm_sinkhorn_log_f32", "cfm_assign_exact_f32",
+                 "cfm_plan_sample_perm", "cfm_plan_sample_dense", "cfm_sample_xt_ut_f32",
+                 "cfm_mlp_forward_f32", "cfm_ode_dopri5_mlp_f32", "cfm_workspace_bytes"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    lib = ctypes.CDLL(lib_built.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in include/cfm_gfx950.h but not exported"
+
+
+def test_python_binding_covers_header(lib_built):
+    assert sorted(lib_built.SIGNATURES) == _declared()
+    assert sorted(lib_built.exported_symbols()) == _declared()
+
+
+def test_workspace_sizes(lib_built):
+    lib = lib_built.load()
+    assert lib.cfm_abi_version() == 1
+    for op in (1, 2, 3, 4, 5):
+        n = lib.cfm_workspace_bytes(op, 4096, 4096, 784)
+        assert n > 0 and n % 256 == 0
+    assert lib.cfm_workspace_bytes(99, 4, 4, 4) == 0
+    # Sinkhorn scratch is O(B) potentials + strip partials, far below the B^2 matrix
+    assert lib.cfm_workspace_bytes(1, 4096, 4096, 0) < 16 * 2**20
+    assert lib.cfm_workspace_bytes(2, 4096, 4096, 0) < 2**20
+
+
+def test_code_object_is_gfx950_only(lib_built):
+    blob = open(lib_built.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_"):
+        assert other not in blob

@@ -1,0 +1,137 @@
+"""CPU: host-side behaviour of the drop-in API (names, signatures, errors, loud failure
+without a GPU).  No kernels run here."""
+import inspect
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cfm_amd
+from cfm_amd import _lib
+from cfm_amd.conditional_flow_matching import (
+    ConditionalFlowMatcher,
+    ExactOptimalTransportConditionalFlowMatcher,
+    SchrodingerBridgeConditionalFlowMatcher,
+    TargetConditionalFlowMatcher,
+    VariancePreservingConditionalFlowMatcher,
+    pad_t_like_x,
+)
+from cfm_amd.optimal_transport import OTPlanSampler, wasserstein
+
+import ref_import
+
+HAS_GPU = torch.cuda.is_available()
+
+
+def test_public_names():
+    for n in ("ConditionalFlowMatcher", "ExactOptimalTransportConditionalFlowMatcher",
+              "TargetConditionalFlowMatcher", "SchrodingerBridgeConditionalFlowMatcher",
+              "VariancePreservingConditionalFlowMatcher", "pad_t_like_x", "MLP", "OTPlanSampler",
+              "wasserstein", "__version__"):
+        assert hasattr(cfm_amd, n)
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present")
+def test_signatures_match_reference():
+    cfm, ot = ref_import.import_reference()
+    import cfm_amd.conditional_flow_matching as mine_cfm
+    import cfm_amd.optimal_transport as mine_ot
+    for mod_ref, mod_mine, classes in (
+        (cfm, mine_cfm, ["ConditionalFlowMatcher", "ExactOptimalTransportConditionalFlowMatcher",
+                         "TargetConditionalFlowMatcher", "SchrodingerBridgeConditionalFlowMatcher",
+                         "VariancePreservingConditionalFlowMatcher"]),
+        (ot, mine_ot, ["OTPlanSampler"]),
+    ):
+        for c in classes:
+            R, Mi = getattr(mod_ref, c), getattr(mod_mine, c)
+            for name, fn in inspect.getmembers(R, predicate=inspect.isfunction):
+                if name.startswith("_") and name != "__init__":
+                    continue
+                assert hasattr(Mi, name), f"{c}.{name} missing"
+                ps_r = list(inspect.signature(fn).parameters.values())
+                ps_m = list(inspect.signature(getattr(Mi, name)).parameters.values())
+                assert [p.name for p in ps_r] == [p.name for p in ps_m], f"{c}.{name}"
+                assert [p.default for p in ps_r] == [p.default for p in ps_m], f"{c}.{name}"
+    assert list(inspect.signature(ot.wasserstein).parameters) == list(inspect.signature(wasserstein).parameters)
+
+
+def test_error_behaviour():
+    with pytest.raises(ValueError, match="Unknown method"):
+        OTPlanSampler(method="nope")
+    for m in ("exact", "sinkhorn", "unbalanced", "partial"):
+        OTPlanSampler(method=m)          # constructible like the reference
+    with pytest.raises(ValueError):
+        SchrodingerBridgeConditionalFlowMatcher(sigma=0.0)
+    with pytest.raises(ValueError):
+        SchrodingerBridgeConditionalFlowMatcher(sigma=-1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        SchrodingerBridgeConditionalFlowMatcher(sigma=5e-4)
+        assert any("numerical instability" in str(x.message) for x in w)
+    with pytest.raises(ValueError):
+        wasserstein(torch.randn(4, 2), torch.randn(4, 2), "noname")
+    with pytest.raises(AssertionError):
+        wasserstein(torch.randn(4, 2), torch.randn(4, 2), power=3)
+    s = SchrodingerBridgeConditionalFlowMatcher(sigma=0.5, ot_method="sinkhorn")
+    assert s.ot_method == "sinkhorn" and s.ot_sampler.reg == pytest.approx(0.5)
+    assert ExactOptimalTransportConditionalFlowMatcher(0.1).ot_sampler.method == "exact"
+
+
+def test_small_host_helpers():
+    x = torch.randn(5, 2, 3)
+    assert pad_t_like_x(0.5, x) == 0.5
+    assert pad_t_like_x(torch.rand(5), x).shape == (5, 1, 1)
+    fm = ConditionalFlowMatcher(sigma=0.3)
+    assert fm.compute_sigma_t(torch.rand(5)) == 0.3
+    assert fm.compute_lambda(torch.rand(5)) == pytest.approx(2 * 0.3 / (0.09 + 1e-8))
+    t = torch.rand(7)
+    sb = SchrodingerBridgeConditionalFlowMatcher(sigma=0.7)
+    assert torch.equal(sb.compute_sigma_t(t), 0.7 * torch.sqrt(t * (1 - t)))
+    tg = TargetConditionalFlowMatcher(sigma=0.2)
+    assert torch.equal(tg.compute_sigma_t(t), 1 - (1 - 0.2) * t)
+    assert isinstance(VariancePreservingConditionalFlowMatcher(0.1), ConditionalFlowMatcher)
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+    """No silent CPU path: every compute entry raises CfmBackendError when no GPU is visible."""
+    x0, x1 = torch.randn(8, 2), torch.randn(8, 2)
+    with pytest.raises(_lib.CfmBackendError):
+        OTPlanSampler("exact").sample_plan(x0, x1)
+    with pytest.raises(_lib.CfmBackendError):
+        OTPlanSampler("sinkhorn").get_map(x0, x1)
+    with pytest.raises(_lib.CfmBackendError):
+        ConditionalFlowMatcher(0.1).sample_location_and_conditional_flow(x0, x1)
+    with pytest.raises(_lib.CfmBackendError):
+        ExactOptimalTransportConditionalFlowMatcher(0.1).sample_location_and_conditional_flow(x0, x1)
+    with pytest.raises(_lib.CfmBackendError):
+        wasserstein(x0, x1)
+    with pytest.raises(_lib.CfmBackendError):
+        OTPlanSampler("exact").sample_map(np.eye(4) / 4, 4)
+
+
+def test_product_path_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the package may import it, scipy's
+    LSAP, or call a CPU solver."""
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       "conditional-flow-matching_amd")
+    bad = re.compile(r"cfm_oracle|ref_import|linear_sum_assignment|import\s+ot\b|from\s+ot\b|import scipy")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            code = "\n".join(l for l in src.splitlines() if not l.strip().startswith("#"))
+            code = re.sub(r'""".*?"""', "", code, flags=re.S)
+            assert not bad.search(code), fn
+
+
+def test_mlp_state_dict_layout():
+    m = cfm_amd.MLP(dim=2, time_varying=True, w=64)
+    keys = list(m.state_dict().keys())
+    assert keys == ["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight",
+                    "net.4.bias", "net.6.weight", "net.6.bias"]
+    assert m.net[0].in_features == 3 and m.net[6].out_features == 2
+    y = m(torch.randn(4, 3, requires_grad=True))      # autograd path = torch
+    y.sum().backward()
