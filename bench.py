@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py — OT-CFM train-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic minibatch already resident in HBM
+(config C3: x0 ~ N(0,I) in R^784, x1 MNIST-like, B = 4096 per GPU):
+    cost matrix -> exact OT assignment -> plan sampling -> fused gather + xt/ut  (HIP kernels)
+    -> MLP(785-512-512-512-784) forward, MSE loss, backward, Adam step           (PyTorch-ROCm)
+N > 1: one process per GPU (torchrun), every rank couples its own minibatch (no collective in
+the OT path), the model is data parallel (gradient all-reduce over RCCL), weak scaling.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def synth_batches(B, d, n, seed, dev):
+    """Pool of n synthetic (x0, x1) minibatches in HBM (C3 shapes)."""
+    g = torch.Generator().manual_seed(seed)
+    mu = torch.rand(10, d, generator=g) * 2 - 1
+    out = []
+    for _ in range(n):
+        x0 = torch.randn(B, d, generator=g)
+        k = torch.randint(0, 10, (B,), generator=g)
+        x1 = torch.clamp(0.35 * torch.randn(B, d, generator=g) + mu[k], -1, 1)
+        out.append((x0.to(dev), x1.to(dev)))
+    return out
+
+
+def sinkhorn_leg(dev, iters=200):
+    """Sinkhorn iterations/s on config C2 (8gaussians -> moons, B=4096, d=2, eps=0.05)."""
+    import cfm_amd.optimal_transport as ot
+    import cfm_oracle as oracle
+    x0, x1 = oracle.config_inputs("C2")
+    M = ot.cost_matrix(x0.to(dev), x1.to(dev))
+    ot.sinkhorn_log(M, 0.05, max_iter=20, stop_thr=0.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ot.sinkhorn_log(M, 0.05, max_iter=iters, stop_thr=0.0)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    B = M.shape[0]
+    per_iter_bytes = 2 * 4 * B * B + 16 * B
+    gbs = per_iter_bytes * iters / (ms * 1e-3) / 1e9
+    return {"iters_per_s": iters / (ms * 1e-3), "ms_per_iter": ms / iters,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "note": "2 passes over the 64 MiB cost matrix per iteration (Infinity-Cache resident)"}}
+
+
+def cpu_baseline(B, d, max_seconds=30.0):
+    """Oracle restatement of the reference CPU path (OTPlanSampler('exact').sample_plan +
+    sample_location_and_conditional_flow) timed on this box's host cores, bounded sample."""
+    import cfm_oracle as oracle
+    x0, x1 = oracle.config_inputs("C3", B=B)
+    torch.manual_seed(0); np.random.seed(0)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 2 and (time.perf_counter() - t_start) < max_seconds:
+        t0 = time.perf_counter()
+        oracle.ot_cfm_step(x0, x1, sigma=0.0)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": B / best, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times)} step(s) of B={B}, d={d}: torch.cdist**2 + SciPy LSAP (stand-in for "
+                      f"POT emd, single thread) + flattened-cdf sampling + eager xt/ut; best {best:.2f} s/step; "
+                      f"host has {os.cpu_count()} cores, torch intra-op threads {torch.get_num_threads()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--dim", type=int, default=784)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--sigma", type=float, default=0.0)
+    ap.add_argument("--mode", default="train", choices=["train", "coupling"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sinkhorn", action="store_true")
+    args = ap.parse_args()
+
+    import cfm_amd
+    from cfm_amd import _lib, distributed as D
+    from cfm_amd.conditional_flow_matching import ExactOptimalTransportConditionalFlowMatcher
+    import cfm_amd.optimal_transport as ot
+
+    _lib.load()
+    rank, local, world = D.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B, d = args.batch, args.dim
+
+    pool = synth_batches(B, d, min(8, args.steps + args.warmup), D.shard_seed(1000, rank), dev)
+    fm = ExactOptimalTransportConditionalFlowMatcher(sigma=args.sigma)
+    torch.manual_seed(0)
+    model = cfm_amd.MLP(dim=d, time_varying=True, w=args.width).to(dev)
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    np.random.seed(D.shard_seed(1, rank)); torch.manual_seed(D.shard_seed(1, rank))
+
+    asg_events, stats_log = [], []
+
+    def step(k, timed):
+        x0, x1 = pool[k % len(pool)]
+        if timed:
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # --- coupling (HIP): cost -> exact assignment -> sampling -> fused xt/ut ---
+        M = ot.cost_matrix(x0, x1)
+        if timed:
+            ea.record()
+        perm, info = ot.assign_exact(M, return_info=True)
+        if timed:
+            eb.record(); asg_events.append((ea, eb)); stats_log.append(info["stats"])
+        u = torch.from_numpy(np.random.random_sample(B)).to(dev)
+        i, j = ot.sample_perm(perm, u, B)
+        t, xt, ut = fm._sample(x0, x1, None, False, idx=(i, j))
+        if args.mode == "coupling":
+            return
+        # --- model (PyTorch-ROCm): forward, loss, backward, optimizer ---
+        opt.zero_grad(set_to_none=True)
+        vt = model(torch.cat([xt, t[:, None]], dim=-1))
+        loss = torch.mean((vt - ut) ** 2)
+        loss.backward()
+        opt.step()
+
+    for k in range(args.warmup):
+        step(k, False)
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, True)
+    torch.cuda.synchronize(); D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+
+    if rank != 0:
+        return
+    value = world * B * args.steps / elapsed
+    asg_ms = [a.elapsed_time(b) for a, b in asg_events]
+    scans = [s[5] for s in stats_log]
+    # algorithmic bytes of the assignment: every row scan reads one fp32 cost row + the fp64 prices
+    asg_bytes = [sc * (4 * B + 8 * B) for sc in scans]
+    asg_gbs = sum(asg_bytes) / (sum(asg_ms) * 1e-3) / 1e9 if asg_ms else 0.0
+    out = {
+        "metric": "OT-CFM train-step samples/sec (B=4096,d=784)", "value": value, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3: MNIST-shaped d=784, B=4096 per GPU, ExactOptimalTransportConditionalFlowMatcher "
+                               "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd + Adam (PyTorch-ROCm)",
+                   "batch_per_gpu": B, "dim": d, "mlp_width": args.width, "mode": args.mode,
+                   "parallelism": f"dp{world}" if world > 1 else "single"},
+        "roofline": {"bound": "hbm", "achieved": asg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": asg_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "asg_wide+asg_ctrl (cfm_assign_exact_f32)",
+                     "note": "algorithmic bytes = row scans x (4B cost row + 8B prices); irregular, latency-bound tail"},
+        "assign_ms_per_step": float(np.mean(asg_ms)) if asg_ms else None,
+        "assign_stats_mean": [float(x) for x in np.mean(np.array(stats_log), axis=0)] if stats_log else None,
+    }
+    if not args.no_sinkhorn:
+        sk = sinkhorn_leg(dev)
+        out["sinkhorn_iters_per_s"] = sk["iters_per_s"]
+        out["roofline_sinkhorn"] = sk["roofline"]
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(B, d)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""GPU: the committed golden vectors (recorded from the reference's own code) reproduced by the
+product path end to end."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _fm(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
+    return np.load(os.path.join(golden_dir, "fm_cases.npz"))
+
+
+def _ctor(mname, sigma):
+    import cfm_amd.conditional_flow_matching as c
+    return {
+        "i_cfm": lambda: c.ConditionalFlowMatcher(sigma=sigma),
+        "exact_ot_cfm": lambda: c.ExactOptimalTransportConditionalFlowMatcher(sigma=sigma),
+        "t_cfm": lambda: c.TargetConditionalFlowMatcher(sigma=sigma),
+        "vp_cfm": lambda: c.VariancePreservingConditionalFlowMatcher(sigma=sigma),
+        "sb_cfm_exact": lambda: c.SchrodingerBridgeConditionalFlowMatcher(sigma=sigma, ot_method="exact"),
+        "sb_cfm_sinkhorn": lambda: c.SchrodingerBridgeConditionalFlowMatcher(sigma=sigma, ot_method="sinkhorn"),
+    }[mname]()
+
+
+@pytest.mark.parametrize("key", list(_fm()["names"]))
+def test_golden_fm_case(key):
+    d = _fm()
+    mname, sig, _ = key.split("|")
+    g = {k: torch.from_numpy(d[f"{key}|{k}"]) for k in ("x0", "x1", "t", "xt", "ut", "eps")}
+    fm = _ctor(mname, eval(sig))
+    torch.manual_seed(1994)
+    np.random.seed(1994)
+    t, xt, ut, eps = fm.sample_location_and_conditional_flow(g["x0"], g["x1"], return_noise=True)
+    assert torch.equal(t, g["t"]) and torch.equal(eps, g["eps"])
+    assert torch.all(xt.eq(g["xt"])), (key, (xt - g["xt"]).abs().max())
+    assert torch.all(ut.eq(g["ut"])), (key, (ut - g["ut"]).abs().max())
+
+
+def test_golden_ot_cases(golden_dir):
+    from cfm_amd.optimal_transport import OTPlanSampler, wasserstein
+    d = np.load(os.path.join(golden_dir, "ot_cases.npz"))
+    x0, x1 = torch.from_numpy(d["x0"]), torch.from_numpy(d["x1"])
+    s = OTPlanSampler(method="exact")
+    pi = s.get_map(x0, x1)
+    assert np.array_equal(np.argmax(pi, 1), d["perm"]) and pi.max() == d["pi_nnz_value"]
+    assert np.count_nonzero(pi) == len(d["perm"])
+    torch.manual_seed(1980); np.random.seed(1980)
+    sx0, sx1 = s.sample_plan(x0, x1, replace=True)
+    assert np.array_equal(sx0.numpy(), d["sx0"]) and np.array_equal(sx1.numpy(), d["sx1"])
+    np.random.seed(7)
+    i, j = s.sample_map(pi, len(pi), replace=True)
+    assert np.array_equal(i, d["map_i"]) and np.array_equal(j, d["map_j"])
+    np.random.seed(7)
+    i, j = s.sample_map(pi, len(pi), replace=False)
+    assert np.array_equal(i, d["map_i_norep"]) and np.array_equal(j, d["map_j_norep"])
+    y0 = torch.arange(len(pi)).reshape(-1, 1); y1 = y0 + 1000
+    np.random.seed(11)
+    lx0, lx1, ly0, ly1 = s.sample_plan_with_labels(x0, x1, y0, y1)
+    assert np.array_equal(ly0.numpy(), d["ly0"]) and np.array_equal(ly1.numpy(), d["ly1"])
+    assert np.array_equal(lx0.numpy(), d["lx0"]) and np.array_equal(lx1.numpy(), d["lx1"])
+    px0, px1 = s.sample_plan_with_scipy(x0, x1)
+    assert np.array_equal(px1.numpy(), d["scipy_x1"]) and torch.equal(px0, x0.reshape(len(pi), -1))
+    assert wasserstein(x0, x1, "exact") == pytest.approx(float(d["W2_exact"]), rel=2e-6)
+    assert wasserstein(x0, x1, "exact", power=1) == pytest.approx(float(d["W1_exact"]), rel=2e-6)
+    assert wasserstein(x0, x1, "sinkhorn", reg=1.0) == pytest.approx(float(d["W2_sinkhorn_reg1"]), rel=1e-5)
+    # Sinkhorn sampler where POT's Knopp iteration is alive: same plan -> same draws
+    s2 = OTPlanSampler(method="sinkhorn", reg=2.0)
+    pik = s2.get_map(x0, x1)
+    np.testing.assert_allclose(pik.sum(1), d["sk_rowsum"], rtol=1e-6)
+    np.testing.assert_allclose(pik.sum(0), d["sk_colsum"], rtol=1e-6)
+    np.random.seed(5)
+    ki, kj = s2.sample_map(pik, len(pi))
+    assert (ki != d["sk_i"]).sum() + (kj != d["sk_j"]).sum() <= 1
+
+
+def test_sample_trajectory_shape_and_rng(golden_dir):
+    from cfm_amd.optimal_transport import OTPlanSampler
+    import cfm_oracle as oracle
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(48, 3, 2, generator=g)
+    s = OTPlanSampler(method="exact")
+    np.random.seed(0)
+    out = s.sample_trajectory(X)
+    assert out.shape == (48, 3, 2)
+    # exact plans are permutations: each slice is a permutation of the input slice
+    idx = np.arange(48)
+    for t in range(2):
+        perm = oracle.exact_perm(oracle.ref_cost_f32(X[:, t], X[:, t + 1]))
+        idx = perm[idx]
+        assert np.array_equal(out[:, t + 1], X[:, t + 1].numpy()[idx])
