@@ -46,13 +46,13 @@ SIGNATURES = {
     "cfm_sqeuclid_cost_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "cfm_scale_inv_f32": (_i, [_vp, _sz, _vp, _vp]),
     "cfm_sqrt_inplace_f32": (_i, [_vp, _sz, _vp]),
-    "cfm_sinkhorn_log_f32": (_i, [_vp, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cfm_sinkhorn_log_f32": (_i, [_vp, _i, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfm_sinkhorn_potentials_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
-    "cfm_sinkhorn_plan_f64": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp]),
-    "cfm_sinkhorn_cost_f64": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp]),
+    "cfm_sinkhorn_plan_f64": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),
+    "cfm_sinkhorn_cost_f64": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),
     "cfm_assign_exact_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_perm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
-    "cfm_plan_sample_dense": (_i, [_vp, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "cfm_plan_sample_dense": (_i, [_vp, _i, _i, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_pi_f64": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "cfm_sample_xt_ut_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i,
                                   _vp, _vp, _vp, _vp, _vp]),

@@ -47,6 +47,11 @@ def _fused_xt_ut(variant, sigma, x0, x1, t, eps, idx=None, xt_in=None, want_xt=T
         ang = math.pi / 2 * t.reshape(-1)
         c0 = _lib.to_dev_f32(torch.cos(ang), dev)
         c1 = _lib.to_dev_f32(torch.sin(ang), dev)
+    elif variant == _lib.VARIANT_SB:
+        # sigma_t exactly as the reference's compute_sigma_t (ref:446) on t's own device: eager
+        # torch.sqrt is not correctly rounded on every backend, so the [B] scalars come from it
+        tt = t.reshape(-1)
+        c0 = _lib.to_dev_f32(sigma * torch.sqrt(tt * (1 - tt)), dev)
     xt = torch.empty((B, d), dtype=torch.float32, device=dev) if want_xt else None
     ut = torch.empty((B, d), dtype=torch.float32, device=dev)
     gi, gj = (idx if idx is not None else (None, None))

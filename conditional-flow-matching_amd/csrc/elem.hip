@@ -8,10 +8,21 @@
 //   VP       :588-589, :617-618
 // The reference's tests demand bit equality with eager fp32
 // (tests/test_conditional_flow_matcher.py:124-126), so every operation below is
-// an explicitly rounded IEEE op (__fmul_rn/__fadd_rn/... : never contracted
-// into FMAs) in the reference's operation order.  HBM-bound: reads x0[i], x1[j],
+// a separately rounded IEEE op in the reference's operation order: the file is
+// compiled with contraction off (pragma + -ffp-contract=off) and uses sqrtf / '/'
+// (correctly rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt).  NOTE: HIP's f_sqrt/f_div are
+// NOT IEEE on ROCm 7.2 without OCML_BASIC_ROUNDED_OPERATIONS (they lower to the
+// native approximations) — measured 1-ulp mismatches on gfx950 — so they are not used.  HBM-bound: reads x0[i], x1[j],
 // eps once, writes xt, ut once (16-byte accesses when rows allow it).
 #include "cfm_common.h"
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float f_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float f_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float f_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float f_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float f_sqrt(float a) { return sqrtf(a); }
 
 struct RowCoef {       // per-sample scalars
     float c1;          // multiplies x1 in mu
@@ -25,18 +36,21 @@ __device__ __forceinline__ RowCoef row_coef(float t, float sigma_f, float oms_f,
                                             const float* c1p, int b) {
     RowCoef r;
     if (VARIANT == CFM_VARIANT_ICFM) {
-        r.c1 = t; r.c0 = __fsub_rn(1.0f, t); r.sig = sigma_f; r.a = 0.f;
+        r.c1 = t; r.c0 = f_sub(1.0f, t); r.sig = sigma_f; r.a = 0.f;
     } else if (VARIANT == CFM_VARIANT_SB) {
-        const float omt = __fsub_rn(1.0f, t);
+        const float omt = f_sub(1.0f, t);
         r.c1 = t; r.c0 = omt;
-        r.sig = __fmul_rn(sigma_f, __fsqrt_rn(__fmul_rn(t, omt)));           // sigma*sqrt(t*(1-t))
-        const float two_t = __fmul_rn(2.0f, t);
-        const float num = __fsub_rn(1.0f, two_t);                             // 1 - 2t
-        const float den = __fadd_rn(__fmul_rn(two_t, omt), 1e-8f);            // 2t(1-t) + 1e-8
-        r.a = __fdiv_rn(num, den);
+        // sigma_t = sigma*sqrt(t*(1-t)): taken from the caller's tensor library when provided
+        // (c0p) — eager torch.sqrt is NOT correctly rounded on every backend (CPU/MKL deviates
+        // by 1 ulp on ~0.6 % of inputs), so bit parity needs the caller's own sqrt; otherwise IEEE.
+        r.sig = c0p ? c0p[b] : f_mul(sigma_f, f_sqrt(f_mul(t, omt)));
+        const float two_t = f_mul(2.0f, t);
+        const float num = f_sub(1.0f, two_t);                             // 1 - 2t
+        const float den = f_add(f_mul(two_t, omt), 1e-8f);            // 2t(1-t) + 1e-8
+        r.a = f_div(num, den);
     } else if (VARIANT == CFM_VARIANT_TARGET) {
         r.c1 = t; r.c0 = 0.f;
-        r.sig = __fsub_rn(1.0f, __fmul_rn(oms_f, t));                         // 1 - (1-sigma) t
+        r.sig = f_sub(1.0f, f_mul(oms_f, t));                         // 1 - (1-sigma) t
         r.a = r.sig;
     } else {  // VP
         r.c0 = c0p[b]; r.c1 = c1p[b]; r.sig = sigma_f; r.a = 0.f;
@@ -49,21 +63,21 @@ __device__ __forceinline__ void point(const RowCoef& r, float oms_f, float a0, f
                                       bool have_xt, float xin, float& xt, float& ut) {
     const float HALF_PI = 1.5707963267948966f;
     if (VARIANT == CFM_VARIANT_ICFM) {
-        const float mu = __fadd_rn(__fmul_rn(r.c1, a1), __fmul_rn(r.c0, a0));
-        xt = have_xt ? xin : __fadd_rn(mu, __fmul_rn(r.sig, e));
-        ut = __fsub_rn(a1, a0);
+        const float mu = f_add(f_mul(r.c1, a1), f_mul(r.c0, a0));
+        xt = have_xt ? xin : f_add(mu, f_mul(r.sig, e));
+        ut = f_sub(a1, a0);
     } else if (VARIANT == CFM_VARIANT_SB) {
-        const float mu = __fadd_rn(__fmul_rn(r.c1, a1), __fmul_rn(r.c0, a0));
-        xt = have_xt ? xin : __fadd_rn(mu, __fmul_rn(r.sig, e));
-        ut = __fsub_rn(__fadd_rn(__fmul_rn(r.a, __fsub_rn(xt, mu)), a1), a0);
+        const float mu = f_add(f_mul(r.c1, a1), f_mul(r.c0, a0));
+        xt = have_xt ? xin : f_add(mu, f_mul(r.sig, e));
+        ut = f_sub(f_add(f_mul(r.a, f_sub(xt, mu)), a1), a0);
     } else if (VARIANT == CFM_VARIANT_TARGET) {
-        const float mu = __fmul_rn(r.c1, a1);
-        xt = have_xt ? xin : __fadd_rn(mu, __fmul_rn(r.sig, e));
-        ut = __fdiv_rn(__fsub_rn(a1, __fmul_rn(oms_f, xt)), r.a);
+        const float mu = f_mul(r.c1, a1);
+        xt = have_xt ? xin : f_add(mu, f_mul(r.sig, e));
+        ut = f_div(f_sub(a1, f_mul(oms_f, xt)), r.a);
     } else {
-        const float mu = __fadd_rn(__fmul_rn(r.c0, a0), __fmul_rn(r.c1, a1));
-        xt = have_xt ? xin : __fadd_rn(mu, __fmul_rn(r.sig, e));
-        ut = __fmul_rn(HALF_PI, __fsub_rn(__fmul_rn(r.c0, a1), __fmul_rn(r.c1, a0)));
+        const float mu = f_add(f_mul(r.c0, a0), f_mul(r.c1, a1));
+        xt = have_xt ? xin : f_add(mu, f_mul(r.sig, e));
+        ut = f_mul(HALF_PI, f_sub(f_mul(r.c0, a1), f_mul(r.c1, a0)));
     }
 }
 

@@ -170,7 +170,7 @@ static int sd_run(P plan, int B0, int B1, const double* u01, int n, int64_t* i, 
 }
 
 // layout of the Sinkhorn workspace (must match sinkhorn.hip)
-struct SkStateView { int done, iters_done, vfinal, pad; double err2[2]; double last_err; };
+struct SkStateView { int done, iters_done, vfinal, precise; double err2[2]; double last_err; };
 
 __global__ void sd_pick_v(const SkStateView* st, const double* v0, const double* v1, int B1,
                           double* vout) {
@@ -178,10 +178,10 @@ __global__ void sd_pick_v(const SkStateView* st, const double* v0, const double*
     if (j < B1) vout[j] = st->vfinal ? v1[j] : v0[j];
 }
 
-extern "C" int cfm_plan_sample_dense(const float* M, int B0, int B1, float reg, const void* sk_ws,
+extern "C" int cfm_plan_sample_dense(const float* M, int B0, int B1, double reg, const void* sk_ws,
                                      const double* u01, int n, int64_t* i, int64_t* j, void* ws,
                                      void* stream) {
-    if (!M || !sk_ws || !ws || B0 <= 0 || B1 <= 0 || n < 0 || !(reg > 0.f)) return CFM_EINVAL;
+    if (!M || !sk_ws || !ws || B0 <= 0 || B1 <= 0 || n < 0 || !(reg > 0.0)) return CFM_EINVAL;
     if (n > 0 && (!u01 || !i || !j)) return CFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // ws: [row sums B0][v copy B1]
@@ -193,7 +193,7 @@ extern "C" int cfm_plan_sample_dense(const float* M, int B0, int B1, float reg, 
     const double* v0 = u + B0;
     const double* v1 = v0 + B1;
     hipLaunchKernelGGL(sd_pick_v, dim3((B1 + 255) / 256), dim3(256), 0, s, st, v0, v1, B1, vsel);
-    PlanFromPotentials plan{M, u, vsel, 1.0 / (double)reg, B1};
+    PlanFromPotentials plan{M, u, vsel, 1.0 / reg, B1};
     return sd_run(plan, B0, B1, u01, n, i, j, ws, s);
 }
 

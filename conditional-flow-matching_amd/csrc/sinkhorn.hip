@@ -21,6 +21,7 @@
 // Convergence is decided on the device (no host sync): every kernel of the
 // pre-enqueued sequence reads the state block and exits if `done` is set.
 #include "cfm_common.h"
+#include <type_traits>
 
 #define SK_NEG (-1.0e300)
 #define SK_NCHUNK_MAX 64
@@ -29,7 +30,7 @@ struct SkState {
     int done;        // set once converged
     int iters_done;  // POT's ii+1 at break, or max_iter
     int vfinal;      // which v buffer holds the final v
-    int pad;
+    int precise;     // 1: fp64 exp/accumulate (near convergence)
     double err2[2];  // sum of squared marginal violations (ping-pong)
     double last_err;
 };
@@ -78,7 +79,7 @@ __global__ void sk_init(SkState* st, double* u, double* v0, double* v1, int B0, 
     if (i < B0) u[i] = 0.0;
     if (i < B1) { v0[i] = 0.0; v1[i] = 0.0; }
     if (i == 0) {
-        st->done = 0; st->iters_done = max_iter; st->vfinal = (max_iter - 1) & 1; st->pad = 0;
+        st->done = 0; st->iters_done = max_iter; st->vfinal = (max_iter - 1) & 1; st->precise = 0;
         st->err2[0] = 0.0; st->err2[1] = 0.0; st->last_err = 1.0;
     }
 }
@@ -94,13 +95,16 @@ __device__ __forceinline__ float4 sk_load4(const float* __restrict__ row, int j,
 }
 
 // Column pass: partial LSE_i(u_i - M_ij/reg) over a strip of rows.
-__global__ __launch_bounds__(256) void sk_col_pass(const float* __restrict__ M, int B0, int B1,
-                                                   double inv_reg, const SkState* __restrict__ st,
-                                                   const double* __restrict__ u,
-                                                   double* __restrict__ pm,
-                                                   double* __restrict__ ps, int rows_per_chunk,
-                                                   int vec) {
-    if (st->done) return;
+// PRECISE = false: exponent formed in fp64, exp() in fp32 (fast, HBM-bound).
+// PRECISE = true : exp() and the running sums in fp64 (engaged near convergence,
+// where the fp32 exp noise floor ~1e-7 would hide a 1e-9 marginal violation).
+template <bool PRECISE>
+__device__ __forceinline__ void sk_col_body(const float* __restrict__ M, int B0, int B1,
+                                            double inv_reg, const double* __restrict__ u,
+                                            double* __restrict__ pm, double* __restrict__ ps,
+                                            int rows_per_chunk, int vec, double (*sm)[256],
+                                            double (*ss)[256]) {
+    typedef typename std::conditional<PRECISE, double, float>::type acc_t;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 256 + lane * 4;
     const int chunk = blockIdx.y;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void sk_col_pass(const float* __restrict__ M, 
     const bool v4 = vec && (j + 3 < B1);
 
     double m[4] = {SK_NEG, SK_NEG, SK_NEG, SK_NEG};
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    acc_t s[4] = {0, 0, 0, 0};
 
     constexpr int U = 8;
     for (int r0 = r_beg + wv * U; r0 < r_end; r0 += 4 * U) {
@@ -136,18 +140,23 @@ __global__ __launch_bounds__(256) void sk_col_pass(const float* __restrict__ M, 
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float acc = s[q] * __expf((float)(m[q] - mx[q]));
+            if (PRECISE) {
+                double acc = (double)s[q] * exp(m[q] - mx[q]);
 #pragma unroll
-            for (int k = 0; k < U; ++k) acc += __expf((float)(x[k][q] - mx[q]));
-            s[q] = acc;
+                for (int k = 0; k < U; ++k) acc += exp(x[k][q] - mx[q]);
+                s[q] = (acc_t)acc;
+            } else {
+                float acc = (float)s[q] * __expf((float)(m[q] - mx[q]));
+#pragma unroll
+                for (int k = 0; k < U; ++k) acc += __expf((float)(x[k][q] - mx[q]));
+                s[q] = (acc_t)acc;
+            }
             m[q] = mx[q];
         }
     }
     // merge the 4 waves of the workgroup (same columns, different rows)
-    __shared__ double sm[4][256];
-    __shared__ float ss[4][256];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { sm[wv][lane * 4 + q] = m[q]; ss[wv][lane * 4 + q] = s[q]; }
+    for (int q = 0; q < 4; ++q) { sm[wv][lane * 4 + q] = m[q]; ss[wv][lane * 4 + q] = (double)s[q]; }
     __syncthreads();
     const int c = threadIdx.x;  // one column per thread
     const int jc = blockIdx.x * 256 + c;
@@ -155,10 +164,23 @@ __global__ __launch_bounds__(256) void sk_col_pass(const float* __restrict__ M, 
         double mm = fmax(fmax(sm[0][c], sm[1][c]), fmax(sm[2][c], sm[3][c]));
         double tot = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) tot += (double)ss[w][c] * exp(sm[w][c] - mm);
+        for (int w = 0; w < 4; ++w) tot += ss[w][c] * exp(sm[w][c] - mm);
         pm[(size_t)chunk * B1 + jc] = mm;
         ps[(size_t)chunk * B1 + jc] = tot;
     }
+}
+
+__global__ __launch_bounds__(256) void sk_col_pass(const float* __restrict__ M, int B0, int B1,
+                                                   double inv_reg, const SkState* __restrict__ st,
+                                                   const double* __restrict__ u,
+                                                   double* __restrict__ pm,
+                                                   double* __restrict__ ps, int rows_per_chunk,
+                                                   int vec) {
+    __shared__ double sm[4][256];
+    __shared__ double ss[4][256];
+    if (st->done) return;
+    if (st->precise) sk_col_body<true>(M, B0, B1, inv_reg, u, pm, ps, rows_per_chunk, vec, sm, ss);
+    else             sk_col_body<false>(M, B0, B1, inv_reg, u, pm, ps, rows_per_chunk, vec, sm, ss);
 }
 
 // Merge strip partials -> v_new; accumulate the previous iteration's marginal
@@ -194,45 +216,19 @@ __global__ __launch_bounds__(256) void sk_col_finalize(int B1, int nchunk, doubl
     }
 }
 
-// Row pass: u_i = log a - LSE_j(v_j - M_ij/reg); also the convergence decision
-// for the previous iteration (every workgroup derives it from the same data).
-__global__ __launch_bounds__(256) void sk_row_pass(const float* __restrict__ M, int B0, int B1,
-                                                   double inv_reg, double loga,
-                                                   SkState* __restrict__ st,
-                                                   const double* __restrict__ v,
-                                                   double* __restrict__ u, int rows_per_wg,
-                                                   int check, int slot, double stop_thr, int ii,
-                                                   int vec, int v_in_lds) {
-    if (st->done) return;
-    if (check) {
-        const double err = sqrt(st->err2[slot]);
-        if (err < stop_thr) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
-                st->last_err = err;
-                st->iters_done = ii;          // iterations 0..ii-1 ran; POT broke at ii-1
-                st->vfinal = (ii - 1) & 1;
-                __threadfence();
-                st->done = 1;
-            }
-            return;
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0) st->last_err = err;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->err2[slot ^ 1] = 0.0;  // next accumulation slot
-
-    extern __shared__ __attribute__((aligned(16))) double vs[];
-    if (v_in_lds) {
-        for (int j = threadIdx.x; j < B1; j += 256) vs[j] = v[j];
-        __syncthreads();
-    }
-    const double* vv = v_in_lds ? vs : v;
+template <bool PRECISE>
+__device__ __forceinline__ void sk_row_body(const float* __restrict__ M, int B0, int B1,
+                                            double inv_reg, double loga,
+                                            const double* __restrict__ vv, double* __restrict__ u,
+                                            int rows_per_wg, int vec) {
+    typedef typename std::conditional<PRECISE, double, float>::type acc_t;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r_beg = blockIdx.x * rows_per_wg;
     const int r_end = min(B0, r_beg + rows_per_wg);
     for (int r = r_beg + wv; r < r_end; r += 4) {
         const float* row = M + (size_t)r * B1;
         double m = SK_NEG;
-        float s = 0.f;
+        acc_t s = 0;
         constexpr int U = 4;
         for (int j0 = lane * 4; j0 < B1; j0 += 256 * U) {
             float4 c[U];
@@ -253,18 +249,68 @@ __global__ __launch_bounds__(256) void sk_row_pass(const float* __restrict__ M, 
                     mx = fmax(mx, x[k][q]);
                 }
             }
-            float acc = s * __expf((float)(m - mx));
+            if (PRECISE) {
+                double acc = (double)s * exp(m - mx);
 #pragma unroll
-            for (int k = 0; k < U; ++k)
+                for (int k = 0; k < U; ++k)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc += __expf((float)(x[k][q] - mx));
-            s = acc;
+                    for (int q = 0; q < 4; ++q) acc += exp(x[k][q] - mx);
+                s = (acc_t)acc;
+            } else {
+                float acc = (float)s * __expf((float)(m - mx));
+#pragma unroll
+                for (int k = 0; k < U; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc += __expf((float)(x[k][q] - mx));
+                s = (acc_t)acc;
+            }
             m = mx;
         }
         const double mm = wave_max_d(m);
         const double tot = wave_sum_d((double)s * exp(m - mm));
         if (lane == 0) u[r] = loga - (mm + log(tot));
     }
+}
+
+// Row pass: u_i = log a - LSE_j(v_j - M_ij/reg); also the convergence decision
+// for the previous iteration (every workgroup derives it from the same data).
+__global__ __launch_bounds__(256) void sk_row_pass(const float* __restrict__ M, int B0, int B1,
+                                                   double inv_reg, double loga,
+                                                   SkState* __restrict__ st,
+                                                   const double* __restrict__ v,
+                                                   double* __restrict__ u, int rows_per_wg,
+                                                   int check, int slot, double stop_thr, int ii,
+                                                   int vec, int v_in_lds, double precise_below) {
+    if (st->done) return;
+    if (check) {
+        const double err = sqrt(st->err2[slot]);
+        if (err < stop_thr) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                st->last_err = err;
+                st->iters_done = ii;          // iterations 0..ii-1 ran; POT broke at ii-1
+                st->vfinal = (ii - 1) & 1;
+                __threadfence();
+                st->done = 1;
+            }
+            return;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->last_err = err;
+            // fp32 exp leaves ~1e-7 relative noise per column sum -> ~1e-7/sqrt(B1) in the L2
+            // violation; go precise well above that floor when the caller asks for less.
+            if (!st->precise && err < precise_below && stop_thr < precise_below) st->precise = 1;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->err2[slot ^ 1] = 0.0;  // next accumulation slot
+
+    extern __shared__ __attribute__((aligned(16))) double vs[];
+    if (v_in_lds) {
+        for (int j = threadIdx.x; j < B1; j += 256) vs[j] = v[j];
+        __syncthreads();
+    }
+    const double* vv = v_in_lds ? vs : v;
+    if (st->precise) sk_row_body<true>(M, B0, B1, inv_reg, loga, vv, u, rows_per_wg, vec);
+    else             sk_row_body<false>(M, B0, B1, inv_reg, loga, vv, u, rows_per_wg, vec);
 }
 
 __global__ void sk_finish(SkState* st, const double* u, const double* v0, const double* v1,
@@ -282,10 +328,10 @@ __global__ void sk_finish(SkState* st, const double* u, const double* v0, const 
     }
 }
 
-extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, int max_iter,
-                                    float stop_thr, int check_every, float* f, float* g,
+extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, int max_iter,
+                                    double stop_thr, int check_every, float* f, float* g,
                                     int* iters_done, float* last_err, void* ws, void* stream) {
-    if (!M || !ws || B0 <= 0 || B1 <= 0 || !(reg > 0.f) || max_iter < 0 || check_every <= 0)
+    if (!M || !ws || B0 <= 0 || B1 <= 0 || !(reg > 0.0) || max_iter < 0 || check_every <= 0)
         return CFM_EINVAL;
     if (((uintptr_t)ws & 15) != 0) return CFM_EALIGN;
     hipStream_t s = (hipStream_t)stream;
@@ -294,8 +340,9 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, i
     const int rows_per_chunk = (B0 + nchunk - 1) / nchunk;
     const int col_tiles = (B1 + 255) / 256;
     const int vec = ((B1 & 3) == 0) && (((uintptr_t)M & 15) == 0);
-    const double inv_reg = 1.0 / (double)reg;
+    const double inv_reg = 1.0 / reg;
     const double a = 1.0 / B0, b = 1.0 / B1;
+    const double precise_below = 1e-4 / sqrt((double)B1);
     const double loga = log(a), logb = log(b);
     const int rows_per_wg = 8;
     const int row_wgs = (B0 + rows_per_wg - 1) / rows_per_wg;
@@ -333,8 +380,8 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, i
                            w.st, w.pm, w.ps, w.v[(ii + 1) & 1], w.v[ii & 1], check, slot);
         if (trailing) break;
         hipLaunchKernelGGL(sk_row_pass, dim3(row_wgs), dim3(256), lds, s, M, B0, B1, inv_reg, loga,
-                           w.st, w.v[ii & 1], w.u, rows_per_wg, check, slot, (double)stop_thr, ii,
-                           vec, v_in_lds);
+                           w.st, w.v[ii & 1], w.u, rows_per_wg, check, slot, stop_thr, ii,
+                           vec, v_in_lds, precise_below);
         if (poll && (ii & 511) == 511) {
             int rc = cfm_hip(hipMemcpyAsync(&host_done, &w.st->done, sizeof(int), hipMemcpyDeviceToHost, s));
             if (rc) return rc;
@@ -345,7 +392,7 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, i
     }
     const int pending = (max_iter >= 1) && (((max_iter - 1) % check_every) == 0);
     hipLaunchKernelGGL(sk_finish, dim3((n + 255) / 256), dim3(256), 0, s, w.st, w.u, w.v[0], w.v[1],
-                       B0, B1, (double)reg, f, g, iters_done, last_err, pending, max_iter & 1);
+                       B0, B1, reg, f, g, iters_done, last_err, pending, max_iter & 1);
     return cfm_status();
 }
 
@@ -394,22 +441,22 @@ __global__ __launch_bounds__(256) void sk_plan_f64(const float* __restrict__ M, 
     }
 }
 
-extern "C" int cfm_sinkhorn_plan_f64(const float* M, int B0, int B1, float reg, const void* ws,
+extern "C" int cfm_sinkhorn_plan_f64(const float* M, int B0, int B1, double reg, const void* ws,
                                      double* pi, void* stream) {
-    if (!M || !ws || !pi || B0 <= 0 || B1 <= 0 || !(reg > 0.f)) return CFM_EINVAL;
+    if (!M || !ws || !pi || B0 <= 0 || B1 <= 0 || !(reg > 0.0)) return CFM_EINVAL;
     SkWs w = sk_carve((void*)ws, B0, B1);
     hipLaunchKernelGGL(sk_plan_f64, dim3(2048), dim3(256), 0, (hipStream_t)stream, M, B0, B1,
-                       1.0 / (double)reg, w.st, w.u, w.v[0], w.v[1], pi, (double*)nullptr);
+                       1.0 / reg, w.st, w.u, w.v[0], w.v[1], pi, (double*)nullptr);
     return cfm_status();
 }
 
-extern "C" int cfm_sinkhorn_cost_f64(const float* M, int B0, int B1, float reg, const void* ws,
+extern "C" int cfm_sinkhorn_cost_f64(const float* M, int B0, int B1, double reg, const void* ws,
                                      double* out, void* stream) {
-    if (!M || !ws || !out || B0 <= 0 || B1 <= 0 || !(reg > 0.f)) return CFM_EINVAL;
+    if (!M || !ws || !out || B0 <= 0 || B1 <= 0 || !(reg > 0.0)) return CFM_EINVAL;
     SkWs w = sk_carve((void*)ws, B0, B1);
     int rc = cfm_hip(hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream));
     if (rc) return rc;
     hipLaunchKernelGGL(sk_plan_f64, dim3(2048), dim3(256), 0, (hipStream_t)stream, M, B0, B1,
-                       1.0 / (double)reg, w.st, w.u, w.v[0], w.v[1], (double*)nullptr, out);
+                       1.0 / reg, w.st, w.u, w.v[0], w.v[1], (double*)nullptr, out);
     return cfm_status();
 }

@@ -77,12 +77,15 @@ int cfm_sqrt_inplace_f32(float* M, size_t n, void* stream);
  *   v = log b - LSE_i(-M/reg + u),  u = log a - LSE_j(-M/reg + v),
  * marginal check every `check_every` iterations (ii % check_every == 0):
  * err = || sum_i exp(-M/reg + u + v) - b ||_2 ; stop when err < stop_thr or
- * after max_iter iterations.  Outputs the potentials f = reg*u [B0],
+ * after max_iter iterations (reg, stop_thr are doubles: the reference passes
+ * Python floats to POT).  The iteration runs with fp32 exp() (HBM-bound fast
+ * path) and switches itself to fp64 exp once the measured violation approaches
+ * the fp32 noise floor, so stop_thr = 1e-9 is honoured.  Outputs f = reg*u [B0],
  * g = reg*v [B1] (fp32), *iters_done, *last_err (device scalars).
  * ws: cfm_workspace_bytes(CFM_OP_SINKHORN,B0,B1,0) bytes, 16-byte aligned;
  * it keeps the fp64 potentials (see cfm_sinkhorn_potentials_f64). */
-int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, float reg, int max_iter,
-                         float stop_thr, int check_every, float* f, float* g,
+int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, int max_iter,
+                         double stop_thr, int check_every, float* f, float* g,
                          int* iters_done, float* last_err, void* ws, void* stream);
 
 /* Copy the fp64 log-scalings u [B0], v [B1] left in `ws` by the last
@@ -93,12 +96,12 @@ int cfm_sinkhorn_potentials_f64(const void* ws, int B0, int B1, double* u, doubl
 /* Dense plan  pi[i,j] = exp(u_i + v_j - M[i,j]/reg)  in fp64 from the fp64
  * log-scalings in `ws`  — what get_map() hands back to Python,
  * torchcfm/optimal_transport.py:87 (return value of pot.sinkhorn). */
-int cfm_sinkhorn_plan_f64(const float* M, int B0, int B1, float reg, const void* ws,
+int cfm_sinkhorn_plan_f64(const float* M, int B0, int B1, double reg, const void* ws,
                           double* pi, void* stream);
 
 /* sum_ij pi_ij * M_ij — pot.sinkhorn2 value, torchcfm/optimal_transport.py:288.
  * out: one double. */
-int cfm_sinkhorn_cost_f64(const float* M, int B0, int B1, float reg, const void* ws,
+int cfm_sinkhorn_cost_f64(const float* M, int B0, int B1, double reg, const void* ws,
                           double* out, void* stream);
 
 /* K4 — exact optimal assignment for uniform, equal-size marginals.
@@ -129,7 +132,7 @@ int cfm_plan_sample_perm(const int* perm, const double* u01, int B, int n,
  * semantics as np.random.choice              torchcfm/optimal_transport.py:116-121.
  * ws: cfm_workspace_bytes(CFM_OP_SAMPLE_DENSE,B0,B1,0); `sk_ws` is the Sinkhorn
  * workspace holding u,v. */
-int cfm_plan_sample_dense(const float* M, int B0, int B1, float reg, const void* sk_ws,
+int cfm_plan_sample_dense(const float* M, int B0, int B1, double reg, const void* sk_ws,
                           const double* u01, int n, int64_t* i, int64_t* j, void* ws,
                           void* stream);
 
@@ -149,7 +152,9 @@ int cfm_plan_sample_pi_f64(const double* pi, int B0, int B1, const double* u01, 
  * NULL only when sigma terms vanish is NOT assumed: pass eps always).
  * VP: c0 = cos(pi/2 t), c1 = sin(pi/2 t) are passed in ([B] each, computed by
  * the caller's tensor library so they match its libm bit for bit); NULL for
- * the other variants.  `sigma` is the Python-side value (double): the kernel
+ * the other variants, except SB where c0 (optional) = sigma_t = sigma*sqrt(t(1-t))
+ * as the caller's library computes it (eager sqrt is not IEEE on every backend).
+ * `sigma` is the Python-side value (double): the kernel
  * uses (float)sigma and, for TARGET, (float)(1.0 - sigma) exactly as eager
  * PyTorch casts Python scalars.  Outputs xt, ut [B,d]; x0g, x1g (may be NULL)
  * receive the gathered pairs.  xt_in (may be NULL): use this xt instead of

@@ -35,8 +35,21 @@ def test_golden_fm_case(key):
     np.random.seed(1994)
     t, xt, ut, eps = fm.sample_location_and_conditional_flow(g["x0"], g["x1"], return_noise=True)
     assert torch.equal(t, g["t"]) and torch.equal(eps, g["eps"])
-    assert torch.all(xt.eq(g["xt"])), (key, (xt - g["xt"]).abs().max())
-    assert torch.all(ut.eq(g["ut"])), (key, (ut - g["ut"]).abs().max())
+    if mname.startswith("sb"):
+        # sigma_t = sigma*sqrt(t(1-t)) comes from the HOST tensor library (reference line :446).
+        # torch.sqrt on CPU is MKL-VML: not correctly rounded and host dependent (0.6 % of inputs
+        # are 1 ulp off on the Intel box that recorded the goldens, a different 0.6 % on the GPU
+        # box's EPYC), so SB goldens recorded elsewhere are reproducible to 1 ulp of sigma_t only.
+        # Bit-exact SB parity against same-host eager torch is asserted in
+        # test_gpu_kernels.py::test_xt_ut_bit_exact and test_gpu_reference_suite.py::test_fm.
+        tb = g["t"].reshape(-1, *([1] * (xt.dim() - 1)))
+        a = ((1 - 2 * tb) / (2 * tb * (1 - tb) + 1e-8)).abs()
+        ulp = 1.2e-7 * (xt.abs() + g["eps"].abs() * float(eval(sig)))
+        assert torch.all((xt - g["xt"]).abs() <= 2 * ulp), (key, (xt - g["xt"]).abs().max())
+        assert torch.all((ut - g["ut"]).abs() <= (a + 1) * 4 * ulp + 1e-6), (key, (ut - g["ut"]).abs().max())
+    else:
+        assert torch.all(xt.eq(g["xt"])), (key, (xt - g["xt"]).abs().max())
+        assert torch.all(ut.eq(g["ut"])), (key, (ut - g["ut"]).abs().max())
 
 
 def test_golden_ot_cases(golden_dir):
