@@ -64,15 +64,24 @@ struct AsgState {
     int mode, n, phase, round;
     int nU, stop, arr_round, error;
     int nF, fidx, i0, nS;
-    int jfree, certified, cert_bad, pad0;
+    int jfree, certified, cert_bad, nN;
     // stats
     int st_auction_rounds, st_arr_rounds, st_free_after_arr, st_sap_batches;
-    int st_sap_row_scans, st_total_row_scans, st_steps, pad1;
+    int st_sap_row_scans, st_total_row_scans, st_steps, cur;
     double eps, eps_last, theta, stop_frac;
     double cmin, cmax, dfree, total_cost;
     unsigned long long minslack_ord, pad2;
     unsigned cmin_bits, cmax_bits;  // ordered-float atomics
     int round_cap, arr_cap;
+    int nFC, pad3;
+};
+
+// SAP scan list entry arrays (two copies: current / next)
+struct SList {
+    int* col;       // column j
+    int* row;       // owner[j]
+    double* base;   // dist[j] when it was listed
+    double* rj;     // c[row,j] + p[j]  (= u_row: matched edge is tight)
 };
 
 struct AsgWs {
@@ -86,14 +95,14 @@ struct AsgWs {
     int* bidcol;
     int* listA;       // unassigned rows (current)
     int* listF;       // free rows snapshot for SAP
-    int* listS;       // SAP scan list (columns)
+    int* listFC;      // free columns during SAP
     int* pred;
-    int* dirty;
+    SList S[2];
 };
 
 static inline size_t asg_ws_bytes(int n) {
     size_t N = (size_t)n;
-    return 512 + 8 * N * 4 + 4 * N * 8 + 256;
+    return 512 + 8 * N * (4 + 4) + 4 * N * (7 + 4) + 256;
 }
 
 static inline AsgWs asg_carve(void* ws, int n) {
@@ -103,14 +112,15 @@ static inline AsgWs asg_carve(void* ws, int n) {
     w.bidval = (double*)q; q += 8 * N;
     w.dist = (double*)q; q += 8 * N;
     w.packed = (unsigned long long*)q; q += 8 * N;
+    for (int c = 0; c < 2; ++c) { w.S[c].base = (double*)q; q += 8 * N; w.S[c].rj = (double*)q; q += 8 * N; }
     w.a = (int*)q; q += 4 * N;
     w.owner = (int*)q; q += 4 * N;
     w.bidcol = (int*)q; q += 4 * N;
     w.listA = (int*)q; q += 4 * N;
     w.listF = (int*)q; q += 4 * N;
-    w.listS = (int*)q; q += 4 * N;
+    w.listFC = (int*)q; q += 4 * N;
     w.pred = (int*)q; q += 4 * N;
-    w.dirty = (int*)q; q += 4 * N;
+    for (int c = 0; c < 2; ++c) { w.S[c].col = (int*)q; q += 4 * N; w.S[c].row = (int*)q; q += 4 * N; }
     return w;
 }
 
@@ -130,22 +140,34 @@ __device__ __forceinline__ float ord2f(unsigned k) {
 __global__ __launch_bounds__(256) void asg_minmax(const float* __restrict__ M, size_t n2,
                                                   AsgState* st) {
     float lo = INFINITY, hi = -INFINITY;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
-        float v = M[i];
-        lo = fminf(lo, v); hi = fmaxf(hi, v);
+    const size_t n4 = n2 / 4;
+    const float4* M4 = reinterpret_cast<const float4*>(M);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = M4[i];
+        lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
+        hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        lo = fminf(lo, M[i]); hi = fmaxf(hi, M[i]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o, 64));
         hi = fmaxf(hi, __shfl_xor(hi, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
+    __shared__ float slo[4], shi[4];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+        hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
         atomicMin(&st->cmin_bits, f2ord(lo));
         atomicMax(&st->cmax_bits, f2ord(hi));
     }
 }
 
 // --------------------------------------------------------- wide: auction -----
+#define WT 1024   // threads of the wide kernel (16 waves)
 // One wave per bidding row.  r_k = c_ik + p_k (fp64).  Top-2 over the row.
 struct Top2 { double b; double s; int j; };
 
@@ -218,40 +240,61 @@ __device__ void wide_bid(const float* __restrict__ M, const AsgWs& w, const AsgS
 }
 
 // ------------------------------------------------------------ wide: SAP ------
-// Relax all rows owner[j], j in S.  Workgroup g owns columns [64g, 64g+64):
-// lane <-> column, the 4 waves split S, LDS merge, single writer per column.
-__device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+// Relax every listed row.  Workgroup g owns columns [64g, 64g+64): lane <-> column
+// (single writer: dist/pred stay consistent without atomics), the 16 waves split the
+// list, 8 independent row loads in flight per lane, LDS merge.  The writer lane
+// appends improved assigned columns to the NEXT list (one atomic per append).
+__device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState* st,
                            double* sh_d, int* sh_i) {
-    const int n = st->n, nS = st->nS;
+    const int n = st->n, nS = st->nS, cur = st->cur;
+    const double dfree = st->dfree;
+    const SList L = w.S[cur], Nx = w.S[cur ^ 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_groups = (n + 63) / 64;
+    constexpr int Q = 8, NW = WT / 64;
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const int k = g * 64 + lane;
         const bool ok = k < n;
         const double pk = ok ? w.p[k] : 0.0;
-        double best = INFINITY; int bi = -1;
-        for (int t = wv; t < nS; t += 4) {
-            const int j = w.listS[t];                 // wave-uniform
-            const int i = w.owner[j];
-            const double base = w.dist[j];
-            const double rj = (double)M[(size_t)i * n + j] + w.p[j];   // = u_i (matched edge tight)
-            if (ok && k != j) {
-                double rc = ((double)M[(size_t)i * n + k] + pk) - rj;
-                rc = fmax(rc, 0.0);                   // dual feasible up to rounding
-                const double cand = base + rc;
-                if (cand < best) { best = cand; bi = i; }
+        double best = INFINITY; int bi = 0x7fffffff;
+        for (int t0 = wv * Q; t0 < nS; t0 += NW * Q) {
+            int ri[Q], cj[Q]; double bs[Q], rj[Q]; float c[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int t = t0 + q;
+                const bool v = t < nS;
+                ri[q] = v ? L.row[t] : 0; cj[q] = v ? L.col[t] : -1;
+                bs[q] = v ? L.base[t] : INFINITY; rj[q] = v ? L.rj[t] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                c[q] = (ok && bs[q] < dfree) ? M[(size_t)ri[q] * n + k] : 0.f;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if (ok && bs[q] < dfree && k != cj[q]) {
+                    double rc = ((double)c[q] + pk) - rj[q];
+                    rc = fmax(rc, 0.0);                   // dual feasible up to rounding
+                    const double cand = bs[q] + rc;
+                    if (cand < best || (cand == best && ri[q] < bi)) { best = cand; bi = ri[q]; }
+                }
             }
         }
         sh_d[wv * 64 + lane] = best; sh_i[wv * 64 + lane] = bi;
         __syncthreads();
         if (wv == 0 && ok) {
 #pragma unroll
-            for (int q = 1; q < 4; ++q) {
-                const double c2 = sh_d[q * 64 + lane];
-                if (c2 < best) { best = c2; bi = sh_i[q * 64 + lane]; }
+            for (int q = 1; q < NW; ++q) {
+                const double c2 = sh_d[q * 64 + lane]; const int i2 = sh_i[q * 64 + lane];
+                if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; }
             }
-            if (bi >= 0 && best < w.dist[k]) {
-                w.dist[k] = best; w.pred[k] = bi; w.dirty[k] = 1;
+            if (best < w.dist[k]) {
+                w.dist[k] = best; w.pred[k] = bi;
+                const int ow = w.owner[k];
+                if (ow >= 0 && best < dfree) {
+                    const int idx = atomicAdd(&st->nN, 1);
+                    Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best;
+                    Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
+                }
             }
         }
         __syncthreads();
@@ -282,14 +325,15 @@ __device__ void wide_cert(const float* __restrict__ M, const AsgWs& w, AsgState*
     }
 }
 
-__global__ __launch_bounds__(256) void asg_wide(const float* __restrict__ M, AsgWs w) {
-    __shared__ double sh_d[256];
-    __shared__ int sh_i[256];
+__global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgWs w) {
+    __shared__ double sh_d[WT];
+    __shared__ int sh_i[WT];
     AsgState* st = w.st;
     const int mode = st->mode;
     if (mode == MODE_DONE || st->error) return;
-    const int wave_gid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * 4;
+    // consecutive work items go to different workgroups (different CUs)
+    const int wave_gid = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    const int n_waves = gridDim.x * (WT / 64);
     if (mode == MODE_AUCTION || mode == MODE_ARR) wide_bid(M, w, st, wave_gid, n_waves);
     else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i);
     else if (mode == MODE_CERT) wide_cert(M, w, st, wave_gid, n_waves);
@@ -379,13 +423,29 @@ __device__ void ctrl_award(const AsgWs& w, AsgState* st, int* sh) {
     __syncthreads();
 }
 
-// Start the search from the next free row (or move to CERT).  Leaves dist/pred/
-// dirty initialised.  Returns false when there is no free row left.
+// best free column under the current labels
+__device__ void ctrl_dfree(const AsgWs& w, AsgState* st, double* shd, int* shi) {
+    const int nFC = st->nFC;
+    double lm = INFINITY; int li = 0x7fffffff;
+    for (int t = threadIdx.x; t < nFC; t += CT) {
+        const int k = w.listFC[t]; const double dk = w.dist[k];
+        if (dk < lm || (dk == lm && k < li)) { lm = dk; li = k; }
+    }
+    double dfree; int jfree;
+    block_argmin(lm, li, &dfree, &jfree, shd, shi);
+    if (threadIdx.x == 0) { st->dfree = dfree; st->jfree = jfree; }
+    __syncthreads();
+}
+
+// Start the search from the next free row: labels from row i0, first scan list.
+// Returns false when there is no free row left.
 __device__ bool ctrl_sap_begin(const float* __restrict__ M, const AsgWs& w, AsgState* st,
-                               double* shd, int* shi) {
+                               double* shd, int* shi, int* sh) {
     const int n = st->n;
     if (st->fidx >= st->nF) return false;
     const int i0 = w.listF[st->fidx];
+    const int cur = st->cur;
+    __syncthreads();
     const float* row = M + (size_t)i0 * n;
     double lm = INFINITY; int li = 0x7fffffff;
     for (int k = threadIdx.x; k < n; k += CT) {
@@ -398,43 +458,50 @@ __device__ bool ctrl_sap_begin(const float* __restrict__ M, const AsgWs& w, AsgS
     for (int k = threadIdx.x; k < n; k += CT) {
         w.dist[k] = w.dist[k] - rmin;       // >= 0, exact zero at the argmin
         w.pred[k] = i0;
-        w.dirty[k] = (w.owner[k] >= 0) ? 1 : 0;
     }
-    if (threadIdx.x == 0) st->i0 = i0;
+    if (threadIdx.x == 0) { st->i0 = i0; st->nN = 0; }
+    __syncthreads();
+    ctrl_dfree(w, st, shd, shi);
+    const double dfree = st->dfree;
+    const SList L = w.S[cur];
+    int base = 0;
+    for (int k0 = 0; k0 < n; k0 += CT) {
+        const int k = k0 + threadIdx.x;
+        int f = 0, ow = -1; double dk = 0.0;
+        if (k < n) { ow = w.owner[k]; dk = w.dist[k]; f = (ow >= 0 && dk < dfree) ? 1 : 0; }
+        int tot;
+        const int off = block_scan_excl(f, &tot, sh);
+        if (f) {
+            const int idx = base + off;
+            L.col[idx] = k; L.row[idx] = ow; L.base[idx] = dk;
+            L.rj[idx] = (double)M[(size_t)ow * n + k] + w.p[k];
+        }
+        base += tot;
+    }
+    if (threadIdx.x == 0) st->nS = base;
     __syncthreads();
     return true;
 }
 
-// dfree/jfree = best free column; S = dirty assigned columns below dfree.
-__device__ void ctrl_sap_select(const AsgWs& w, AsgState* st, double* shd, int* shi, int* sh) {
-    const int n = st->n;
-    double lm = INFINITY; int li = 0x7fffffff;
-    for (int k = threadIdx.x; k < n; k += CT)
-        if (w.owner[k] < 0) { const double dk = w.dist[k]; if (dk < lm || (dk == lm && k < li)) { lm = dk; li = k; } }
-    double dfree; int jfree;
-    block_argmin(lm, li, &dfree, &jfree, shd, shi);
-    int base = 0;
-    for (int k0 = 0; k0 < n; k0 += CT) {
-        const int k = k0 + threadIdx.x;
-        int f = 0;
-        if (k < n && w.dirty[k] && w.owner[k] >= 0) {
-            if (w.dist[k] < dfree) f = 1;
-            else w.dirty[k] = 0;            // can never matter: labels only decrease towards dfree
-        }
-        int tot;
-        const int off = block_scan_excl(f, &tot, sh);
-        if (f) { w.listS[base + off] = k; w.dirty[k] = 0; }
-        base += tot;
-    }
-    if (threadIdx.x == 0) { st->nS = base; st->dfree = dfree; st->jfree = jfree; }
+// After a relax batch: new dfree, swap lists; returns true if another batch is needed.
+__device__ bool ctrl_sap_step(const AsgWs& w, AsgState* st, double* shd, int* shi) {
+    ctrl_dfree(w, st, shd, shi);
+    const double dfree = st->dfree;
+    const int nN = st->nN, cur = st->cur;
+    const SList Nx = w.S[cur ^ 1];
+    int any = 0;
+    for (int t = threadIdx.x; t < nN; t += CT) any |= (Nx.base[t] < dfree) ? 1 : 0;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) { st->cur = cur ^ 1; st->nS = any ? nN : 0; st->nN = 0; }
     __syncthreads();
+    return any != 0;
 }
 
 // dual update + augmentation along pred (path walk in LDS when it fits)
 __device__ void ctrl_sap_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds_pred, bool use_lds) {
     const int n = st->n;
     const double dfree = st->dfree;
-    const int i0 = st->i0, jfree = st->jfree;
+    const int i0 = st->i0, jfree = st->jfree, nFC = st->nFC;
     __syncthreads();
     for (int k = threadIdx.x; k < n; k += CT) {
         if (w.owner[k] >= 0) {
@@ -444,6 +511,9 @@ __device__ void ctrl_sap_finish(const AsgWs& w, AsgState* st, int* lds_a, int* l
         if (use_lds) lds_pred[k] = w.pred[k];
     }
     if (use_lds) for (int i = threadIdx.x; i < n; i += CT) lds_a[i] = w.a[i];
+    // drop jfree from the free-column list (swap with last)
+    for (int t = threadIdx.x; t < nFC; t += CT)
+        if (w.listFC[t] == jfree) w.listFC[t] = w.listFC[nFC - 1];   // single match
     __syncthreads();
     if (threadIdx.x == 0) {
         int j = jfree, guard = 0;
@@ -458,9 +528,16 @@ __device__ void ctrl_sap_finish(const AsgWs& w, AsgState* st, int* lds_a, int* l
             if (j < 0) break;
         }
         if (!closed) st->error = 3;
+        st->nFC = nFC - 1;
         st->st_total_row_scans += 1;
     }
     __syncthreads();
+}
+
+__device__ void ctrl_enter_cert(AsgState* st) {
+    if (threadIdx.x == 0) {
+        st->mode = MODE_CERT; st->minslack_ord = ~0ull; st->total_cost = 0.0; st->cert_bad = 0;
+    }
 }
 
 __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgWs w, int* perm,
@@ -486,8 +563,7 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
             if (!(cr > 0.0)) cr = 1.0;
             st->eps = cr * st->eps;          // eps/eps_last hold the fractions on entry
             st->eps_last = cr * st->eps_last;
-            int stop = (int)(st->stop_frac * n);
-            st->stop = stop;
+            st->stop = (int)(st->stop_frac * n);
             st->mode = MODE_AUCTION; st->phase = 0;
         }
         for (int k = threadIdx.x; k < n; k += CT) w.p[k] = 0.0;
@@ -495,9 +571,11 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
         return;
     }
 
+    bool sap_converged = false;
     if (mode == MODE_AUCTION || mode == MODE_ARR) {
         // snapshot everything the decision needs BEFORE thread 0 mutates the state
         const int bidders = st->nU, round = st->round, round_cap = st->round_cap, stop = st->stop;
+        const int arr_round = st->arr_round, arr_cap = st->arr_cap;
         const double eps_cur = st->eps, eps_last = st->eps_last, theta = st->theta;
         __syncthreads();
         ctrl_award(w, st, sh);
@@ -521,46 +599,53 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
             return;
         }
         // MODE_ARR
-        if (threadIdx.x == 0) { st->arr_round++; st->st_arr_rounds++; }
+        if (threadIdx.x == 0) { st->arr_round = arr_round + 1; st->st_arr_rounds++; }
         __syncthreads();
         if (nU == 0) {
-            if (threadIdx.x == 0) {
-                st->st_free_after_arr = 0;
-                st->mode = MODE_CERT; st->minslack_ord = ~0ull; st->total_cost = 0.0; st->cert_bad = 0;
-            }
+            if (threadIdx.x == 0) st->st_free_after_arr = 0;
+            ctrl_enter_cert(st);
             return;
         }
-        if (st->arr_round < st->arr_cap) return;
-        // -> SAP: snapshot the free rows
+        if (arr_round + 1 < arr_cap) return;
+        // -> SAP: snapshot the free rows and the free columns
         for (int t = threadIdx.x; t < nU; t += CT) w.listF[t] = w.listA[t];
-        if (threadIdx.x == 0) { st->nF = nU; st->fidx = 0; st->st_free_after_arr = nU; st->mode = MODE_SAP; }
+        {
+            int base = 0;
+            for (int k0 = 0; k0 < n; k0 += CT) {
+                const int k = k0 + threadIdx.x;
+                const int f = (k < n && w.owner[k] < 0) ? 1 : 0;
+                int tot;
+                const int off = block_scan_excl(f, &tot, sh);
+                if (f) w.listFC[base + off] = k;
+                base += tot;
+            }
+            if (threadIdx.x == 0) {
+                st->nFC = base; st->nF = nU; st->fidx = 0; st->st_free_after_arr = nU;
+                st->mode = MODE_SAP; st->cur = 0; st->nN = 0;
+                if (base != nU) st->error = 4;
+            }
+        }
         __syncthreads();
-        ctrl_sap_begin(M, w, st, shd, shi);
-        ctrl_sap_select(w, st, shd, shi, sh);
-        // nS may be 0 already (a free column is the best column): handled next step
+        ctrl_sap_begin(M, w, st, shd, shi, sh);
         if (st->nS > 0) return;
-        mode = MODE_SAP;   // fall through to finish below with an empty batch
+        mode = MODE_SAP; sap_converged = true;
     } else if (mode == MODE_SAP) {
-        if (threadIdx.x == 0) { st->st_sap_batches++; st->st_sap_row_scans += st->nS; st->st_total_row_scans += st->nS; }
+        const int scanned = st->nS;
         __syncthreads();
-        ctrl_sap_select(w, st, shd, shi, sh);
-        if (st->nS > 0) return;
+        if (threadIdx.x == 0) { st->st_sap_batches++; st->st_sap_row_scans += scanned; st->st_total_row_scans += scanned; }
+        if (ctrl_sap_step(w, st, shd, shi)) return;
+        sap_converged = true;
     }
 
-    if (mode == MODE_SAP) {
+    if (mode == MODE_SAP && sap_converged) {
         // search converged (possibly several in a row if they need no relaxation)
         for (;;) {
             ctrl_sap_finish(w, st, dyn, dyn + n, use_lds);
             if (threadIdx.x == 0) st->fidx++;
             __syncthreads();
-            if (!ctrl_sap_begin(M, w, st, shd, shi)) {
-                if (threadIdx.x == 0) {
-                    st->mode = MODE_CERT; st->minslack_ord = ~0ull; st->total_cost = 0.0; st->cert_bad = 0;
-                }
-                return;
-            }
-            ctrl_sap_select(w, st, shd, shi, sh);
-            if (st->nS > 0 || st->error) return;
+            if (st->error) return;
+            if (!ctrl_sap_begin(M, w, st, shd, shi, sh)) { ctrl_enter_cert(st); return; }
+            if (st->nS > 0) return;
         }
     }
 
@@ -571,6 +656,7 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
         const double scale = fmax(fabs(st->cmax), fabs(st->cmin));
         const double tol = 1e-10 * fmax(scale, 1e-30);
         for (int i = threadIdx.x; i < n; i += CT) perm[i] = w.a[i];
+        __syncthreads();
         if (threadIdx.x == 0) {
             const int ok = (!st->cert_bad) && (minslack >= -tol);
             st->certified = ok;
@@ -627,20 +713,21 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
     int rc = cfm_hip(hipMemcpyAsync(w.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
     if (rc) return rc;
     const size_t n2 = (size_t)n * n;
-    const int mm_blocks = (int)((n2 + 255) / 256 < 2048 ? (n2 + 255) / 256 : 2048);
+    const int mm_blocks = (int)((n2 / 4 + 255) / 256 < 1024 ? (n2 / 4 + 255) / 256 + 1 : 1024);
     hipLaunchKernelGGL(asg_minmax, dim3(mm_blocks), dim3(256), 0, s, M, n2, w.st);
     const size_t dyn = (n <= 6144) ? (size_t)2 * n * sizeof(int) : 16;
     hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, M, w, perm, certified, total_cost, stats);
     rc = cfm_status();
     if (rc) return rc;
 
-    int wide_blocks = (n + 3) / 4;          // one wave per row when everything bids
-    if (wide_blocks > 1024) wide_blocks = 1024;
+    int wide_blocks = (n + 15) / 16;        // one wave per row when everything bids
+    if (wide_blocks > 512) wide_blocks = 512;
     if (wide_blocks < (n + 63) / 64) wide_blocks = (n + 63) / 64;
+    if (wide_blocks < 1) wide_blocks = 1;
     int pairs = 0;
     for (;;) {
         for (int c = 0; c < g_params.chunk; ++c) {
-            hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(256), 0, s, M, w);
+            hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), 0, s, M, w);
             hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, M, w, perm, certified, total_cost, stats);
         }
         pairs += g_params.chunk;
