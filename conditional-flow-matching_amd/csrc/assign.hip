@@ -34,7 +34,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { MODE_INIT = 0, MODE_AUCTION = 1, MODE_ARR = 2, MODE_SAP = 3, MODE_CERT = 4, MODE_DONE = 5 };
+enum { MODE_INIT = 0, MODE_AUCTION = 1, MODE_ARR = 2, MODE_SAP = 3, MODE_CERT = 4, MODE_DONE = 5,
+       MODE_BUILD = 6, MODE_SAP1 = 7, MODE_SAP1_DONE = 8 };
 
 struct AsgParams {
     double theta;          // epsilon reduction factor
@@ -45,9 +46,10 @@ struct AsgParams {
     int arr_cap;           // max epsilon = 0 rounds
     int chunk;             // kernel pairs per host poll
     int max_pairs;         // safety cap on kernel pairs
+    int sparse;            // 1: phase C on candidate lists in one workgroup (n <= 4096)
 };
 
-static AsgParams g_params = {5.0, 0.2, 1e-6, 0.02, 4000, 30, 48, 400000};
+static AsgParams g_params = {5.0, 0.2, 1e-6, 0.02, 4000, 30, 48, 400000, 1};
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
                                       double stop_frac, int round_cap, int arr_cap, int chunk) {
@@ -59,6 +61,8 @@ extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps
     if (arr_cap >= 0) g_params.arr_cap = arr_cap;
     if (chunk > 0) g_params.chunk = chunk;
 }
+
+extern "C" void cfm_assign_set_mode(int sparse) { g_params.sparse = sparse ? 1 : 0; }
 
 struct AsgState {
     int mode, n, phase, round;
@@ -73,7 +77,8 @@ struct AsgState {
     unsigned long long minslack_ord, pad2;
     unsigned cmin_bits, cmax_bits;  // ordered-float atomics
     int round_cap, arr_cap;
-    int nFC, pad3;
+    int nFC, sparse;
+    int st_dense_fallbacks, pad4;
 };
 
 // SAP scan list entry arrays (two copies: current / next)
@@ -98,11 +103,15 @@ struct AsgWs {
     int* listFC;      // free columns during SAP
     int* pred;
     SList S[2];
+    // candidate lists (n <= SP_NMAX): SP_K columns / costs per row, bound of the dropped ones
+    uint2* cl;        // {column, fp32 cost bits}
+    double* cT;
 };
 
 static inline size_t asg_ws_bytes(int n) {
     size_t N = (size_t)n;
-    return 512 + 8 * N * (4 + 4) + 4 * N * (7 + 4) + 256;
+    size_t lists = (n <= 4096) ? N * 64 * 8 + 8 * N : 0;
+    return 512 + 8 * N * (4 + 4) + 4 * N * (7 + 4) + lists + 256;
 }
 
 static inline AsgWs asg_carve(void* ws, int n) {
@@ -121,6 +130,8 @@ static inline AsgWs asg_carve(void* ws, int n) {
     w.listFC = (int*)q; q += 4 * N;
     w.pred = (int*)q; q += 4 * N;
     for (int c = 0; c < 2; ++c) { w.S[c].col = (int*)q; q += 4 * N; w.S[c].row = (int*)q; q += 4 * N; }
+    w.cT = (double*)q; w.cl = nullptr;
+    if (n <= 4096) { q += 8 * N; w.cl = (uint2*)q; q += 8 * N * 64; }
     return w;
 }
 
@@ -325,9 +336,12 @@ __device__ void wide_cert(const float* __restrict__ M, const AsgWs& w, AsgState*
     }
 }
 
+#include "assign_sparse.h"
+
 __global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgWs w) {
-    __shared__ double sh_d[WT];
-    __shared__ int sh_i[WT];
+    extern __shared__ __attribute__((aligned(16))) char wide_lds[];   // modes are exclusive
+    double* sh_d = reinterpret_cast<double*>(wide_lds);
+    int* sh_i = reinterpret_cast<int*>(wide_lds + sizeof(double) * WT);
     AsgState* st = w.st;
     const int mode = st->mode;
     if (mode == MODE_DONE || st->error) return;
@@ -337,6 +351,8 @@ __global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgW
     if (mode == MODE_AUCTION || mode == MODE_ARR) wide_bid(M, w, st, wave_gid, n_waves);
     else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i);
     else if (mode == MODE_CERT) wide_cert(M, w, st, wave_gid, n_waves);
+    else if (mode == MODE_BUILD) wide_build(M, w, st, wide_lds);
+    else if (mode == MODE_SAP1) { if (blockIdx.x == 0) sp_solver(M, w, st, wide_lds); }
 }
 
 // ------------------------------------------------------------------ ctrl -----
@@ -619,11 +635,14 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
                 if (f) w.listFC[base + off] = k;
                 base += tot;
             }
+            const int sparse = st->sparse;
+            __syncthreads();
             if (threadIdx.x == 0) {
                 st->nFC = base; st->nF = nU; st->fidx = 0; st->st_free_after_arr = nU;
-                st->mode = MODE_SAP; st->cur = 0; st->nN = 0;
+                st->mode = sparse ? MODE_BUILD : MODE_SAP; st->cur = 0; st->nN = 0;
                 if (base != nU) st->error = 4;
             }
+            if (sparse) return;
         }
         __syncthreads();
         ctrl_sap_begin(M, w, st, shd, shi, sh);
@@ -637,6 +656,14 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
         sap_converged = true;
     }
 
+    if (mode == MODE_BUILD) {          // the wide pass has written the candidate lists
+        if (threadIdx.x == 0) st->mode = MODE_SAP1;
+        return;
+    }
+    if (mode == MODE_SAP1_DONE) {      // the one-workgroup solver has matched every row
+        ctrl_enter_cert(st);
+        return;
+    }
     if (mode == MODE_SAP && sap_converged) {
         // search converged (possibly several in a row if they need no relaxation)
         for (;;) {
@@ -666,7 +693,7 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
                 stats[0] = st->st_auction_rounds; stats[1] = st->st_arr_rounds;
                 stats[2] = st->st_free_after_arr; stats[3] = st->st_sap_batches;
                 stats[4] = st->st_sap_row_scans; stats[5] = st->st_total_row_scans;
-                stats[6] = st->st_steps; stats[7] = st->phase;
+                stats[6] = st->st_steps; stats[7] = st->phase | (st->st_dense_fallbacks << 8);
             }
             __threadfence();
             st->mode = MODE_DONE;
@@ -687,8 +714,8 @@ __global__ void asg_trivial(const float* M, int n, int* perm, int* certified, do
 
 static int* g_pinned = nullptr;
 
-extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,
-                                    double* total_cost, int* stats, void* ws, void* stream) {
+static int asg_run(const float* M, int B, int* perm, int* certified, double* total_cost, int* stats,
+                   void* ws, void* stream, int use_sparse, int* cert_out) {
     if (!M || !perm || B < 0 || (B > 1 && !ws)) return CFM_EINVAL;
     if (B > (1 << 20)) return CFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -710,6 +737,20 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
     h.eps = g_params.eps0_frac; h.eps_last = g_params.eps_last_frac; h.theta = g_params.theta;
     h.stop_frac = g_params.stop_frac; h.round_cap = g_params.round_cap; h.arr_cap = g_params.arr_cap;
     h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
+    h.sparse = (use_sparse && n <= SP_NMAX) ? 1 : 0;
+    size_t wide_dyn = sizeof(double) * WT + sizeof(int) * WT;
+    if (h.sparse) {
+        const size_t need = sp_lds_bytes(n);
+        if (need > wide_dyn) wide_dyn = need;
+        static int raised = 0;   // dynamic LDS above the 64 KiB default needs the attribute
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)asg_wide,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = (e == hipSuccess) ? 1 : -1;
+            (void)hipGetLastError();
+        }
+        if (raised < 0 && wide_dyn > 64 * 1024) { h.sparse = 0; wide_dyn = sizeof(double) * WT + sizeof(int) * WT; }
+    }
     int rc = cfm_hip(hipMemcpyAsync(w.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
     if (rc) return rc;
     const size_t n2 = (size_t)n * n;
@@ -727,20 +768,31 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
     int pairs = 0;
     for (;;) {
         for (int c = 0; c < g_params.chunk; ++c) {
-            hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), 0, s, M, w);
+            hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), wide_dyn, s, M, w);
             hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, M, w, perm, certified, total_cost, stats);
         }
         pairs += g_params.chunk;
         rc = cfm_status();
         if (rc) return rc;
-        rc = cfm_hip(hipMemcpyAsync(g_pinned, w.st, 32, hipMemcpyDeviceToHost, s));
+        rc = cfm_hip(hipMemcpyAsync(g_pinned, w.st, 64, hipMemcpyDeviceToHost, s));
         if (rc) return rc;
         rc = cfm_hip(hipStreamSynchronize(s));
         if (rc) return rc;
         const int mode = g_pinned[0], err = g_pinned[7];
         if (err) return CFM_ENOCONV;
-        if (mode == MODE_DONE) break;
+        if (mode == MODE_DONE) { if (cert_out) *cert_out = g_pinned[13]; break; }
         if (pairs >= g_params.max_pairs) return CFM_ETIMEOUT;
     }
     return 0;
+}
+
+extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,
+                                    double* total_cost, int* stats, void* ws, void* stream) {
+    int cert = 1;
+    int rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, g_params.sparse, &cert);
+    // The candidate-list path is exact by construction; should its certificate ever fail
+    // (or its solver report an inconsistency) the dense state machine decides.
+    if (g_params.sparse && B > 1 && B <= SP_NMAX && (rc == CFM_ENOCONV || (rc == 0 && !cert)))
+        rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, 0, &cert);
+    return rc;
 }

@@ -1,0 +1,784 @@
+// assign_sparse.h — phase C of the exact assignment on candidate lists (n <= 4096).
+//
+// After the epsilon = 0 rounds the duals are feasible and every kept pair is tight; what
+// is left is a handful of free rows, each needing one shortest-augmenting-path search.  The
+// searches are sequential and each is ~40 label-correcting batches deep, so the dense form
+// (one grid launch per batch) is bound by kernel boundaries, not by bandwidth.  Here:
+//
+//   wide_build   (whole grid, one wave per row)  keeps, for every row i, the SP_K = 64
+//                columns with the smallest c_ik + p_k, their fp32 costs, and a bound T_i with
+//                c_ik + p_k >= T_i for every column that was NOT kept.  Prices only rise
+//                afterwards, so the bound stays valid for the rest of the solve.
+//   sp_solver    (ONE workgroup, 16 waves, state in LDS: prices, labels, predecessors,
+//                owners, the scan list)  runs all searches with workgroup barriers instead
+//                of kernel boundaries.  A row is relaxed over its 64 candidates only; when a
+//                search has converged every tree row is checked a posteriori:
+//                    label(row) + (T_row - u_row) >= dfree
+//                proves that none of its dropped edges could have produced a label below
+//                dfree, i.e. that the sparse search equals the dense one.  Rows that fail
+//                the test are relaxed over their full matrix row and the search resumes.
+//
+// Exactness therefore never depends on the lists (they only decide how much is read), and
+// the fp64 certificate pass over the whole matrix still closes the solve.
+#pragma once
+
+#define SP_K 64
+#define SP_NMAX 4096
+#define SP_NOCOL 0xffffu
+#define SP_DENSE 0x8000u      // list entry: relax over the full matrix row
+#define SP_ROOT 0x4000u       // list entry: the free root row of the search
+#define SP_COLMASK 0x0fffu
+#define SP_STALE 0x80000000u  // pred[k]: not improved in the current batch
+#define SP_MARK 0x7fffffffu   // pred[k]: improved in this batch, winner not chosen yet
+
+#define SP_BUILD_WAVES 8   // waves per workgroup that build lists
+#define SP_CAP 64          // list entries per batch (16 waves x 4 entries kept in registers)
+
+// dynamic LDS of asg_wide when the candidate-list path is on: the solver's state (34 B per
+// column) or the list builder's strips (one fp32 row per building wave), whichever is larger
+static inline size_t sp_lds_bytes(int n) {
+    const size_t solver = (size_t)n * 34 + 4096;
+    const size_t build = (size_t)SP_BUILD_WAVES * (size_t)((n + 63) / 64) * 64 * sizeof(float) + 64;
+    return solver > build ? solver : build;
+}
+
+struct SpL {
+    double* p;               // prices
+    double* dist;            // labels of the current search (>= 0)
+    unsigned* pred;          // predecessor row | SP_STALE
+    unsigned short* owner;   // col -> row (SP_NOCOL: free)
+    unsigned short* a;       // row -> col (SP_NOCOL: free)
+    unsigned short* fcol;    // free columns
+    unsigned short* pl[2];   // pending columns: improved, assigned, not yet relaxed (ping-pong)
+    unsigned char* ddone;    // row of this column already relaxed densely at its current label
+    unsigned char* inl;      // column is in the pending list
+    double* lbase;           // scan list (<= SP_CAP): label of the entry when it was listed
+    unsigned short* lcol;    // scan list: column | flags
+    double* rd;              // 64 doubles of scratch
+    int* ri;                 // 128 ints of scratch
+};
+// scratch slots
+#define SP_RI_NPL 64     // pending-list length (atomic append counter)
+#define SP_RI_NS 65      // entries in the scan list
+#define SP_RI_FLAG 66
+#define SP_RD_DFREE 48   // best free-column label
+#define SP_RD_FAR 49     // labels above this are only flagged (inl = 2), not listed, until the near list is empty
+
+__device__ __forceinline__ SpL sp_carve(char* lds, int n) {
+    SpL L; char* q = lds; const size_t N = (size_t)n;
+    L.rd = (double*)q; q += 64 * 8;
+    L.lbase = (double*)q; q += SP_CAP * 8;
+    L.ri = (int*)q; q += 128 * 4;
+    L.lcol = (unsigned short*)q; q += SP_CAP * 2;
+    q += 128;   // 512 + 512 + 512 + 128 + 128 = 1792: keeps the arrays below 16-byte aligned
+    L.p = (double*)q; q += 8 * N;
+    L.dist = (double*)q; q += 8 * N;
+    L.pred = (unsigned*)q; q += 4 * N;
+    L.owner = (unsigned short*)q; q += 2 * N;
+    L.a = (unsigned short*)q; q += 2 * N;
+    L.fcol = (unsigned short*)q; q += 2 * N;
+    L.pl[0] = (unsigned short*)q; q += 2 * N;
+    L.pl[1] = (unsigned short*)q; q += 2 * N;
+    L.ddone = (unsigned char*)q; q += N;
+    L.inl = (unsigned char*)q;
+    return L;
+}
+
+// ------------------------------------------------------------ list build -----
+__device__ __forceinline__ int sp_count(const float* __restrict__ r, int nt, float tau) {
+    int c = 0;
+#pragma unroll 8
+    for (int t = 0; t < nt; ++t) c += (r[t * 64] < tau) ? 1 : 0;
+    return wave_sum_i(c);
+}
+
+// One wave per row.  Lane l owns columns l, 64 + l, ...; r[t] = fl32((c + p) - rowmin) >= 0
+// lives in the wave's LDS strip (lane-major: conflict free).  A threshold tau with
+// count(r < tau) in [32, 64] is found by bisection; members are r < tau, and every
+// non-member satisfies (c + p) >= rowmin + tau * (1 - 2^-22) =: T.
+__device__ void wide_build(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+                           char* lds) {
+    const int n = st->n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wv >= SP_BUILD_WAVES) return;
+    const int nt = (n + 63) / 64;
+    float* r = reinterpret_cast<float*>(lds) + (size_t)wv * nt * 64 + lane;   // r[t * 64]
+    const int wave_gid = wv * gridDim.x + blockIdx.x, n_waves = gridDim.x * SP_BUILD_WAVES;
+    for (int i = wave_gid; i < n; i += n_waves) {
+        const float* row = M + (size_t)i * n;
+        double m = INFINITY;
+        for (int t0 = 0; t0 < nt; t0 += 8) {
+            float c[8]; double pk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = (t0 + q) * 64 + lane;
+                c[q] = (k < n) ? row[k] : INFINITY; pk[q] = (k < n) ? w.p[k] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m = fmin(m, (double)c[q] + pk[q]);
+        }
+        m = wave_min_d(m);
+        float lmin = INFINITY;
+        for (int t0 = 0; t0 < nt; t0 += 8) {
+            float c[8]; double pk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = (t0 + q) * 64 + lane;
+                c[q] = (k < n) ? row[k] : INFINITY; pk[q] = (k < n) ? w.p[k] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = (t0 + q) * 64 + lane;
+                if (t0 + q < nt) {
+                    const float x = (k < n) ? (float)(((double)c[q] + pk[q]) - m) : INFINITY;
+                    r[(t0 + q) * 64] = x; lmin = fminf(lmin, x);
+                }
+            }
+        }
+        float tau;
+        if (n <= SP_K) {
+            tau = INFINITY;
+        } else {
+            const float hi = wave_max_f(lmin);                 // count(r <= hi) >= 64
+            const float t1 = __uint_as_float(__float_as_uint(hi) + 1u);
+            if (sp_count(r, nt, t1) <= SP_K) {
+                tau = t1;
+            } else {
+                float lo = 0.f, hh = t1; int clo = 0;
+                for (int it = 0; it < 48 && clo < SP_K / 2; ++it) {
+                    const float mid = 0.5f * (lo + hh);
+                    if (!(mid > lo && mid < hh)) break;
+                    const int cm = sp_count(r, nt, mid);
+                    if (cm <= SP_K) { lo = mid; clo = cm; } else hh = mid;
+                }
+                tau = lo;
+            }
+        }
+        const bool all = (tau == INFINITY);
+        int off = 0;
+        for (int t = 0; t < nt; ++t) {
+            const int k = t * 64 + lane;
+            const bool mem = (k < n) && (all || r[t * 64] < tau);
+            const unsigned long long mask = __ballot(mem);
+            if (mask) {
+                if (mem) {
+                    const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+                    w.cl[(size_t)i * SP_K + pos] = make_uint2((unsigned)k, __float_as_uint(row[k]));
+                }
+                off += __popcll(mask);
+            }
+        }
+        if (lane >= off) w.cl[(size_t)i * SP_K + lane] = make_uint2(SP_NOCOL, 0x7f800000u);
+        if (lane == 0) w.cT[i] = all ? INFINITY : (m + (double)tau * (1.0 - 2.4e-7) - 1e-290);
+    }
+}
+
+// --------------------------------------------------------------- solver ------
+// One workgroup is instruction-issue bound (16 waves share 4 SIMDs), so the batch loop keeps
+// whole-workgroup work to the relaxations themselves; list bookkeeping runs in ONE wave on an
+// explicit pending list (no O(n) scans, no block-wide reductions) while the others wait.
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which
+// would make every barrier wait for the list prefetches issued for the NEXT batch; inside the
+// solver loop all cross-wave traffic is LDS (M, the candidate lists and cT are read-only).
+__device__ __forceinline__ void sp_sync() {
+#ifdef SP_FULLSYNC
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// wave64 DPP primitives (row_shr within 16-lane rows, then row_bcast 15 / 31)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int sp_dpp_i(int oldv, int v) {
+    return __builtin_amdgcn_update_dpp(oldv, v, CTRL, ROWMASK, 0xf, false);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double sp_dpp_d(double oldv, double v) {
+    const int lo = sp_dpp_i<CTRL, ROWMASK>(__double2loint(oldv), __double2loint(v));
+    const int hi = sp_dpp_i<CTRL, ROWMASK>(__double2hiint(oldv), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the wave
+__device__ __forceinline__ int sp_wave_scan(int v) {
+    v += sp_dpp_i<0x111, 0xf>(0, v);
+    v += sp_dpp_i<0x112, 0xf>(0, v);
+    v += sp_dpp_i<0x114, 0xf>(0, v);
+    v += sp_dpp_i<0x118, 0xf>(0, v);
+    v += sp_dpp_i<0x142, 0xa>(0, v);
+    v += sp_dpp_i<0x143, 0xc>(0, v);
+    return v;
+}
+// min over the wave, result uniform
+__device__ __forceinline__ double sp_wave_min(double v) {
+    v = fmin(v, sp_dpp_d<0x111, 0xf>(INFINITY, v));
+    v = fmin(v, sp_dpp_d<0x112, 0xf>(INFINITY, v));
+    v = fmin(v, sp_dpp_d<0x114, 0xf>(INFINITY, v));
+    v = fmin(v, sp_dpp_d<0x118, 0xf>(INFINITY, v));
+    v = fmin(v, sp_dpp_d<0x142, 0xa>(INFINITY, v));
+    v = fmin(v, sp_dpp_d<0x143, 0xc>(INFINITY, v));
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sp_wave_max(double v) { return -sp_wave_min(-v); }
+__device__ __forceinline__ int sp_wave_total(int v) {
+    return __builtin_amdgcn_readlane(sp_wave_scan(v), 63);
+}
+
+#define SP_T 1024
+#define SP_NW (SP_T / 64)
+#define SP_IPT 4   // columns per thread in the O(n) passes (n <= 4096)
+#define SP_E (SP_CAP / SP_NW)   // list entries per wave, kept in registers by the fast batch
+
+__device__ __forceinline__ double sp_block_min(double v, const SpL& L) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v = sp_wave_min(v);
+    if (lane == 0) L.rd[wv] = v;
+    sp_sync();
+    const double r = sp_wave_min(L.rd[lane & (SP_NW - 1)]);
+    sp_sync();
+    return r;
+}
+
+// Candidate update.  sp_lower: lower the label (LDS atomic min on the bit pattern: labels
+// are >= +0) and mark the column as improved.  sp_claim: among the lanes whose candidate
+// equals the final label of a column improved in this batch the lowest row id becomes the
+// predecessor (deterministic under ties); the first claimer files an assigned column in the
+// pending list.
+__device__ __forceinline__ void sp_lower(const SpL& L, int k, double cand, double cur) {
+    if (cand < cur) {
+        const unsigned long long nb = (unsigned long long)__double_as_longlong(cand);
+        const unsigned long long old = atomicMin((unsigned long long*)&L.dist[k], nb);
+        if (old > nb) { L.pred[k] = SP_MARK; L.ddone[k] = 0; }
+    }
+}
+__device__ __forceinline__ void sp_file(const SpL& L, int k, double label, unsigned char state, int plcur,
+                                        double far_thr) {
+    if (label <= far_thr) {
+        if (state != 1) {
+            L.inl[k] = 1;
+            const int pos = atomicAdd(&L.ri[SP_RI_NPL], 1);
+            (plcur ? L.pl[1] : L.pl[0])[pos] = (unsigned short)k;
+        }
+    } else if (state == 0) {
+        L.inl[k] = 2;
+    }
+}
+__device__ __forceinline__ void sp_claim(const SpL& L, int k, double cand, unsigned i, double cur, unsigned pk,
+                                         int plcur, double far_thr) {
+    if (cand == cur && !(pk & SP_STALE)) {
+        const unsigned old = atomicMin(&L.pred[k], i);
+        if (old == SP_MARK && L.owner[k] != SP_NOCOL) sp_file(L, k, cand, L.inl[k], plcur, far_thr);
+    }
+}
+__device__ __forceinline__ double sp_cand(double pk, float c, double rj, double base) {
+    const double rc = fmax(((double)c + pk) - rj, 0.0);   // dual feasible up to rounding
+    return base + rc;
+}
+
+// generic entry (dense entries allowed); recomputed in phase W
+template <bool PHASE_W>
+__device__ __forceinline__ void sp_entry(const float* __restrict__ M, const AsgWs& w, const SpL& L, int n,
+                                         unsigned e, double base, int i0, double u0, int lane, int plcur,
+                                         double dfree, double far_thr) {
+    const bool dense = (e & SP_DENSE) != 0, root = (e & SP_ROOT) != 0;
+    const int j = root ? -1 : (int)(e & SP_COLMASK);
+    const int i = root ? i0 : (int)L.owner[j];
+    double rj = u0;
+    if (!dense) {
+        const uint2 cl = w.cl[(size_t)i * SP_K + lane];
+        const unsigned col = cl.x; const float c = __uint_as_float(cl.y);
+        const bool valid = col != SP_NOCOL;
+        if (!root) {
+            const unsigned long long hit = __ballot(valid && (int)col == j);
+            float cij;
+            if (hit) cij = __shfl(c, __ffsll((long long)hit) - 1, 64);
+            else cij = M[(size_t)i * n + j];
+            rj = (double)cij + L.p[j];                        // = u_i: the matched edge is tight
+        }
+        if (valid && (int)col != j) {
+            const double cand = sp_cand(L.p[col], c, rj, base);
+            if (PHASE_W) sp_claim(L, (int)col, cand, (unsigned)i, L.dist[col], L.pred[col], plcur, far_thr);
+            else if (cand < dfree) sp_lower(L, (int)col, cand, L.dist[col]);
+        }
+    } else {
+        const float* row = M + (size_t)i * n;
+        if (!root) rj = (double)row[j] + L.p[j];
+        for (int k0 = 0; k0 < n; k0 += 64 * 8) {
+            float c[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int k = k0 + q * 64 + lane; c[q] = (k < n) ? row[k] : 0.f; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + q * 64 + lane;
+                if (k < n && k != j) {
+                    const double cand = sp_cand(L.p[k], c[q], rj, base);
+                    if (PHASE_W) sp_claim(L, k, cand, (unsigned)i, L.dist[k], L.pred[k], plcur, far_thr);
+                    else if (cand < dfree) sp_lower(L, k, cand, L.dist[k]);
+                }
+            }
+        }
+    }
+}
+
+// best free column label (one wave)
+__device__ __forceinline__ double sp_dfree(const SpL& L, int nFC, int lane) {
+    double lm = INFINITY;
+    for (int t = lane; t < nFC; t += 64) lm = fmin(lm, L.dist[L.fcol[t]]);
+    return sp_wave_min(lm);
+}
+
+#ifdef SP_PROFILE
+#define FB_TICK(slot) do { if (threadIdx.x == 0) { const long long t_ = clock64(); fb[slot] += t_ - tl; tl = t_; } } while (0)
+#else
+#define FB_TICK(slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ double sp_rfl_d(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// One batch of <= SP_CAP sparse entries.  Written in stages over the (at most SP_E) entries
+// of this wave so that the LDS / global round trips of different entries overlap; everything
+// that is uniform over the wave (entry, row, base label, the lane holding the matched edge)
+// is moved to scalar registers so the control flow is scalar.  Candidates stay in registers
+// between the two phases.  The last wave also refreshes dfree (published through LDS).
+__device__ __forceinline__ void sp_fast_batch(const float* __restrict__ M, const AsgWs& w, const SpL& L,
+                                              int n, int nS, int nFC, double dfree, int i0, double u0,
+                                              int lane, int wv, int plcur, double far_thr, long long* fb) {
+#ifdef SP_PROFILE
+    long long tl = clock64();
+#endif
+    const int swv = __builtin_amdgcn_readfirstlane(wv);
+    int nq = 0;
+    if (nS > swv) { nq = (nS - swv + SP_NW - 1) / SP_NW; if (nq > SP_E) nq = SP_E; }
+    int jj[SP_E], ii[SP_E], kk[SP_E]; bool root[SP_E], on[SP_E], use[SP_E];
+    double bs[SP_E], cd[SP_E], pj[SP_E], pk[SP_E], dc[SP_E];
+    uint2 cl[SP_E];
+    // stage 1: entries (uniform LDS reads)
+    unsigned ev[SP_E];
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        ev[q] = SP_ROOT; bs[q] = INFINITY;
+        if (q < nq) { ev[q] = L.lcol[swv + SP_NW * q]; bs[q] = L.lbase[swv + SP_NW * q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)ev[q]);
+        bs[q] = sp_rfl_d(bs[q]);
+        root[q] = (e & SP_ROOT) != 0;
+        jj[q] = root[q] ? -1 : (int)(e & SP_COLMASK);
+        on[q] = (q < nq) && bs[q] < dfree;
+    }
+    // stage 2: rows
+    unsigned ov[SP_E];
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) { ov[q] = (unsigned)i0; if (on[q] && !root[q]) ov[q] = L.owner[jj[q]]; }
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) ii[q] = __builtin_amdgcn_readfirstlane((int)ov[q]);
+    // stage 3: candidate lists (one 8-byte load per lane and entry, all in flight together)
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        cl[q] = make_uint2(SP_NOCOL, 0u);
+        if (on[q]) cl[q] = w.cl[(size_t)ii[q] * SP_K + lane];
+    }
+    FB_TICK(0);
+    // stage 4: prices / labels of the candidates, price of the matched column
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        pj[q] = 0.0; pk[q] = 0.0; dc[q] = 0.0; use[q] = false; kk[q] = 0;
+        if (on[q]) {
+            const unsigned col = cl[q].x;
+            use[q] = col != SP_NOCOL && (int)col != jj[q];
+            kk[q] = use[q] ? (int)col : 0;
+            pk[q] = L.p[kk[q]];
+            dc[q] = L.dist[kk[q]];
+            if (!root[q]) pj[q] = L.p[jj[q]];
+        }
+    }
+    // stage 5: candidates
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        cd[q] = 0.0;
+        if (on[q]) {
+            double rj = u0;
+            if (!root[q]) {
+                const unsigned long long hit = __ballot((int)cl[q].x == jj[q]);
+                float cij;
+                if (hit) cij = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)cl[q].y, __ffsll((long long)hit) - 1));
+                else cij = M[(size_t)ii[q] * n + jj[q]];
+                rj = (double)cij + sp_rfl_d(pj[q]);            // = u_i: the matched edge is tight
+            }
+            cd[q] = sp_cand(pk[q], __uint_as_float(cl[q].y), rj, bs[q]);
+        }
+    }
+    // stage 6: lower the labels (all atomics in flight before the first result is used)
+    unsigned long long oldb[SP_E];
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        oldb[q] = 0ull;
+        if (on[q]) {
+            if (use[q] && cd[q] < dc[q] && cd[q] < dfree)      // labels >= dfree can never matter
+                oldb[q] = atomicMin((unsigned long long*)&L.dist[kk[q]], (unsigned long long)__double_as_longlong(cd[q]));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q)
+        if (on[q] && oldb[q] > (unsigned long long)__double_as_longlong(cd[q])) { L.pred[kk[q]] = SP_MARK; L.ddone[kk[q]] = 0; }
+    FB_TICK(1);
+    sp_sync();
+    FB_TICK(2);
+    if (swv == SP_NW - 1) {
+        const double dnew = sp_dfree(L, nFC, lane);
+        if (lane == 0) L.rd[SP_RD_DFREE] = dnew;
+    }
+    FB_TICK(3);
+    // phase W, staged the same way
+    unsigned pc[SP_E], oldp[SP_E], ow[SP_E]; unsigned char il[SP_E]; bool won[SP_E];
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) { dc[q] = -1.0; pc[q] = SP_STALE; if (on[q]) { dc[q] = L.dist[kk[q]]; pc[q] = L.pred[kk[q]]; } }
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        oldp[q] = 0u; won[q] = false;
+        if (on[q]) {
+            won[q] = use[q] && cd[q] == dc[q] && !(pc[q] & SP_STALE);
+            if (won[q]) oldp[q] = atomicMin(&L.pred[kk[q]], (unsigned)ii[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        ow[q] = SP_NOCOL; il[q] = 1;
+        if (on[q]) { won[q] = won[q] && oldp[q] == SP_MARK; ow[q] = L.owner[kk[q]]; il[q] = L.inl[kk[q]]; }
+    }
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        if (on[q]) {
+            if (won[q] && ow[q] != SP_NOCOL) sp_file(L, kk[q], cd[q], il[q], plcur, far_thr);
+        }
+    }
+    FB_TICK(4);
+    sp_sync();
+    FB_TICK(5);
+}
+
+// Bookkeeping after a batch, ONE wave, on the NEAR pending list (labels <= far_thr; columns
+// improved to a label above far_thr are only flagged inl = 2 and found again by sp_rebucket
+// when the near list runs dry: a two-level bucket queue, so a batch never pays for the whole
+// frontier).  Every listed column gets SP_STALE (its improvement batch is over); columns at
+// or above dfree are dropped; of the rest the ones within `delta` of the smallest label (at
+// most SP_CAP) become the next scan list.  Publishes nS, the new list length and far_thr;
+// returns the adapted delta.
+__device__ __forceinline__ double sp_collect(const SpL& L, int plcur, double dfree, double delta, double far_thr,
+                                             int lane) {
+    const int npl = L.ri[SP_RI_NPL];
+#ifdef SP_PROFILE
+    if (lane == 0) L.ri[125] += npl;
+#endif
+    const unsigned short* src = plcur ? L.pl[1] : L.pl[0];
+    unsigned short* dst = plcur ? L.pl[0] : L.pl[1];
+    double lmin = INFINITY, lmax = 0.0; int np = 0;
+    for (int t = lane; t < npl; t += 64) {
+        const int k = src[t];
+        const double d = L.dist[k];
+        L.pred[k] |= SP_STALE;
+        if (d < dfree) { lmin = fmin(lmin, d); lmax = fmax(lmax, d); ++np; }
+    }
+    const double dmin = sp_wave_min(lmin), dmax = sp_wave_max(lmax);
+    const int npend = sp_wave_total(np);
+    if (!(far_thr < INFINITY) && delta < INFINITY && npend > 2 * SP_CAP) far_thr = dmin + 8.0 * delta;
+    const double tau = dmin + delta;
+    int nsel = 0, nkeep = 0;
+    for (int t0 = 0; t0 < npl; t0 += 64) {
+        const int t = t0 + lane;
+        int k = 0; double d = INFINITY; bool live = false;
+        if (t < npl) { k = src[t]; d = L.dist[k]; live = d < dfree; }
+        const bool want = live && d <= tau;
+        const int sinc = sp_wave_scan(want ? 1 : 0);
+        const int spos = nsel + sinc - 1;
+        const bool sel = want && spos < SP_CAP;
+        const bool keep = live && !sel && d <= far_thr;
+        const int kinc = sp_wave_scan(keep ? 1 : 0);
+        if (sel) { L.lcol[spos] = (unsigned short)k; L.lbase[spos] = d; L.inl[k] = 0; }
+        if (keep) dst[nkeep + kinc - 1] = (unsigned short)k;
+        if (t < npl && !sel && !keep) L.inl[k] = live ? 2 : 0;
+        nsel += __builtin_amdgcn_readlane(sinc, 63);
+        nkeep += __builtin_amdgcn_readlane(kinc, 63);
+    }
+    if (lane == 0) {
+        L.ri[SP_RI_NS] = nsel < SP_CAP ? nsel : SP_CAP; L.ri[SP_RI_NPL] = nkeep; L.rd[SP_RD_FAR] = far_thr;
+    }
+    // adapt the window: aim at 32 .. 64 entries per batch
+    if (nsel > SP_CAP) delta = 0.5 * fmin(delta, dmax - dmin);
+    else if (nsel < SP_CAP / 2 && npend > nsel) delta = fmax(2.0 * delta, (dmax - dmin) * (1.0 / 64.0));
+    return delta;
+}
+
+#ifdef SP_PROFILE
+#define SP_TICK(slot) do { if (tid == 0) { const long long t_ = clock64(); dbg[slot] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define SP_TICK(slot) do { } while (0)
+#endif
+
+__device__ void sp_solver(const float* __restrict__ M, const AsgWs& w, AsgState* st, char* lds) {
+#ifdef SP_PROFILE
+    long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long fbv[6] = {0, 0, 0, 0, 0, 0};
+    long long* fb = fbv;
+    long long tlast = clock64();
+    int nfast = 0;
+#else
+    long long* fb = nullptr;
+#endif
+    const int n = st->n, nF = st->nF;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const SpL L = sp_carve(lds, n);
+    int nFC = st->nFC;
+    for (int k = tid; k < n; k += SP_T) {
+        L.p[k] = w.p[k];
+        const int o = w.owner[k]; L.owner[k] = (o < 0) ? (unsigned short)SP_NOCOL : (unsigned short)o;
+        const int ak = w.a[k]; L.a[k] = (ak < 0) ? (unsigned short)SP_NOCOL : (unsigned short)ak;
+    }
+    for (int t = tid; t < nFC; t += SP_T) L.fcol[t] = (unsigned short)w.listFC[t];
+    if (tid == 0) { L.ri[126] = 0; L.ri[125] = 0; }
+    sp_sync();
+
+    int batches = 0, scans = 0, dense_scans = 0, err = 0;
+    for (int f = 0; f < nF && !err; ++f) {
+        const int i0 = w.listF[f];
+        for (int k = tid; k < n; k += SP_T) {
+            L.dist[k] = INFINITY; L.pred[k] = SP_STALE | SP_MARK; L.ddone[k] = 0; L.inl[k] = 0;
+        }
+        // root: u0 = min_k (c_i0k + p_k).  The candidate minimum is the row minimum iff it does
+        // not exceed the bound T_i0 of the dropped columns; otherwise take it over the full row
+        // and start with a dense root entry.
+        double u0;
+        {
+            const uint2 cl = w.cl[(size_t)i0 * SP_K + lane];
+            const double val = (cl.x != SP_NOCOL) ? (double)__uint_as_float(cl.y) + L.p[cl.x] : INFINITY;
+            u0 = sp_wave_min(val);                // every wave computes the same value
+        }
+        bool root_dense = false;
+        if (!(u0 <= w.cT[i0])) {
+            double mm = INFINITY;
+            for (int k = tid; k < n; k += SP_T) mm = fmin(mm, (double)M[(size_t)i0 * n + k] + L.p[k]);
+            u0 = sp_block_min(mm, L);
+            root_dense = true;
+        }
+        const double bound0 = w.cT[i0] - u0;
+        if (tid == 0) {
+            L.lcol[0] = (unsigned short)(root_dense ? (SP_ROOT | SP_DENSE) : SP_ROOT); L.lbase[0] = 0.0;
+            L.ri[SP_RI_NPL] = 0; L.rd[SP_RD_DFREE] = INFINITY; L.rd[SP_RD_FAR] = INFINITY;
+        }
+        int nS = 1, plcur = 0;
+        bool any_dense = root_dense;
+        double dfree = INFINITY;
+        double delta = INFINITY;      // label window of a batch above the smallest pending label
+        double far_thr = INFINITY;    // near / far split of the pending columns
+        sp_sync();
+        SP_TICK(0);
+
+        for (int guard = 0;; ++guard) {
+            if (guard > 8 * n + 64) { err = 6; break; }
+            if (nS > 0) {
+                if (!any_dense) {
+                    sp_fast_batch(M, w, L, n, nS, nFC, dfree, i0, u0, lane, wv, plcur, far_thr, fb);
+                } else {
+                    for (int t = wv; t < nS; t += SP_NW) {
+                        const double b = L.lbase[t];
+                        if (b < dfree) sp_entry<false>(M, w, L, n, L.lcol[t], b, i0, u0, lane, plcur, dfree, far_thr);
+                    }
+                    sp_sync();
+                    if (wv == SP_NW - 1) {
+                        const double dnew = sp_dfree(L, nFC, lane);
+                        if (lane == 0) L.rd[SP_RD_DFREE] = dnew;
+                    }
+                    for (int t = wv; t < nS; t += SP_NW) {
+                        const double b = L.lbase[t];
+                        if (b < dfree) sp_entry<true>(M, w, L, n, L.lcol[t], b, i0, u0, lane, plcur, dfree, far_thr);
+                    }
+                    sp_sync();
+                }
+                ++batches; scans += nS;
+#ifdef SP_PROFILE
+                if (!any_dense) { SP_TICK(1); ++nfast; } else { SP_TICK(5); }
+#endif
+            }
+            dfree = L.rd[SP_RD_DFREE];
+            if (wv == 0) delta = sp_collect(L, plcur, dfree, delta, far_thr, lane);
+            sp_sync();
+            nS = L.ri[SP_RI_NS]; far_thr = L.rd[SP_RD_FAR]; plcur ^= 1; any_dense = false;
+            SP_TICK(2);
+            if (nS > 0) continue;
+            if (L.ri[SP_RI_NPL] > 0) { err = 7; break; }   // tau >= dmin always selects something
+
+            // ---- near list empty: re-bucket the flagged far columns (all threads, O(n))
+            {
+                double dk4[SP_IPT]; bool far[SP_IPT]; double lm = INFINITY;
+#pragma unroll
+                for (int e = 0; e < SP_IPT; ++e) {
+                    const int k = e * SP_T + tid;
+                    far[e] = false; dk4[e] = INFINITY;
+                    if (k < n && L.inl[k] == 2) {
+                        const double d = L.dist[k];
+                        if (d < dfree) { far[e] = true; dk4[e] = d; lm = fmin(lm, d); }
+                        else L.inl[k] = 0;
+                    }
+                }
+                const double fmin_ = sp_block_min(lm, L);
+                if (fmin_ < INFINITY) {
+                    far_thr = fmin_ + 8.0 * delta;
+                    int cnt2 = 0;
+#pragma unroll
+                    for (int e = 0; e < SP_IPT; ++e) { far[e] = far[e] && dk4[e] <= far_thr; cnt2 += far[e] ? 1 : 0; }
+                    const int winc = sp_wave_scan(cnt2);
+                    if (lane == 63) L.ri[32 + wv] = winc;
+                    sp_sync();
+                    const int wsum = (lane < SP_NW) ? L.ri[32 + lane] : 0;
+                    const int wscan = sp_wave_scan(wsum);
+                    const int nmove = __builtin_amdgcn_readlane(wscan, 63);
+                    int off2 = __shfl(wscan - wsum, wv, 64) + (winc - cnt2);
+                    unsigned short* near = plcur ? L.pl[1] : L.pl[0];
+#pragma unroll
+                    for (int e = 0; e < SP_IPT; ++e) {
+                        const int k = e * SP_T + tid;
+                        if (far[e]) { near[off2++] = (unsigned short)k; L.inl[k] = 1; }
+                    }
+                    if (tid == 0) { L.ri[SP_RI_NPL] = nmove; L.rd[SP_RD_FAR] = far_thr; }
+                    sp_sync();
+                    if (wv == 0) delta = sp_collect(L, plcur, dfree, delta, far_thr, lane);
+                    sp_sync();
+                    nS = L.ri[SP_RI_NS]; far_thr = L.rd[SP_RD_FAR]; plcur ^= 1;
+                    SP_TICK(2);
+                    if (nS > 0) continue;
+                    err = 8; break;                          // fmin_ <= far_thr: something must be selected
+                }
+            }
+
+            // ---- converged on the lists: a-posteriori pruning test for every tree row
+            int cnt = 0; bool sel[SP_IPT]; double dk[SP_IPT];
+#pragma unroll
+            for (int e = 0; e < SP_IPT; ++e) {
+                const int k = e * SP_T + tid;
+                sel[e] = false; dk[e] = 0.0;
+                if (k < n && L.owner[k] != SP_NOCOL && !L.ddone[k]) {
+                    const double d = L.dist[k];
+                    if (d < dfree) {
+                        const int i = L.owner[k];
+                        const double rj = (double)M[(size_t)i * n + k] + L.p[k];
+                        if (!(d + (w.cT[i] - rj) >= dfree)) { sel[e] = true; dk[e] = d; }
+                    }
+                }
+                cnt += sel[e] ? 1 : 0;
+            }
+            int nsel, off;
+            {
+                const int winc = sp_wave_scan(cnt);
+                if (lane == 63) L.ri[32 + wv] = winc;
+                sp_sync();
+                const int wsum = (lane < SP_NW) ? L.ri[32 + lane] : 0;
+                const int wscan = sp_wave_scan(wsum);
+                nsel = __builtin_amdgcn_readlane(wscan, 63);
+                off = __shfl(wscan - wsum, wv, 64) + (winc - cnt);
+            }
+#pragma unroll
+            for (int e = 0; e < SP_IPT; ++e) {
+                const int k = e * SP_T + tid;
+                if (sel[e]) {
+                    if (off < SP_CAP - 1) {
+                        L.lcol[off] = (unsigned short)(k | SP_DENSE); L.lbase[off] = dk[e]; L.ddone[k] = 1;
+                    }
+                    ++off;
+                }
+            }
+            nS = nsel < SP_CAP - 1 ? nsel : SP_CAP - 1;
+            if (!root_dense && !(bound0 >= dfree)) {
+                root_dense = true;
+                if (tid == 0) { L.lcol[nS] = (unsigned short)(SP_ROOT | SP_DENSE); L.lbase[nS] = 0.0; }
+                ++nS;
+            }
+            any_dense = nS > 0;
+            dense_scans += nS;
+            sp_sync();
+            SP_TICK(3);
+            if (nS == 0) break;
+        }
+        if (err) break;
+
+        // ---- search done: argmin free column, dual update, augmentation
+        double lm = INFINITY; int li = 0x7fffffff;
+        for (int t = tid; t < nFC; t += SP_T) {
+            const int k = L.fcol[t]; const double dk = L.dist[k];
+            if (dk < lm || (dk == lm && k < li)) { lm = dk; li = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double v2 = __shfl_xor(lm, o, 64); const int i2 = __shfl_xor(li, o, 64);
+            if (v2 < lm || (v2 == lm && i2 < li)) { lm = v2; li = i2; }
+        }
+        if (lane == 0) { L.rd[wv] = lm; L.ri[wv] = li; }
+        sp_sync();
+        {
+            double bv = L.rd[0]; int bi = L.ri[0];
+            for (int q = 1; q < SP_T / 64; ++q) {
+                const double v2 = L.rd[q]; const int i2 = L.ri[q];
+                if (v2 < bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+            }
+            lm = bv; li = bi;
+        }
+        sp_sync();
+        dfree = lm;
+        const int jfree = li;
+        if (!(dfree < INFINITY)) { err = 5; break; }
+        for (int k = tid; k < n; k += SP_T) {
+            if (L.owner[k] != SP_NOCOL) {
+                const double dk = L.dist[k];
+                if (dk < dfree) L.p[k] += dfree - dk;        // v_k -= (dfree - d_k)
+            }
+        }
+        for (int t = tid; t < nFC; t += SP_T)
+            if (L.fcol[t] == jfree) L.fcol[t] = L.fcol[nFC - 1];   // single match
+        --nFC;
+        sp_sync();
+        if (tid == 0) {
+            int j = jfree, g2 = 0; bool closed = false;
+            while (g2++ <= n) {
+                const int i = (int)(L.pred[j] & 0x7fffffffu);
+                const int jprev = L.a[i];
+                L.owner[j] = (unsigned short)i; L.a[i] = (unsigned short)j;
+                if (i == i0) { closed = true; break; }
+                j = jprev;
+                if (j == (int)SP_NOCOL) break;
+            }
+            if (!closed) L.ri[32] = 1; else L.ri[32] = 0;
+        }
+        sp_sync();
+        if (L.ri[32]) { err = 3; }
+        sp_sync();
+        SP_TICK(4);
+    }
+
+    for (int k = tid; k < n; k += SP_T) {
+        w.p[k] = L.p[k];
+        w.owner[k] = (L.owner[k] == SP_NOCOL) ? -1 : (int)L.owner[k];
+        w.a[k] = (L.a[k] == SP_NOCOL) ? -1 : (int)L.a[k];
+    }
+#ifdef SP_PROFILE
+    if (tid == 0) {
+        long long* out = reinterpret_cast<long long*>(reinterpret_cast<char*>(st) + 256);
+        for (int q = 0; q < 5; ++q) out[q] = dbg[q];
+        out[5] = dbg[5]; out[6] = nfast; out[7] = batches; out[8] = L.ri[126]; for (int q = 0; q < 6; ++q) out[9 + q] = fbv[q]; out[15] = L.ri[125];
+    }
+#endif
+    if (tid == 0) {
+        st->nFC = nFC;
+        st->st_sap_batches += batches;
+        st->st_sap_row_scans += scans;
+        st->st_total_row_scans += scans;
+        st->st_dense_fallbacks += dense_scans;
+        if (err) st->error = err;
+        st->mode = MODE_SAP1_DONE;
+    }
+}

@@ -4,12 +4,12 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../libcfm_gfx950.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $CFM_EXTRA_FLAGS"
 mkdir -p "$HERE/obj"
 objs=""
 for f in abi cost sinkhorn assign sample elem mlp ode; do
   src="$HERE/$f.hip"; obj="$HERE/obj/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/cfm_common.h" -nt "$obj" ] || [ "$HERE/../../include/cfm_gfx950.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/cfm_common.h" -nt "$obj" ] || [ "$HERE/assign_sparse.h" -nt "$obj" ] || [ "$HERE/../../include/cfm_gfx950.h" -nt "$obj" ]; then
     "$HIPCC" $FLAGS -c "$src" -o "$obj" &
   fi
   objs="$objs $obj"

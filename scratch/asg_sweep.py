@@ -21,12 +21,14 @@ for name,B in (("C3",4096),("C2",4096),("C5",8192)):
     x0,x1=oracle.config_inputs(name,B=B)
     cfgs[name]=ot.cost_matrix(x0.to(dev),x1.to(dev))
 ref={}
-params=[(5,0.2,1e-6,0.02,4000,30,48),(5,0.2,1e-8,0.02,4000,30,48),(5,0.2,1e-6,0.01,4000,60,48),(4,0.1,1e-7,0.02,4000,30,48),(10,0.2,1e-7,0.02,4000,30,48),(5,0.2,1e-6,0.02,4000,30,16),(5,0.2,1e-6,0.02,4000,30,128),(5,0.2,1e-10,0.02,4000,30,48),(5,0.2,1e-6,0.05,4000,100,48)]
-for p in params:
+params=[(5,0.2,1e-6,0.02,4000,30,48),(5,0.2,1e-6,0.01,4000,60,48),(4,0.1,1e-7,0.02,4000,30,48),(5,0.2,1e-4,0.02,4000,30,48),(5,0.2,1e-5,0.05,4000,20,48),(10,0.2,1e-5,0.05,4000,10,48)]
+for sparse in (1,0):
+  lib.cfm_assign_set_mode(sparse)
+  for p in (params if sparse else params[:1]):
     lib.cfm_assign_set_params(*map(float,p[:4]),*map(int,p[4:]))
     for name in which:
         ms,st,perm=run(cfgs[name])
         key=name
         if key not in ref: ref[key]=perm.clone()
         same=bool(torch.equal(ref[key],perm))
-        print(f"{name} params={p} -> {ms:8.2f} ms stats[auct,arr,free,batches,sapscans,scans,steps,phases]={st} same_perm={same}",flush=True)
+        print(f"{name} sparse={sparse} params={p} -> {ms:8.2f} ms stats[auct,arr,free,batches,sapscans,scans,steps,phases]={st} same_perm={same}",flush=True)
