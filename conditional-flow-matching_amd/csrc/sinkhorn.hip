@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void sk_col_pass(const float* __restrict__ M, 
 }
 
 // Merge strip partials -> v_new; accumulate the previous iteration's marginal
-// error when that iteration was a check iteration.
+// error when that iteration was a check iteration.  Workgroup = 64 columns x 4
+// groups of strips (lane <-> column: every partial load is a coalesced 512 B
+// wave load, all of a thread's loads are in flight together), LDS merge.
+#define SK_FIN_MAXPER 16   // strips per thread: SK_NCHUNK_MAX / 4
 __global__ __launch_bounds__(256) void sk_col_finalize(int B1, int nchunk, double logb, double b,
                                                        SkState* __restrict__ st,
                                                        const double* __restrict__ pm,
@@ -192,32 +195,50 @@ __global__ __launch_bounds__(256) void sk_col_finalize(int B1, int nchunk, doubl
                                                        const double* __restrict__ v_old,
                                                        double* __restrict__ v_new, int check,
                                                        int slot) {
+    __shared__ double sm[4][64];
+    __shared__ double ss[4][64];
     if (st->done) return;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    double e2 = 0.0;
-    if (j < B1) {
-        double mm = SK_NEG;
-        for (int c = 0; c < nchunk; ++c) mm = fmax(mm, pm[(size_t)c * B1 + j]);
-        double tot = 0.0;
-        for (int c = 0; c < nchunk; ++c) tot += ps[(size_t)c * B1 + j] * exp(pm[(size_t)c * B1 + j] - mm);
-        const double vn = logb - (mm + log(tot));
-        v_new[j] = vn;
-        if (check) {
-            const double e = b * exp(v_old[j] - vn) - b;
-            e2 = e * e;
-        }
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    double m[SK_FIN_MAXPER], sv[SK_FIN_MAXPER];
+#pragma unroll
+    for (int q = 0; q < SK_FIN_MAXPER; ++q) {
+        const int c = part + 4 * q;
+        const bool ok = (j < B1) && (c < nchunk);
+        m[q] = ok ? pm[(size_t)c * B1 + j] : SK_NEG;
+        sv[q] = ok ? ps[(size_t)c * B1 + j] : 0.0;
     }
-    if (check) {
-        e2 = wave_sum_d(e2);
-        __shared__ double red[4];
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e2;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(&st->err2[slot], red[0] + red[1] + red[2] + red[3]);
+    double mm = SK_NEG;
+#pragma unroll
+    for (int q = 0; q < SK_FIN_MAXPER; ++q) mm = fmax(mm, m[q]);
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < SK_FIN_MAXPER; ++q) tot += sv[q] * exp(m[q] - mm);
+    sm[part][lane] = mm; ss[part][lane] = tot;
+    __syncthreads();
+    double e2 = 0.0;
+    if (part == 0) {
+        if (j < B1) {
+            const double m4 = fmax(fmax(sm[0][lane], sm[1][lane]), fmax(sm[2][lane], sm[3][lane]));
+            double t4 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t4 += ss[w][lane] * exp(sm[w][lane] - m4);
+            const double vn = logb - (m4 + log(t4));
+            v_new[j] = vn;
+            if (check) {
+                const double e = b * exp(v_old[j] - vn) - b;
+                e2 = e * e;
+            }
+        }
+        if (check) {
+            e2 = wave_sum_d(e2);
+            if (lane == 0) atomicAdd(&st->err2[slot], e2);
+        }
     }
 }
 
 template <bool PRECISE>
-__device__ __forceinline__ void sk_row_body(const float* __restrict__ M, int B0, int B1,
+__device__ __forceinline__ void sk_row_body_generic(const float* __restrict__ M, int B0, int B1,
                                             double inv_reg, double loga,
                                             const double* __restrict__ vv, double* __restrict__ u,
                                             int rows_per_wg, int vec) {
@@ -272,15 +293,91 @@ __device__ __forceinline__ void sk_row_body(const float* __restrict__ M, int B0,
     }
 }
 
+
+// ---- fast row pass: B1 % 1024 == 0, 16-byte aligned rows -------------------
+// One trip of the row LSE: U float4 per lane (4 * U columns), online (max, sum).
+template <bool PRECISE, int U>
+__device__ __forceinline__ void sk_row_trip(const float4 (&c)[U], int j0, double inv_reg,
+                                            const double* __restrict__ vv, double& m,
+                                            typename std::conditional<PRECISE, double, float>::type& s) {
+    typedef typename std::conditional<PRECISE, double, float>::type acc_t;
+    double x[U][4];
+    double mx = m;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int j = j0 + 256 * k;
+        const double4 v4 = *reinterpret_cast<const double4*>(vv + j);
+        x[k][0] = fma(-(double)c[k].x, inv_reg, v4.x);
+        x[k][1] = fma(-(double)c[k].y, inv_reg, v4.y);
+        x[k][2] = fma(-(double)c[k].z, inv_reg, v4.z);
+        x[k][3] = fma(-(double)c[k].w, inv_reg, v4.w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mx = fmax(mx, x[k][q]);
+    }
+    if (PRECISE) {
+        double acc = (double)s * exp(m - mx);
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += exp(x[k][q] - mx);
+        s = (acc_t)acc;
+    } else {
+        float acc = (float)s * __expf((float)(m - mx));
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += __expf((float)(x[k][q] - mx));
+        s = (acc_t)acc;
+    }
+    m = mx;
+}
+
+#define SK_ROW_PRE 16   // float4 per lane in flight per 4096-column segment
+
+// One wave per row; the row's first segment was loaded BEFORE v was staged into LDS (the two
+// latencies overlap), later segments of a longer row are loaded 16 float4 at a time.
+template <bool PRECISE>
+__device__ __forceinline__ void sk_row_fast(const float* __restrict__ row, int B1, double inv_reg,
+                                            double loga, const double* __restrict__ vv,
+                                            double* __restrict__ u_out, float4 (&pre)[SK_ROW_PRE]) {
+    typedef typename std::conditional<PRECISE, double, float>::type acc_t;
+    const int lane = threadIdx.x & 63;
+    double m = SK_NEG;
+    acc_t s = 0;
+    constexpr int UT = PRECISE ? 1 : 2;      // float4 per trip (the fp64-exp path is register hungry)
+    for (int seg = 0; seg < B1; seg += 4096) {
+        if (seg > 0) {
+#pragma unroll
+            for (int k = 0; k < SK_ROW_PRE; ++k)
+                pre[k] = *reinterpret_cast<const float4*>(row + seg + lane * 4 + 256 * k);
+        }
+        const int ntrip = min(4096, B1 - seg) / (256 * UT);     // B1 % 1024 == 0
+#pragma unroll
+        for (int t = 0; t < SK_ROW_PRE / UT; ++t) {
+            if (t < ntrip) {
+                float4 c4[UT];
+#pragma unroll
+                for (int k = 0; k < UT; ++k) c4[k] = pre[UT * t + k];
+                sk_row_trip<PRECISE, UT>(c4, seg + lane * 4 + 256 * UT * t, inv_reg, vv, m, s);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one trip at a time: bounds the live registers
+        }
+    }
+    const double mm = wave_max_d(m);
+    const double tot = wave_sum_d((double)s * exp(m - mm));
+    if (lane == 0) *u_out = loga - (mm + log(tot));
+}
+
 // Row pass: u_i = log a - LSE_j(v_j - M_ij/reg); also the convergence decision
 // for the previous iteration (every workgroup derives it from the same data).
-__global__ __launch_bounds__(256) void sk_row_pass(const float* __restrict__ M, int B0, int B1,
-                                                   double inv_reg, double loga,
-                                                   SkState* __restrict__ st,
-                                                   const double* __restrict__ v,
-                                                   double* __restrict__ u, int rows_per_wg,
-                                                   int check, int slot, double stop_thr, int ii,
-                                                   int vec, int v_in_lds, double precise_below) {
+template <bool FAST>
+__global__ __launch_bounds__(256, FAST ? 3 : 4) void sk_row_pass(const float* __restrict__ M, int B0, int B1,
+                                                      double inv_reg, double loga,
+                                                      SkState* __restrict__ st,
+                                                      const double* __restrict__ v,
+                                                      double* __restrict__ u, int rows_per_wg,
+                                                      int check, int slot, double stop_thr, int ii,
+                                                      int vec, int v_in_lds, double precise_below) {
     if (st->done) return;
     if (check) {
         const double err = sqrt(st->err2[slot]);
@@ -302,15 +399,38 @@ __global__ __launch_bounds__(256) void sk_row_pass(const float* __restrict__ M, 
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) st->err2[slot ^ 1] = 0.0;  // next accumulation slot
+    const int precise = st->precise;
 
     extern __shared__ __attribute__((aligned(16))) double vs[];
-    if (v_in_lds) {
-        for (int j = threadIdx.x; j < B1; j += 256) vs[j] = v[j];
+    if (FAST) {
+        // rows_per_wg == 4: one row per wave, v always staged in LDS
+        const int lane = threadIdx.x & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar row base
+        const int r = blockIdx.x * 4 + wv;
+        const bool have = r < B0;
+        const float* row = M + (size_t)(have ? r : 0) * B1;
+        float4 pre[SK_ROW_PRE];
+#pragma unroll
+        for (int k = 0; k < SK_ROW_PRE; ++k) {
+            const int j = lane * 4 + 256 * k;
+            pre[k] = (j < B1) ? *reinterpret_cast<const float4*>(row + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int j = threadIdx.x * 2; j < B1; j += 512)
+            *reinterpret_cast<double2*>(vs + j) = *reinterpret_cast<const double2*>(v + j);
         __syncthreads();
+        if (have) {
+            if (precise) sk_row_fast<true>(row, B1, inv_reg, loga, vs, u + r, pre);
+            else         sk_row_fast<false>(row, B1, inv_reg, loga, vs, u + r, pre);
+        }
+    } else {
+        if (v_in_lds) {
+            for (int j = threadIdx.x; j < B1; j += 256) vs[j] = v[j];
+            __syncthreads();
+        }
+        const double* vv = v_in_lds ? vs : v;
+        if (precise) sk_row_body_generic<true>(M, B0, B1, inv_reg, loga, vv, u, rows_per_wg, vec);
+        else         sk_row_body_generic<false>(M, B0, B1, inv_reg, loga, vv, u, rows_per_wg, vec);
     }
-    const double* vv = v_in_lds ? vs : v;
-    if (st->precise) sk_row_body<true>(M, B0, B1, inv_reg, loga, vv, u, rows_per_wg, vec);
-    else             sk_row_body<false>(M, B0, B1, inv_reg, loga, vv, u, rows_per_wg, vec);
 }
 
 __global__ void sk_finish(SkState* st, const double* u, const double* v0, const double* v1,
@@ -344,15 +464,19 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, 
     const double a = 1.0 / B0, b = 1.0 / B1;
     const double precise_below = 1e-4 / sqrt((double)B1);
     const double loga = log(a), logb = log(b);
-    const int rows_per_wg = 8;
+    // fast row pass: whole 1024-column trips, 16-byte aligned rows, v fits in LDS
+    const bool row_fast = vec && (B1 % 1024 == 0) && ((size_t)B1 * 8 <= 128 * 1024);
+    const int rows_per_wg = row_fast ? 4 : 8;
     const int row_wgs = (B0 + rows_per_wg - 1) / rows_per_wg;
     int v_in_lds = ((size_t)B1 * 8 <= 128 * 1024) ? 1 : 0;
     if (v_in_lds && (size_t)B1 * 8 > 48 * 1024) {
         static int raised = 0;   // dynamic LDS above the 64 KiB default needs the attribute
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)sk_row_pass,
+            hipError_t e = hipFuncSetAttribute((const void*)sk_row_pass<true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            raised = (e == hipSuccess) ? 1 : -1;
+            hipError_t e2 = hipFuncSetAttribute((const void*)sk_row_pass<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            raised = (e == hipSuccess && e2 == hipSuccess) ? 1 : -1;
             (void)hipGetLastError();
         }
         if (raised < 0) v_in_lds = 0;
@@ -376,12 +500,17 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, 
         if (trailing && !check) break;  // nothing left to measure
         hipLaunchKernelGGL(sk_col_pass, dim3(col_tiles, nchunk), dim3(256), 0, s, M, B0, B1, inv_reg,
                            w.st, w.u, w.pm, w.ps, rows_per_chunk, vec);
-        hipLaunchKernelGGL(sk_col_finalize, dim3(col_tiles), dim3(256), 0, s, B1, nchunk, logb, b,
+        hipLaunchKernelGGL(sk_col_finalize, dim3((B1 + 63) / 64), dim3(256), 0, s, B1, nchunk, logb, b,
                            w.st, w.pm, w.ps, w.v[(ii + 1) & 1], w.v[ii & 1], check, slot);
         if (trailing) break;
-        hipLaunchKernelGGL(sk_row_pass, dim3(row_wgs), dim3(256), lds, s, M, B0, B1, inv_reg, loga,
-                           w.st, w.v[ii & 1], w.u, rows_per_wg, check, slot, stop_thr, ii,
-                           vec, v_in_lds, precise_below);
+        if (row_fast && v_in_lds)
+            hipLaunchKernelGGL(sk_row_pass<true>, dim3(row_wgs), dim3(256), lds, s, M, B0, B1, inv_reg, loga,
+                               w.st, w.v[ii & 1], w.u, rows_per_wg, check, slot, stop_thr, ii,
+                               vec, v_in_lds, precise_below);
+        else
+            hipLaunchKernelGGL(sk_row_pass<false>, dim3(row_wgs), dim3(256), lds, s, M, B0, B1, inv_reg, loga,
+                               w.st, w.v[ii & 1], w.u, rows_per_wg, check, slot, stop_thr, ii,
+                               vec, v_in_lds, precise_below);
         if (poll && (ii & 511) == 511) {
             int rc = cfm_hip(hipMemcpyAsync(&host_done, &w.st->done, sizeof(int), hipMemcpyDeviceToHost, s));
             if (rc) return rc;
