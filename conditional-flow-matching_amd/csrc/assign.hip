@@ -18,11 +18,17 @@
 //   phase B  the same rounds with epsilon = 0 (Jonker-Volgenant "augmenting row
 //            reduction"): every kept pair is exactly tight, duals are exactly
 //            feasible (up to fp64 rounding).
-//   phase C  for each remaining free row a shortest-augmenting-path search run
-//            as batched Bellman-Ford label correcting: every batch relaxes ALL
-//            dirty rows whose label is below the best free-column label, one
-//            lane per column (single writer: dist/pred stay consistent without
-//            atomics).  Sequential depth = path hops, not visited columns.
+//   phase C  shortest augmenting paths for the remaining free rows.  First the free
+//            columns are "column reduced" (their stale auction prices are lowered until
+//            each is tight for some row: a pure dual ascent step).  Then MULTI-SOURCE
+//            rounds: one batched Bellman-Ford label-correcting search is grown from ALL
+//            free rows at once (a shortest-path forest, one tree per free row; every
+//            round relaxes all dirty rows, one lane per column: single writer, no
+//            atomics), and ONE path per tree that reached a free column is augmented
+//            (the trees are vertex disjoint; the dual update with the radius D = the
+//            longest accepted path makes every accepted path tight).  A phase costs the
+//            hop depth of one search but retires many free rows.  The last few (hard)
+//            rows go to the one-workgroup candidate-list solver (n <= 4096).
 //   phase D  fp64 certificate: dual feasibility + complementary slackness over
 //            the whole matrix, total cost.
 //
@@ -35,7 +41,10 @@
 #include <string.h>
 
 enum { MODE_INIT = 0, MODE_AUCTION = 1, MODE_ARR = 2, MODE_SAP = 3, MODE_CERT = 4, MODE_DONE = 5,
-       MODE_BUILD = 6, MODE_SAP1 = 7, MODE_SAP1_DONE = 8 };
+       MODE_BUILD = 6, MODE_SAP1 = 7, MODE_SAP1_DONE = 8,
+       MODE_UMIN = 9,      // u_i = min_k (c_ik + p_k) for every row (before the column reduction)
+       MODE_COLRED = 10,   // lower the price of every free column until it is tight
+       MODE_ROOTMIN = 11 };// u_r for the free rows of the next multi-source phase
 
 struct AsgParams {
     double theta;          // epsilon reduction factor
@@ -46,10 +55,11 @@ struct AsgParams {
     int arr_cap;           // max epsilon = 0 rounds
     int chunk;             // kernel pairs per host poll
     int max_pairs;         // safety cap on kernel pairs
-    int sparse;            // 1: phase C on candidate lists in one workgroup (n <= 4096)
+    int sparse;            // 1: the last free rows go to the one-workgroup candidate-list solver (n <= 4096)
+    int handoff;           // ... once at most this many free rows are left
 };
 
-static AsgParams g_params = {5.0, 0.2, 1e-6, 0.02, 4000, 30, 48, 400000, 1};
+static AsgParams g_params = {5.0, 0.2, 1e-6, 0.02, 4000, 30, 48, 400000, 1, 6};
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
                                       double stop_frac, int round_cap, int arr_cap, int chunk) {
@@ -63,6 +73,7 @@ extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps
 }
 
 extern "C" void cfm_assign_set_mode(int sparse) { g_params.sparse = sparse ? 1 : 0; }
+extern "C" void cfm_assign_set_handoff(int handoff) { if (handoff >= 0) g_params.handoff = handoff; }
 
 struct AsgState {
     int mode, n, phase, round;
@@ -78,7 +89,8 @@ struct AsgState {
     unsigned cmin_bits, cmax_bits;  // ordered-float atomics
     int round_cap, arr_cap;
     int nFC, sparse;
-    int st_dense_fallbacks, pad4;
+    int st_dense_fallbacks, handoff;
+    int st_ms_phases, st_ms_augmented;
 };
 
 // SAP scan list entry arrays (two copies: current / next)
@@ -87,6 +99,7 @@ struct SList {
     int* row;       // owner[j]
     double* base;   // dist[j] when it was listed
     double* rj;     // c[row,j] + p[j]  (= u_row: matched edge is tight)
+    int* root;      // tree of the entry (index of its free row in listF)
 };
 
 struct AsgWs {
@@ -102,6 +115,7 @@ struct AsgWs {
     int* listF;       // free rows snapshot for SAP
     int* listFC;      // free columns during SAP
     int* pred;
+    int* tcol;        // per tree: accepted free column of the phase (or -1)
     SList S[2];
     // candidate lists (n <= SP_NMAX): SP_K columns / costs per row, bound of the dropped ones
     uint2* cl;        // {column, fp32 cost bits}
@@ -111,7 +125,7 @@ struct AsgWs {
 static inline size_t asg_ws_bytes(int n) {
     size_t N = (size_t)n;
     size_t lists = (n <= 4096) ? N * 64 * 8 + 8 * N : 0;
-    return 512 + 8 * N * (4 + 4) + 4 * N * (7 + 4) + lists + 256;
+    return 512 + 8 * N * (4 + 4) + 4 * N * (8 + 6) + lists + 256;
 }
 
 static inline AsgWs asg_carve(void* ws, int n) {
@@ -129,7 +143,10 @@ static inline AsgWs asg_carve(void* ws, int n) {
     w.listF = (int*)q; q += 4 * N;
     w.listFC = (int*)q; q += 4 * N;
     w.pred = (int*)q; q += 4 * N;
-    for (int c = 0; c < 2; ++c) { w.S[c].col = (int*)q; q += 4 * N; w.S[c].row = (int*)q; q += 4 * N; }
+    w.tcol = (int*)q; q += 4 * N;
+    for (int c = 0; c < 2; ++c) {
+        w.S[c].col = (int*)q; q += 4 * N; w.S[c].row = (int*)q; q += 4 * N; w.S[c].root = (int*)q; q += 4 * N;
+    }
     w.cT = (double*)q; w.cl = nullptr;
     if (n <= 4096) { q += 8 * N; w.cl = (uint2*)q; q += 8 * N * 64; }
     return w;
@@ -251,12 +268,87 @@ __device__ void wide_bid(const float* __restrict__ M, const AsgWs& w, const AsgS
 }
 
 // ------------------------------------------------------------ wide: SAP ------
+// Row minima u_i = min_k (c_ik + p_k), one wave per row: for every row (before the column
+// reduction) or for the free rows of the next multi-source phase.  Result in bidval[row].
+__device__ void wide_umin(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+                          int wave_gid, int n_waves, bool roots_only) {
+    const int n = st->n;
+    const int cnt = roots_only ? st->nF : n;
+    const int lane = threadIdx.x & 63;
+    const bool vec = ((n & 3) == 0);
+    for (int t = wave_gid; t < cnt; t += n_waves) {
+        const int i = roots_only ? w.listF[t] : t;
+        const float* row = M + (size_t)i * n;
+        double m = INFINITY;
+        if (vec) {
+            for (int j0 = lane * 4; j0 < n; j0 += 1024) {
+                float4 c[4]; double2 pa[4], pb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = j0 + 256 * k;
+                    if (j < n) {
+                        c[k] = *reinterpret_cast<const float4*>(row + j);
+                        pa[k] = *reinterpret_cast<const double2*>(w.p + j);
+                        pb[k] = *reinterpret_cast<const double2*>(w.p + j + 2);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = j0 + 256 * k;
+                    if (j < n) {
+                        m = fmin(fmin(m, (double)c[k].x + pa[k].x), (double)c[k].y + pa[k].y);
+                        m = fmin(fmin(m, (double)c[k].z + pb[k].x), (double)c[k].w + pb[k].y);
+                    }
+                }
+            }
+        } else {
+            for (int j = lane; j < n; j += 64) m = fmin(m, (double)row[j] + w.p[j]);
+        }
+        m = wave_min_d(m);
+        if (lane == 0) w.bidval[i] = m;
+    }
+}
+
+// Column reduction of the free columns: p_k <- max_i (u_i - c_ik), the largest price at which
+// column k is still not cheaper than any row's current minimum.  No u_i changes, every matched
+// edge stays tight, the dual objective rises by the price drop.  One workgroup per column
+// (strided reads: 64 B sector per row, only nFC columns).
+__device__ void wide_colred(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+                            double* sh_d) {
+    const int n = st->n, nFC = st->nFC;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < nFC; t += gridDim.x) {
+        const int k = w.listFC[t];
+        double m = -INFINITY;
+        for (int i0 = threadIdx.x; i0 < n; i0 += WT * 4) {
+            float c[4]; double u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * WT;
+                c[q] = (i < n) ? M[(size_t)i * n + k] : 0.f;
+                u[q] = (i < n) ? w.bidval[i] : -INFINITY;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = fmax(m, u[q] - (double)c[q]);
+        }
+        m = wave_max_d(m);
+        if (lane == 0) sh_d[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double r = sh_d[0];
+            for (int q = 1; q < WT / 64; ++q) r = fmax(r, sh_d[q]);
+            if (r < w.p[k]) w.p[k] = r;      // prices of free columns only ever go down here
+        }
+        __syncthreads();
+    }
+}
+
 // Relax every listed row.  Workgroup g owns columns [64g, 64g+64): lane <-> column
-// (single writer: dist/pred stay consistent without atomics), the 16 waves split the
+// (single writer: dist/pred/tree stay consistent without atomics), the 16 waves split the
 // list, 8 independent row loads in flight per lane, LDS merge.  The writer lane
 // appends improved assigned columns to the NEXT list (one atomic per append).
 __device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState* st,
-                           double* sh_d, int* sh_i) {
+                           double* sh_d, int* sh_i, int* sh_r) {
     const int n = st->n, nS = st->nS, cur = st->cur;
     const double dfree = st->dfree;
     const SList L = w.S[cur], Nx = w.S[cur ^ 1];
@@ -267,14 +359,14 @@ __device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState
         const int k = g * 64 + lane;
         const bool ok = k < n;
         const double pk = ok ? w.p[k] : 0.0;
-        double best = INFINITY; int bi = 0x7fffffff;
+        double best = INFINITY; int bi = 0x7fffffff, br = -1;
         for (int t0 = wv * Q; t0 < nS; t0 += NW * Q) {
-            int ri[Q], cj[Q]; double bs[Q], rj[Q]; float c[Q];
+            int ri[Q], cj[Q], rt[Q]; double bs[Q], rj[Q]; float c[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int t = t0 + q;
                 const bool v = t < nS;
-                ri[q] = v ? L.row[t] : 0; cj[q] = v ? L.col[t] : -1;
+                ri[q] = v ? L.row[t] : 0; cj[q] = v ? L.col[t] : -1; rt[q] = v ? L.root[t] : -1;
                 bs[q] = v ? L.base[t] : INFINITY; rj[q] = v ? L.rj[t] : 0.0;
             }
 #pragma unroll
@@ -286,24 +378,24 @@ __device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState
                     double rc = ((double)c[q] + pk) - rj[q];
                     rc = fmax(rc, 0.0);                   // dual feasible up to rounding
                     const double cand = bs[q] + rc;
-                    if (cand < best || (cand == best && ri[q] < bi)) { best = cand; bi = ri[q]; }
+                    if (cand < best || (cand == best && ri[q] < bi)) { best = cand; bi = ri[q]; br = rt[q]; }
                 }
             }
         }
-        sh_d[wv * 64 + lane] = best; sh_i[wv * 64 + lane] = bi;
+        sh_d[wv * 64 + lane] = best; sh_i[wv * 64 + lane] = bi; sh_r[wv * 64 + lane] = br;
         __syncthreads();
         if (wv == 0 && ok) {
 #pragma unroll
             for (int q = 1; q < NW; ++q) {
                 const double c2 = sh_d[q * 64 + lane]; const int i2 = sh_i[q * 64 + lane];
-                if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; }
+                if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = sh_r[q * 64 + lane]; }
             }
             if (best < w.dist[k]) {
                 w.dist[k] = best; w.pred[k] = bi;
                 const int ow = w.owner[k];
                 if (ow >= 0 && best < dfree) {
                     const int idx = atomicAdd(&st->nN, 1);
-                    Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best;
+                    Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = br;
                     Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
                 }
             }
@@ -342,6 +434,7 @@ __global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgW
     extern __shared__ __attribute__((aligned(16))) char wide_lds[];   // modes are exclusive
     double* sh_d = reinterpret_cast<double*>(wide_lds);
     int* sh_i = reinterpret_cast<int*>(wide_lds + sizeof(double) * WT);
+    int* sh_r = sh_i + WT;
     AsgState* st = w.st;
     const int mode = st->mode;
     if (mode == MODE_DONE || st->error) return;
@@ -349,7 +442,10 @@ __global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgW
     const int wave_gid = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
     const int n_waves = gridDim.x * (WT / 64);
     if (mode == MODE_AUCTION || mode == MODE_ARR) wide_bid(M, w, st, wave_gid, n_waves);
-    else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i);
+    else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i, sh_r);
+    else if (mode == MODE_UMIN) wide_umin(M, w, st, wave_gid, n_waves, false);
+    else if (mode == MODE_ROOTMIN) wide_umin(M, w, st, wave_gid, n_waves, true);
+    else if (mode == MODE_COLRED) wide_colred(M, w, st, sh_d);
     else if (mode == MODE_CERT) wide_cert(M, w, st, wave_gid, n_waves);
     else if (mode == MODE_BUILD) wide_build(M, w, st, wide_lds);
     else if (mode == MODE_SAP1) { if (blockIdx.x == 0) sp_solver(M, w, st, wide_lds); }
@@ -439,69 +535,49 @@ __device__ void ctrl_award(const AsgWs& w, AsgState* st, int* sh) {
     __syncthreads();
 }
 
-// best free column under the current labels
-__device__ void ctrl_dfree(const AsgWs& w, AsgState* st, double* shd, int* shi) {
+// Pruning radius of a multi-source phase.  One tree: the best free-column label (no label
+// at or above it can matter).  Several trees: the LARGEST free-column label, an upper bound of
+// the radius the phase will accept (every tree's nearest free column is at most that far);
+// it only ever decreases, so an entry skipped once is never needed later.
+__device__ void ctrl_radius(const AsgWs& w, AsgState* st, double* shd, int* shi) {
     const int nFC = st->nFC;
+    const bool single = (st->nF == 1);
     double lm = INFINITY; int li = 0x7fffffff;
     for (int t = threadIdx.x; t < nFC; t += CT) {
-        const int k = w.listFC[t]; const double dk = w.dist[k];
+        const int k = w.listFC[t];
+        const double dk = single ? w.dist[k] : -w.dist[k];
         if (dk < lm || (dk == lm && k < li)) { lm = dk; li = k; }
     }
-    double dfree; int jfree;
-    block_argmin(lm, li, &dfree, &jfree, shd, shi);
-    if (threadIdx.x == 0) { st->dfree = dfree; st->jfree = jfree; }
+    double r; int jr;
+    block_argmin(lm, li, &r, &jr, shd, shi);
+    if (threadIdx.x == 0) { st->dfree = single ? r : -r; st->jfree = jr; }
     __syncthreads();
 }
 
-// Start the search from the next free row: labels from row i0, first scan list.
-// Returns false when there is no free row left.
-__device__ bool ctrl_sap_begin(const float* __restrict__ M, const AsgWs& w, AsgState* st,
-                               double* shd, int* shi, int* sh) {
-    const int n = st->n;
-    if (st->fidx >= st->nF) return false;
-    const int i0 = w.listF[st->fidx];
-    const int cur = st->cur;
-    __syncthreads();
-    const float* row = M + (size_t)i0 * n;
-    double lm = INFINITY; int li = 0x7fffffff;
-    for (int k = threadIdx.x; k < n; k += CT) {
-        const double r = (double)row[k] + w.p[k];
-        w.dist[k] = r;
-        if (r < lm) { lm = r; li = k; }
-    }
-    double rmin; int rarg;
-    block_argmin(lm, li, &rmin, &rarg, shd, shi);
-    for (int k = threadIdx.x; k < n; k += CT) {
-        w.dist[k] = w.dist[k] - rmin;       // >= 0, exact zero at the argmin
-        w.pred[k] = i0;
-    }
-    if (threadIdx.x == 0) { st->i0 = i0; st->nN = 0; }
-    __syncthreads();
-    ctrl_dfree(w, st, shd, shi);
-    const double dfree = st->dfree;
+#define MS_NONE 0x7fffffff
+
+// Start a multi-source phase: labels unset, one root entry per free row (u_r in bidval[]).
+__device__ void ctrl_ms_begin(const AsgWs& w, AsgState* st) {
+    const int n = st->n, nF = st->nF, cur = st->cur;
     const SList L = w.S[cur];
-    int base = 0;
-    for (int k0 = 0; k0 < n; k0 += CT) {
-        const int k = k0 + threadIdx.x;
-        int f = 0, ow = -1; double dk = 0.0;
-        if (k < n) { ow = w.owner[k]; dk = w.dist[k]; f = (ow >= 0 && dk < dfree) ? 1 : 0; }
-        int tot;
-        const int off = block_scan_excl(f, &tot, sh);
-        if (f) {
-            const int idx = base + off;
-            L.col[idx] = k; L.row[idx] = ow; L.base[idx] = dk;
-            L.rj[idx] = (double)M[(size_t)ow * n + k] + w.p[k];
-        }
-        base += tot;
-    }
-    if (threadIdx.x == 0) st->nS = base;
     __syncthreads();
-    return true;
+    for (int k = threadIdx.x; k < n; k += CT) { w.dist[k] = INFINITY; w.pred[k] = -1; }
+    for (int t = threadIdx.x; t < nF; t += CT) {
+        const int r = w.listF[t];
+        L.col[t] = -1; L.row[t] = r; L.base[t] = 0.0; L.rj[t] = w.bidval[r]; L.root[t] = t;
+        w.listA[r] = t;                 // row -> tree index (listA is free after the auction)
+        w.tcol[t] = MS_NONE; w.packed[t] = ~0ull;
+    }
+    if (threadIdx.x == 0) {
+        st->nS = nF; st->nN = 0; st->dfree = INFINITY; st->jfree = -1; st->mode = MODE_SAP;
+        st->st_ms_phases++;
+    }
+    __syncthreads();
 }
 
-// After a relax batch: new dfree, swap lists; returns true if another batch is needed.
+// After a relax round: new radius, swap lists; returns true if another round is needed.
 __device__ bool ctrl_sap_step(const AsgWs& w, AsgState* st, double* shd, int* shi) {
-    ctrl_dfree(w, st, shd, shi);
+    ctrl_radius(w, st, shd, shi);
     const double dfree = st->dfree;
     const int nN = st->nN, cur = st->cur;
     const SList Nx = w.S[cur ^ 1];
@@ -513,41 +589,113 @@ __device__ bool ctrl_sap_step(const AsgWs& w, AsgState* st, double* shd, int* sh
     return any != 0;
 }
 
-// dual update + augmentation along pred (path walk in LDS when it fits)
-__device__ void ctrl_sap_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds_pred, bool use_lds) {
-    const int n = st->n;
-    const double dfree = st->dfree;
-    const int i0 = st->i0, jfree = st->jfree, nFC = st->nFC;
+// The forest has converged below the radius.  Every free column with a finite label belongs to
+// exactly one tree (walk the predecessors to its free row); each tree accepts its nearest free
+// column (ties: lowest column).  With D = the largest accepted label, the dual update
+//     p_k += D - d_k  for every column with d_k < D   (u follows through the tight matched edges)
+// keeps the duals feasible and makes every accepted path tight; the paths are vertex disjoint
+// (different trees), so all of them are augmented.  Returns the number of augmented paths.
+__device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds_pred, bool use_lds,
+                              double* shd, int* shi, int* sh) {
+    const int n = st->n, nF = st->nF, nFC = st->nFC;
     __syncthreads();
+    if (use_lds) {
+        for (int k = threadIdx.x; k < n; k += CT) { lds_pred[k] = w.pred[k]; lds_a[k] = w.a[k]; }
+        __syncthreads();
+    }
+    const int* A = use_lds ? lds_a : w.a;
+    const int* P = use_lds ? lds_pred : w.pred;
+    int bad = 0;
+    // pass 1: tree of every reached free column, per-tree best label
+    for (int t = threadIdx.x; t < nFC; t += CT) {
+        const int k = w.listFC[t];
+        const double d = w.dist[k];
+        int ti = -1;
+        if (d < INFINITY) {
+            int j = k, guard = 0;
+            for (;;) {
+                const int i = P[j];
+                if (i < 0 || ++guard > n + 1) { bad = 1; break; }
+                const int aj = A[i];
+                if (aj < 0) { ti = w.listA[i]; break; }
+                j = aj;
+            }
+            if (ti >= 0) atomicMin(&w.packed[ti], d2ord(d));
+        }
+        w.bidcol[t] = ti;
+    }
+    bad = __syncthreads_or(bad);
+    if (bad) { if (threadIdx.x == 0) st->error = 3; __syncthreads(); return 0; }
+    // pass 2: accepted column of every tree
+    for (int t = threadIdx.x; t < nFC; t += CT) {
+        const int ti = w.bidcol[t];
+        if (ti >= 0) {
+            const int k = w.listFC[t];
+            if (d2ord(w.dist[k]) == w.packed[ti]) atomicMin(&w.tcol[ti], k);
+        }
+    }
+    __syncthreads();
+    // radius D = largest accepted label
+    double lm = INFINITY; int cnt = 0;
+    for (int t = threadIdx.x; t < nF; t += CT) {
+        if (w.tcol[t] != MS_NONE) { lm = fmin(lm, -ord2d(w.packed[t])); ++cnt; }
+    }
+    double negD; int dummy;
+    block_argmin(lm, threadIdx.x, &negD, &dummy, shd, shi);
+    int total;
+    block_scan_excl(cnt, &total, sh);
+    if (total == 0) { if (threadIdx.x == 0) st->error = 5; __syncthreads(); return 0; }
+    const double D = -negD;
     for (int k = threadIdx.x; k < n; k += CT) {
-        if (w.owner[k] >= 0) {
-            const double dk = w.dist[k];
-            if (dk < dfree) w.p[k] += dfree - dk;     // v_k -= (dfree - d_k)
-        }
-        if (use_lds) lds_pred[k] = w.pred[k];
+        const double dk = w.dist[k];
+        if (dk < D) w.p[k] += D - dk;
     }
-    if (use_lds) for (int i = threadIdx.x; i < n; i += CT) lds_a[i] = w.a[i];
-    // drop jfree from the free-column list (swap with last)
-    for (int t = threadIdx.x; t < nFC; t += CT)
-        if (w.listFC[t] == jfree) w.listFC[t] = w.listFC[nFC - 1];   // single match
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int j = jfree, guard = 0;
-        bool closed = false;
+    // augment (one thread per accepted tree; the paths are vertex disjoint)
+    for (int t = threadIdx.x; t < nF; t += CT) {
+        int j = w.tcol[t];
+        if (j == MS_NONE) continue;
+        const int r = w.listF[t];
+        int guard = 0; bool closed = false;
         while (guard++ <= n) {
-            const int i = use_lds ? lds_pred[j] : w.pred[j];
-            const int jprev = use_lds ? lds_a[i] : w.a[i];
+            const int i = P[j];
+            const int jprev = A[i];          // the OLD match of row i (lds copy / not yet overwritten)
             w.owner[j] = i; w.a[i] = j;
-            if (use_lds) lds_a[i] = j;
-            if (i == i0) { closed = true; break; }
+            if (jprev < 0) { closed = (i == r); break; }
             j = jprev;
-            if (j < 0) break;
         }
-        if (!closed) st->error = 3;
-        st->nFC = nFC - 1;
-        st->st_total_row_scans += 1;
+        if (!closed) bad = 1;
+    }
+    bad = __syncthreads_or(bad);
+    if (bad) { if (threadIdx.x == 0) st->error = 3; __syncthreads(); return 0; }
+    // drop the matched rows / columns from the free lists (in-place, order preserving)
+    int baseF = 0;
+    for (int t0 = 0; t0 < nF; t0 += CT) {
+        const int t = t0 + threadIdx.x;
+        int r = -1, f = 0;
+        if (t < nF) { r = w.listF[t]; f = (w.a[r] < 0) ? 1 : 0; }
+        int tot;
+        const int off = block_scan_excl(f, &tot, sh);
+        if (f) w.listF[baseF + off] = r;
+        baseF += tot;
+    }
+    int baseC = 0;
+    for (int t0 = 0; t0 < nFC; t0 += CT) {
+        const int t = t0 + threadIdx.x;
+        int k = -1, f = 0;
+        if (t < nFC) { k = w.listFC[t]; f = (w.owner[k] < 0) ? 1 : 0; }
+        int tot;
+        const int off = block_scan_excl(f, &tot, sh);
+        if (f) w.listFC[baseC + off] = k;
+        baseC += tot;
+    }
+    if (threadIdx.x == 0) {
+        st->nF = baseF; st->nFC = baseC; st->fidx = 0;
+        st->st_ms_augmented += total;
+        st->st_total_row_scans += total;
+        if (baseF != baseC || baseF != nF - total) st->error = 4;
     }
     __syncthreads();
+    return total;
 }
 
 __device__ void ctrl_enter_cert(AsgState* st) {
@@ -587,7 +735,6 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
         return;
     }
 
-    bool sap_converged = false;
     if (mode == MODE_AUCTION || mode == MODE_ARR) {
         // snapshot everything the decision needs BEFORE thread 0 mutates the state
         const int bidders = st->nU, round = st->round, round_cap = st->round_cap, stop = st->stop;
@@ -623,7 +770,7 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
             return;
         }
         if (arr_round + 1 < arr_cap) return;
-        // -> SAP: snapshot the free rows and the free columns
+        // -> phase C: snapshot the free rows and the free columns, then column reduction
         for (int t = threadIdx.x; t < nU; t += CT) w.listF[t] = w.listA[t];
         {
             int base = 0;
@@ -635,27 +782,20 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
                 if (f) w.listFC[base + off] = k;
                 base += tot;
             }
-            const int sparse = st->sparse;
             __syncthreads();
             if (threadIdx.x == 0) {
                 st->nFC = base; st->nF = nU; st->fidx = 0; st->st_free_after_arr = nU;
-                st->mode = sparse ? MODE_BUILD : MODE_SAP; st->cur = 0; st->nN = 0;
+                st->mode = MODE_UMIN; st->cur = 0; st->nN = 0;
                 if (base != nU) st->error = 4;
             }
-            if (sparse) return;
         }
-        __syncthreads();
-        ctrl_sap_begin(M, w, st, shd, shi, sh);
-        if (st->nS > 0) return;
-        mode = MODE_SAP; sap_converged = true;
-    } else if (mode == MODE_SAP) {
-        const int scanned = st->nS;
-        __syncthreads();
-        if (threadIdx.x == 0) { st->st_sap_batches++; st->st_sap_row_scans += scanned; st->st_total_row_scans += scanned; }
-        if (ctrl_sap_step(w, st, shd, shi)) return;
-        sap_converged = true;
+        return;
     }
 
+    if (mode == MODE_UMIN) {           // bidval[i] = u_i for every row
+        if (threadIdx.x == 0) { st->mode = MODE_COLRED; st->st_total_row_scans += n; }
+        return;
+    }
     if (mode == MODE_BUILD) {          // the wide pass has written the candidate lists
         if (threadIdx.x == 0) st->mode = MODE_SAP1;
         return;
@@ -664,16 +804,28 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
         ctrl_enter_cert(st);
         return;
     }
-    if (mode == MODE_SAP && sap_converged) {
-        // search converged (possibly several in a row if they need no relaxation)
-        for (;;) {
-            ctrl_sap_finish(w, st, dyn, dyn + n, use_lds);
-            if (threadIdx.x == 0) st->fidx++;
-            __syncthreads();
-            if (st->error) return;
-            if (!ctrl_sap_begin(M, w, st, shd, shi, sh)) { ctrl_enter_cert(st); return; }
-            if (st->nS > 0) return;
-        }
+    if (mode == MODE_COLRED || mode == MODE_ROOTMIN) {
+        // free-column prices are reduced / the roots' u_r are known: hand the last few rows to
+        // the candidate-list solver, otherwise grow a forest from all free rows
+        const int nF = st->nF, sparse = st->sparse, handoff = st->handoff;
+        __syncthreads();
+        if (sparse && nF <= handoff) { if (threadIdx.x == 0) st->mode = MODE_BUILD; return; }
+        ctrl_ms_begin(w, st);
+        return;
+    }
+    if (mode == MODE_SAP) {
+        const int scanned = st->nS;
+        __syncthreads();
+        if (threadIdx.x == 0) { st->st_sap_batches++; st->st_sap_row_scans += scanned; st->st_total_row_scans += scanned; }
+        if (ctrl_sap_step(w, st, shd, shi)) return;
+        // converged below the radius: accept one path per tree
+        ctrl_ms_finish(w, st, dyn, dyn + n, use_lds, shd, shi, sh);
+        if (st->error) return;
+        const int nF = st->nF;
+        __syncthreads();
+        if (nF == 0) { ctrl_enter_cert(st); return; }
+        if (threadIdx.x == 0) st->mode = (st->sparse && nF <= st->handoff) ? MODE_BUILD : MODE_ROOTMIN;
+        return;
     }
 
     if (mode == MODE_CERT) {
@@ -693,7 +845,8 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
                 stats[0] = st->st_auction_rounds; stats[1] = st->st_arr_rounds;
                 stats[2] = st->st_free_after_arr; stats[3] = st->st_sap_batches;
                 stats[4] = st->st_sap_row_scans; stats[5] = st->st_total_row_scans;
-                stats[6] = st->st_steps; stats[7] = st->phase | (st->st_dense_fallbacks << 8);
+                stats[6] = st->st_steps;
+                stats[7] = (st->phase & 0xff) | ((st->st_ms_phases & 0xff) << 8) | (st->st_dense_fallbacks << 16);
             }
             __threadfence();
             st->mode = MODE_DONE;
@@ -738,7 +891,8 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     h.stop_frac = g_params.stop_frac; h.round_cap = g_params.round_cap; h.arr_cap = g_params.arr_cap;
     h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
     h.sparse = (use_sparse && n <= SP_NMAX) ? 1 : 0;
-    size_t wide_dyn = sizeof(double) * WT + sizeof(int) * WT;
+    h.handoff = g_params.handoff;
+    size_t wide_dyn = sizeof(double) * WT + 2 * sizeof(int) * WT;
     if (h.sparse) {
         const size_t need = sp_lds_bytes(n);
         if (need > wide_dyn) wide_dyn = need;
@@ -749,7 +903,7 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
             raised = (e == hipSuccess) ? 1 : -1;
             (void)hipGetLastError();
         }
-        if (raised < 0 && wide_dyn > 64 * 1024) { h.sparse = 0; wide_dyn = sizeof(double) * WT + sizeof(int) * WT; }
+        if (raised < 0 && wide_dyn > 64 * 1024) { h.sparse = 0; wide_dyn = sizeof(double) * WT + 2 * sizeof(int) * WT; }
     }
     int rc = cfm_hip(hipMemcpyAsync(w.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
     if (rc) return rc;

@@ -113,7 +113,7 @@ int cfm_sinkhorn_cost_f64(const float* M, int B0, int B1, double reg, const void
  * *total_cost (device double) = sum_i M[i,perm[i]];
  * stats (device int32[8], may be NULL): {auction_rounds, arr_rounds,
  *  free_rows_after_arr, sap_batches, sap_row_scans, total_row_scans, steps,
- *  eps_phases | dense_fallback_row_scans << 8}.
+ *  eps_phases | multi_source_phases << 8 | dense_fallback_row_scans << 16}.
  * ws: cfm_workspace_bytes(CFM_OP_ASSIGN,B,B,0) bytes. */
 int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,
                          double* total_cost, int* stats, void* ws, void* stream);
