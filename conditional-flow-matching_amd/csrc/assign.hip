@@ -57,9 +57,10 @@ struct AsgParams {
     int max_pairs;         // safety cap on kernel pairs
     int sparse;            // 1: the last free rows go to the one-workgroup candidate-list solver (n <= 4096)
     int handoff;           // ... once at most this many free rows are left
+    double ms_q;           // radius of a multi-source phase: quantile of the free-column labels
 };
 
-static AsgParams g_params = {5.0, 0.2, 1e-6, 0.02, 4000, 30, 48, 400000, 1, 6};
+static AsgParams g_params = {5.0, 0.2, 1e-6, 0.02, 4000, 15, 64, 400000, 1, 6, 1.0};
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
                                       double stop_frac, int round_cap, int arr_cap, int chunk) {
@@ -74,6 +75,7 @@ extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps
 
 extern "C" void cfm_assign_set_mode(int sparse) { g_params.sparse = sparse ? 1 : 0; }
 extern "C" void cfm_assign_set_handoff(int handoff) { if (handoff >= 0) g_params.handoff = handoff; }
+extern "C" void cfm_assign_set_ms_quantile(double q) { if (q > 0.0 && q <= 1.0) g_params.ms_q = q; }
 
 struct AsgState {
     int mode, n, phase, round;
@@ -91,6 +93,8 @@ struct AsgState {
     int nFC, sparse;
     int st_dense_fallbacks, handoff;
     int st_ms_phases, st_ms_augmented;
+    double ms_q;
+    int wide_blocks, parts;   // grid of asg_wide; split factor of the relax round just run
 };
 
 // SAP scan list entry arrays (two copies: current / next)
@@ -116,16 +120,22 @@ struct AsgWs {
     int* listFC;      // free columns during SAP
     int* pred;
     int* tcol;        // per tree: accepted free column of the phase (or -1)
+    double* part_d;   // [MS_YMAX][n] partial minima of a split relax round
+    int* part_i;      // [MS_YMAX][n] their rows
+    int* part_r;      // [MS_YMAX][n] their trees
     SList S[2];
     // candidate lists (n <= SP_NMAX): SP_K columns / costs per row, bound of the dropped ones
     uint2* cl;        // {column, fp32 cost bits}
     double* cT;
 };
 
+#define MS_YMAX 4       // a big relax round is split over this many workgroups per column group
+#define MS_SPLIT_MIN 256 // ... when it has more than this many entries
+
 static inline size_t asg_ws_bytes(int n) {
     size_t N = (size_t)n;
     size_t lists = (n <= 4096) ? N * 64 * 8 + 8 * N : 0;
-    return 512 + 8 * N * (4 + 4) + 4 * N * (8 + 6) + lists + 256;
+    return 512 + 8 * N * (4 + 4) + 4 * N * (8 + 6) + 16 * N * MS_YMAX + lists + 256;
 }
 
 static inline AsgWs asg_carve(void* ws, int n) {
@@ -147,6 +157,9 @@ static inline AsgWs asg_carve(void* ws, int n) {
     for (int c = 0; c < 2; ++c) {
         w.S[c].col = (int*)q; q += 4 * N; w.S[c].row = (int*)q; q += 4 * N; w.S[c].root = (int*)q; q += 4 * N;
     }
+    w.part_d = (double*)q; q += 8 * N * MS_YMAX;
+    w.part_i = (int*)q; q += 4 * N * MS_YMAX;
+    w.part_r = (int*)q; q += 4 * N * MS_YMAX;
     w.cT = (double*)q; w.cl = nullptr;
     if (n <= 4096) { q += 8 * N; w.cl = (uint2*)q; q += 8 * N * 64; }
     return w;
@@ -343,10 +356,19 @@ __device__ void wide_colred(const float* __restrict__ M, const AsgWs& w, const A
     }
 }
 
-// Relax every listed row.  Workgroup g owns columns [64g, 64g+64): lane <-> column
-// (single writer: dist/pred/tree stay consistent without atomics), the 16 waves split the
+// How many workgroups share one column group in a relax round of nS entries.
+__device__ __forceinline__ int ms_split(int nS, int n_groups, int blocks) {
+    if (nS <= MS_SPLIT_MIN) return 1;
+    int y = blocks / n_groups;
+    return y < 1 ? 1 : (y > MS_YMAX ? MS_YMAX : y);
+}
+
+// Relax every listed row.  A workgroup owns columns [64g, 64g+64): lane <-> column
+// (single writer: dist/pred/tree stay consistent without atomics), its 16 waves split the
 // list, 8 independent row loads in flight per lane, LDS merge.  The writer lane
-// appends improved assigned columns to the NEXT list (one atomic per append).
+// appends improved assigned columns to the NEXT list (one atomic per append).  A big round
+// is split over Y workgroups per column group (every Y-th slice of the list each); they write
+// per-column partial minima and asg_ctrl merges them (ctrl_ms_merge).
 __device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState* st,
                            double* sh_d, int* sh_i, int* sh_r) {
     const int n = st->n, nS = st->nS, cur = st->cur;
@@ -355,12 +377,14 @@ __device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_groups = (n + 63) / 64;
     constexpr int Q = 8, NW = WT / 64;
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int Y = ms_split(nS, n_groups, gridDim.x);
+    for (int unit = blockIdx.x; unit < n_groups * Y; unit += gridDim.x) {
+        const int g = unit % n_groups, y = unit / n_groups;
         const int k = g * 64 + lane;
         const bool ok = k < n;
         const double pk = ok ? w.p[k] : 0.0;
         double best = INFINITY; int bi = 0x7fffffff, br = -1;
-        for (int t0 = wv * Q; t0 < nS; t0 += NW * Q) {
+        for (int t0 = (y * NW + wv) * Q; t0 < nS; t0 += NW * Q * Y) {
             int ri[Q], cj[Q], rt[Q]; double bs[Q], rj[Q]; float c[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
@@ -390,7 +414,9 @@ __device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState
                 const double c2 = sh_d[q * 64 + lane]; const int i2 = sh_i[q * 64 + lane];
                 if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = sh_r[q * 64 + lane]; }
             }
-            if (best < w.dist[k]) {
+            if (Y > 1) {
+                w.part_d[(size_t)y * n + k] = best; w.part_i[(size_t)y * n + k] = bi; w.part_r[(size_t)y * n + k] = br;
+            } else if (best < w.dist[k]) {
                 w.dist[k] = best; w.pred[k] = bi;
                 const int ow = w.owner[k];
                 if (ow >= 0 && best < dfree) {
@@ -536,12 +562,34 @@ __device__ void ctrl_award(const AsgWs& w, AsgState* st, int* sh) {
 }
 
 // Pruning radius of a multi-source phase.  One tree: the best free-column label (no label
-// at or above it can matter).  Several trees: the LARGEST free-column label, an upper bound of
-// the radius the phase will accept (every tree's nearest free column is at most that far);
-// it only ever decreases, so an entry skipped once is never needed later.
-__device__ void ctrl_radius(const AsgWs& w, AsgState* st, double* shd, int* shi) {
+// at or above it can matter).  Several trees: the q-quantile of the free-column labels (q = 1:
+// the largest).  Any radius is valid — labels at or below it are final once no listed entry is
+// below it, and only free columns at or below it are accepted — a smaller one trades fewer
+// augmentations per phase for far fewer relaxations of rows whose labels are still poor.  It
+// only ever decreases within a phase, so an entry skipped once is never needed later.
+__device__ void ctrl_radius(const AsgWs& w, AsgState* st, double* shd, int* shi, double* scratch) {
     const int nFC = st->nFC;
     const bool single = (st->nF == 1);
+    const double q = st->ms_q;
+    if (!single && nFC <= CT && q < 1.0) {
+        const int t = threadIdx.x;
+        const double v = (t < nFC) ? w.dist[w.listFC[t]] : INFINITY;
+        __syncthreads();
+        if (t < nFC) scratch[t] = v;
+        __syncthreads();
+        int kq = (int)ceil(q * nFC) - 1;
+        kq = kq < 0 ? 0 : (kq > nFC - 1 ? nFC - 1 : kq);
+        if (t < nFC) {
+            int rank = 0;
+            for (int s2 = 0; s2 < nFC; ++s2) {
+                const double vs = scratch[s2];
+                rank += (vs < v || (vs == v && s2 < t)) ? 1 : 0;
+            }
+            if (rank == kq) { st->dfree = v; st->jfree = -1; }
+        }
+        __syncthreads();
+        return;
+    }
     double lm = INFINITY; int li = 0x7fffffff;
     for (int t = threadIdx.x; t < nFC; t += CT) {
         const int k = w.listFC[t];
@@ -575,9 +623,34 @@ __device__ void ctrl_ms_begin(const AsgWs& w, AsgState* st) {
     __syncthreads();
 }
 
+// A split relax round left Y partial minima per column: merge (ties -> lowest row, as inside a
+// workgroup), lower the label, list the improved assigned columns.
+__device__ void ctrl_ms_merge(const float* __restrict__ M, const AsgWs& w, AsgState* st, int Y) {
+    const int n = st->n, cur = st->cur;
+    const double dfree = st->dfree;
+    const SList Nx = w.S[cur ^ 1];
+    for (int k = threadIdx.x; k < n; k += CT) {
+        double best = w.part_d[k]; int bi = w.part_i[k], br = w.part_r[k];
+        for (int y = 1; y < Y; ++y) {
+            const double c2 = w.part_d[(size_t)y * n + k]; const int i2 = w.part_i[(size_t)y * n + k];
+            if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = w.part_r[(size_t)y * n + k]; }
+        }
+        if (best < w.dist[k]) {
+            w.dist[k] = best; w.pred[k] = bi;
+            const int ow = w.owner[k];
+            if (ow >= 0 && best < dfree) {
+                const int idx = atomicAdd(&st->nN, 1);
+                Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = br;
+                Nx.rj[idx] = (double)M[(size_t)ow * n + k] + w.p[k];
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // After a relax round: new radius, swap lists; returns true if another round is needed.
-__device__ bool ctrl_sap_step(const AsgWs& w, AsgState* st, double* shd, int* shi) {
-    ctrl_radius(w, st, shd, shi);
+__device__ bool ctrl_sap_step(const AsgWs& w, AsgState* st, double* shd, int* shi, double* scratch) {
+    ctrl_radius(w, st, shd, shi, scratch);
     const double dfree = st->dfree;
     const int nN = st->nN, cur = st->cur;
     const SList Nx = w.S[cur ^ 1];
@@ -598,6 +671,7 @@ __device__ bool ctrl_sap_step(const AsgWs& w, AsgState* st, double* shd, int* sh
 __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds_pred, bool use_lds,
                               double* shd, int* shi, int* sh) {
     const int n = st->n, nF = st->nF, nFC = st->nFC;
+    const double radius = st->dfree;
     __syncthreads();
     if (use_lds) {
         for (int k = threadIdx.x; k < n; k += CT) { lds_pred[k] = w.pred[k]; lds_a[k] = w.a[k]; }
@@ -611,7 +685,7 @@ __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds
         const int k = w.listFC[t];
         const double d = w.dist[k];
         int ti = -1;
-        if (d < INFINITY) {
+        if (d < INFINITY && d <= radius) {      // labels above the radius are not final
             int j = k, guard = 0;
             for (;;) {
                 const int i = P[j];
@@ -817,7 +891,9 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
         const int scanned = st->nS;
         __syncthreads();
         if (threadIdx.x == 0) { st->st_sap_batches++; st->st_sap_row_scans += scanned; st->st_total_row_scans += scanned; }
-        if (ctrl_sap_step(w, st, shd, shi)) return;
+        const int Y = ms_split(scanned, (n + 63) / 64, st->wide_blocks);
+        if (Y > 1) ctrl_ms_merge(M, w, st, Y);
+        if (ctrl_sap_step(w, st, shd, shi, reinterpret_cast<double*>(dyn))) return;
         // converged below the radius: accept one path per tree
         ctrl_ms_finish(w, st, dyn, dyn + n, use_lds, shd, shi, sh);
         if (st->error) return;
@@ -884,14 +960,19 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
         int rc = cfm_hip(hipHostMalloc((void**)&g_pinned, 256, hipHostMallocDefault));
         if (rc) return rc;
     }
+    int wide_blocks = (n + 15) / 16;        // one wave per row when everything bids
+    if (wide_blocks > 512) wide_blocks = 512;
+    if (wide_blocks < (n + 63) / 64) wide_blocks = (n + 63) / 64;
+    if (wide_blocks < 1) wide_blocks = 1;
     AsgState h;
     memset(&h, 0, sizeof(h));
+    h.wide_blocks = wide_blocks;
     h.mode = MODE_INIT; h.n = n;
     h.eps = g_params.eps0_frac; h.eps_last = g_params.eps_last_frac; h.theta = g_params.theta;
     h.stop_frac = g_params.stop_frac; h.round_cap = g_params.round_cap; h.arr_cap = g_params.arr_cap;
     h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
     h.sparse = (use_sparse && n <= SP_NMAX) ? 1 : 0;
-    h.handoff = g_params.handoff;
+    h.handoff = g_params.handoff; h.ms_q = g_params.ms_q;
     size_t wide_dyn = sizeof(double) * WT + 2 * sizeof(int) * WT;
     if (h.sparse) {
         const size_t need = sp_lds_bytes(n);
@@ -910,15 +991,12 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     const size_t n2 = (size_t)n * n;
     const int mm_blocks = (int)((n2 / 4 + 255) / 256 < 1024 ? (n2 / 4 + 255) / 256 + 1 : 1024);
     hipLaunchKernelGGL(asg_minmax, dim3(mm_blocks), dim3(256), 0, s, M, n2, w.st);
-    const size_t dyn = (n <= 6144) ? (size_t)2 * n * sizeof(int) : 16;
+    // path walks in LDS (2 n ints, n <= 6144); never less than the 1024 doubles of ctrl_radius
+    const size_t dyn = (n <= 6144) ? (size_t)2 * n * sizeof(int) : (size_t)CT * sizeof(double);
     hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, M, w, perm, certified, total_cost, stats);
     rc = cfm_status();
     if (rc) return rc;
 
-    int wide_blocks = (n + 15) / 16;        // one wave per row when everything bids
-    if (wide_blocks > 512) wide_blocks = 512;
-    if (wide_blocks < (n + 63) / 64) wide_blocks = (n + 63) / 64;
-    if (wide_blocks < 1) wide_blocks = 1;
     int pairs = 0;
     for (;;) {
         for (int c = 0; c < g_params.chunk; ++c) {

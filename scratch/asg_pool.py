@@ -9,8 +9,12 @@ import bench
 lib=_lib.load(); dev=_lib.require_gpu()
 nb=int(sys.argv[1]) if len(sys.argv)>1 else 8
 if len(sys.argv)>2: lib.cfm_assign_set_handoff(int(sys.argv[2]))
-if len(sys.argv)>3: lib.cfm_assign_set_params(0.0,0.0,0.0,-1.0,0,int(sys.argv[3]),0)
+stop=float(sys.argv[4]) if len(sys.argv)>4 else -1.0
+theta=float(sys.argv[5]) if len(sys.argv)>5 else 0.0
+elast=float(sys.argv[6]) if len(sys.argv)>6 else 0.0
+if len(sys.argv)>3: lib.cfm_assign_set_params(theta,0.0,elast,stop,0,int(sys.argv[3]),0)
 import cfm_oracle as oracle
+if os.environ.get('MSQ'): lib.cfm_assign_set_ms_quantile(float(os.environ['MSQ']))
 pool=bench.synth_batches(4096,784,nb,1000,dev)
 for k,(x0,x1) in enumerate(pool):
     M=ot.cost_matrix(x0,x1)
