@@ -129,6 +129,16 @@ struct AsgWs {
     double* cT;
 };
 
+// S[c] without dynamic indexing of the by-value kernel argument (which would push the whole
+// struct into scratch memory)
+__device__ __forceinline__ SList slist(const AsgWs& w, int c) {
+    SList L;
+    L.col = c ? w.S[1].col : w.S[0].col; L.row = c ? w.S[1].row : w.S[0].row;
+    L.base = c ? w.S[1].base : w.S[0].base; L.rj = c ? w.S[1].rj : w.S[0].rj;
+    L.root = c ? w.S[1].root : w.S[0].root;
+    return L;
+}
+
 #define MS_YMAX 4       // a big relax round is split over this many workgroups per column group
 #define MS_SPLIT_MIN 256 // ... when it has more than this many entries
 
@@ -209,12 +219,49 @@ __global__ __launch_bounds__(256) void asg_minmax(const float* __restrict__ M, s
 
 // --------------------------------------------------------- wide: auction -----
 #define WT 1024   // threads of the wide kernel (16 waves)
+#define WIDE_PLDS_MAX 8192   // prices are staged into LDS for the bid rounds up to this n
 // One wave per bidding row.  r_k = c_ik + p_k (fp64).  Top-2 over the row.
 struct Top2 { double b; double s; int j; };
 
+// branch-free (fp64 min / max are single instructions): same result as
+//   if (r < b) { s = b; b = r; j = jr; } else if (r < s) s = r;
 __device__ __forceinline__ void top2_push(Top2& t, double r, int j) {
-    if (r < t.b) { t.s = t.b; t.b = r; t.j = j; }
-    else if (r < t.s) { t.s = r; }
+    const double hi = fmax(t.b, r);
+    t.j = (r < t.b) ? j : t.j;
+    t.b = fmin(t.b, r);
+    t.s = fmin(t.s, hi);
+}
+
+// wave64 DPP reductions (row_shr within 16-lane rows, then row_bcast 15 / 31); result uniform
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int asg_dpp_i(int oldv, int v) {
+    return __builtin_amdgcn_update_dpp(oldv, v, CTRL, ROWMASK, 0xf, false);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double asg_dpp_d(double oldv, double v) {
+    const int lo = asg_dpp_i<CTRL, ROWMASK>(__double2loint(oldv), __double2loint(v));
+    const int hi = asg_dpp_i<CTRL, ROWMASK>(__double2hiint(oldv), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double asg_wave_min_d(double v) {
+    v = fmin(v, asg_dpp_d<0x111, 0xf>(INFINITY, v));
+    v = fmin(v, asg_dpp_d<0x112, 0xf>(INFINITY, v));
+    v = fmin(v, asg_dpp_d<0x114, 0xf>(INFINITY, v));
+    v = fmin(v, asg_dpp_d<0x118, 0xf>(INFINITY, v));
+    v = fmin(v, asg_dpp_d<0x142, 0xa>(INFINITY, v));
+    v = fmin(v, asg_dpp_d<0x143, 0xc>(INFINITY, v));
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int asg_wave_min_i(int v) {
+    v = min(v, asg_dpp_i<0x111, 0xf>(0x7fffffff, v));
+    v = min(v, asg_dpp_i<0x112, 0xf>(0x7fffffff, v));
+    v = min(v, asg_dpp_i<0x114, 0xf>(0x7fffffff, v));
+    v = min(v, asg_dpp_i<0x118, 0xf>(0x7fffffff, v));
+    v = min(v, asg_dpp_i<0x142, 0xa>(0x7fffffff, v));
+    v = min(v, asg_dpp_i<0x143, 0xc>(0x7fffffff, v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ Top2 top2_merge(const Top2& x, double b2, double s2, int j2) {
     Top2 o;
@@ -224,66 +271,156 @@ __device__ __forceinline__ Top2 top2_merge(const Top2& x, double b2, double s2, 
     return o;
 }
 
-__device__ void wide_bid(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
-                         int wave_gid, int n_waves) {
-    const int n = st->n, nU = st->nU;
-    const double eps = st->eps;
+// 64 columns of one row segment: top-2 of c + p with the prices in LDS
+__device__ __forceinline__ void bid_segment(Top2& best, const float4 (&c)[16], const double* ps, int jbase) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = jbase + 256 * k;
+        const double2 pa = *reinterpret_cast<const double2*>(ps + 256 * k);
+        const double2 pb = *reinterpret_cast<const double2*>(ps + 256 * k + 2);
+        top2_push(best, (double)c[k].x + pa.x, j + 0);
+        top2_push(best, (double)c[k].y + pa.y, j + 1);
+        top2_push(best, (double)c[k].z + pb.x, j + 2);
+        top2_push(best, (double)c[k].w + pb.y, j + 3);
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads from piling up
+    }
+}
+
+// wave top-2 -> bid (lane 0)
+__device__ __forceinline__ void bid_commit(const AsgWs& w, Top2 best, int i, double eps, const double* p_lds,
+                                           bool use_plds) {
+    const double bmin = asg_wave_min_d(best.b);
+    const int jwin = asg_wave_min_i(best.b == bmin ? best.j : 0x7fffffff);
+    const double rest = (best.b == bmin && best.j == jwin) ? best.s : best.b;
+    const double smin = asg_wave_min_d(rest);       // the best of everything but (bmin, jwin)
+    if ((threadIdx.x & 63) == 0) {
+        const double incr = (smin - bmin) + eps;          // >= eps >= 0
+        const double bv = (use_plds ? p_lds[jwin] : w.p[jwin]) + incr;
+        w.bidcol[i] = jwin;
+        w.bidval[i] = bv;
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint((float)bv) << 32) | (unsigned)(i + 1);
+        atomicMax(&w.packed[jwin], key);
+    }
+}
+
+// One wave per bidding row.  `pre_a` is the (speculatively loaded) match of this wave's row,
+// pst* the thread's share of the prices on their way into LDS: the bidder's first row segment
+// is requested BEFORE the prices are written to LDS and the workgroup barrier, so the staging
+// hides behind the row's latency.
+__device__ __forceinline__ void wide_bid(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+                         int wave_gid, int n_waves, int pre_a, bool stage_p, int n_host, int nU, double eps,
+                         double2 pst0, double2 pst1, double2 pst2, double2 pst3, long long t_entry) {
+    extern __shared__ __attribute__((aligned(16))) char wide_lds_bid[];   // = the kernel's dynamic LDS
+    double* p_lds = reinterpret_cast<double*>(wide_lds_bid);
+    const int n = n_host;
     const int lane = threadIdx.x & 63;
     const bool vec = ((n & 3) == 0);
-    for (int t = wave_gid; t < nU; t += n_waves) {
-        const int i = w.listA[t];
+    const bool fast = stage_p && (n & 4095) == 0;
+#ifdef BID_PROFILE
+    long long tq[6]; tq[0] = clock64(); tq[1] = tq[2] = tq[3] = tq[4] = tq[0];
+#endif
+    // No bidder list: wave <-> row, a row bids iff it is unmatched (pre_a = a[wave_gid] came with
+    // the state block).  Rows beyond the first of a wave (n > number of waves) are checked as they come.
+    int i = wave_gid;
+    bool bids = (i < n) && (pre_a < 0);
+    float4 c[16];
+    if (fast && bids) {
+        const float* rs = M + (size_t)i * n + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = *reinterpret_cast<const float4*>(rs + 256 * k);
+    }
+    if (stage_p) {
+        const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
+        if (j0 < n_host) *reinterpret_cast<double2*>(p_lds + j0) = pst0;
+        if (j1 < n_host) *reinterpret_cast<double2*>(p_lds + j1) = pst1;
+        if (j2 < n_host) *reinterpret_cast<double2*>(p_lds + j2) = pst2;
+        if (j3 < n_host) *reinterpret_cast<double2*>(p_lds + j3) = pst3;
+#ifdef BID_PROFILE
+        tq[1] = clock64();
+#endif
+        __syncthreads();
+    }
+#ifdef BID_PROFILE
+    tq[2] = clock64();
+#endif
+    if (fast) {
+        while (i < n) {
+            if (bids) {
+                Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
+#ifdef BID_PROFILE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                tq[3] = clock64();
+#endif
+                bid_segment(best, c, p_lds + lane * 4, lane * 4);
+#ifdef BID_PROFILE
+                tq[4] = clock64();
+#endif
+                for (int seg = 4096; seg < n; seg += 4096) {
+                    const float* rs = M + (size_t)i * n + seg + lane * 4;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) c[k] = *reinterpret_cast<const float4*>(rs + 256 * k);
+                    bid_segment(best, c, p_lds + seg + lane * 4, seg + lane * 4);
+                }
+                bid_commit(w, best, i, eps, p_lds, true);
+#ifdef BID_PROFILE
+                if (wave_gid == 0 && lane == 0 && nU < 600) {
+                    long long* out = reinterpret_cast<long long*>(reinterpret_cast<char*>(w.st) + 400);
+                    const long long t5 = clock64();
+                    out[0] += tq[0] - t_entry; out[1] += tq[1] - tq[0]; out[2] += tq[2] - tq[1]; out[3] += tq[3] - tq[2];
+                    out[4] += tq[4] - tq[3]; out[5] += t5 - tq[4]; out[6] += 1;
+                }
+#endif
+            }
+            i += n_waves;
+            bids = (i < n) && (w.a[i] < 0);
+            if (bids) {
+                const float* rs = M + (size_t)i * n + lane * 4;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) c[k] = *reinterpret_cast<const float4*>(rs + 256 * k);
+            }
+        }
+        return;
+    }
+    for (; i < n; i += n_waves) {
+        if (!((i == wave_gid) ? (pre_a < 0) : (w.a[i] < 0))) continue;
         const float* row = M + (size_t)i * n;
         Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
         if (vec) {
             for (int j0 = lane * 4; j0 < n; j0 += 1024) {
                 // 4 float4 in flight per lane per trip
-                float4 c[4]; double2 pa[4], pb[4];
+                float4 c4[4]; double2 pa[4], pb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int j = j0 + 256 * k;
                     if (j < n) {
-                        c[k] = *reinterpret_cast<const float4*>(row + j);
-                        pa[k] = *reinterpret_cast<const double2*>(w.p + j);
-                        pb[k] = *reinterpret_cast<const double2*>(w.p + j + 2);
+                        c4[k] = *reinterpret_cast<const float4*>(row + j);
+                        pa[k] = stage_p ? *reinterpret_cast<const double2*>(p_lds + j) : *reinterpret_cast<const double2*>(w.p + j);
+                        pb[k] = stage_p ? *reinterpret_cast<const double2*>(p_lds + j + 2) : *reinterpret_cast<const double2*>(w.p + j + 2);
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int j = j0 + 256 * k;
                     if (j < n) {
-                        top2_push(best, (double)c[k].x + pa[k].x, j + 0);
-                        top2_push(best, (double)c[k].y + pa[k].y, j + 1);
-                        top2_push(best, (double)c[k].z + pb[k].x, j + 2);
-                        top2_push(best, (double)c[k].w + pb[k].y, j + 3);
+                        top2_push(best, (double)c4[k].x + pa[k].x, j + 0);
+                        top2_push(best, (double)c4[k].y + pa[k].y, j + 1);
+                        top2_push(best, (double)c4[k].z + pb[k].x, j + 2);
+                        top2_push(best, (double)c4[k].w + pb[k].y, j + 3);
                     }
                 }
             }
         } else {
             for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + w.p[j], j);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double b2 = __shfl_xor(best.b, o, 64);
-            const double s2 = __shfl_xor(best.s, o, 64);
-            const int j2 = __shfl_xor(best.j, o, 64);
-            best = top2_merge(best, b2, s2, j2);
-        }
-        if (lane == 0) {
-            const double incr = (best.s - best.b) + eps;          // >= eps >= 0
-            const double bv = w.p[best.j] + incr;
-            w.bidcol[i] = best.j;
-            w.bidval[i] = bv;
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint((float)bv) << 32) | (unsigned)(i + 1);
-            atomicMax(&w.packed[best.j], key);
-        }
+        bid_commit(w, best, i, eps, p_lds, stage_p);
     }
 }
 
 // ------------------------------------------------------------ wide: SAP ------
 // Row minima u_i = min_k (c_ik + p_k), one wave per row: for every row (before the column
 // reduction) or for the free rows of the next multi-source phase.  Result in bidval[row].
-__device__ void wide_umin(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+__device__ __forceinline__ void wide_umin(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
                           int wave_gid, int n_waves, bool roots_only) {
     const int n = st->n;
     const int cnt = roots_only ? st->nF : n;
@@ -326,7 +463,7 @@ __device__ void wide_umin(const float* __restrict__ M, const AsgWs& w, const Asg
 // column k is still not cheaper than any row's current minimum.  No u_i changes, every matched
 // edge stays tight, the dual objective rises by the price drop.  One workgroup per column
 // (strided reads: 64 B sector per row, only nFC columns).
-__device__ void wide_colred(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+__device__ __forceinline__ void wide_colred(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
                             double* sh_d) {
     const int n = st->n, nFC = st->nFC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -369,11 +506,11 @@ __device__ __forceinline__ int ms_split(int nS, int n_groups, int blocks) {
 // appends improved assigned columns to the NEXT list (one atomic per append).  A big round
 // is split over Y workgroups per column group (every Y-th slice of the list each); they write
 // per-column partial minima and asg_ctrl merges them (ctrl_ms_merge).
-__device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState* st,
+__device__ __forceinline__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState* st,
                            double* sh_d, int* sh_i, int* sh_r) {
     const int n = st->n, nS = st->nS, cur = st->cur;
     const double dfree = st->dfree;
-    const SList L = w.S[cur], Nx = w.S[cur ^ 1];
+    const SList L = slist(w, cur), Nx = slist(w, cur ^ 1);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_groups = (n + 63) / 64;
     constexpr int Q = 8, NW = WT / 64;
@@ -431,7 +568,7 @@ __device__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState
 }
 
 // ------------------------------------------------------------ wide: cert -----
-__device__ void wide_cert(const float* __restrict__ M, const AsgWs& w, AsgState* st, int wave_gid,
+__device__ __forceinline__ void wide_cert(const float* __restrict__ M, const AsgWs& w, AsgState* st, int wave_gid,
                           int n_waves) {
     const int n = st->n;
     const int lane = threadIdx.x & 63;
@@ -456,19 +593,41 @@ __device__ void wide_cert(const float* __restrict__ M, const AsgWs& w, AsgState*
 
 #include "assign_sparse.h"
 
-__global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgWs w) {
+__global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgWs w, int n_host) {
     extern __shared__ __attribute__((aligned(16))) char wide_lds[];   // modes are exclusive
     double* sh_d = reinterpret_cast<double*>(wide_lds);
     int* sh_i = reinterpret_cast<int*>(wide_lds + sizeof(double) * WT);
     int* sh_r = sh_i + WT;
     AsgState* st = w.st;
-    const int mode = st->mode;
-    if (mode == MODE_DONE || st->error) return;
+    const long long t_kernel_entry = clock64();
     // consecutive work items go to different workgroups (different CUs)
     const int wave_gid = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
     const int n_waves = gridDim.x * (WT / 64);
-    if (mode == MODE_AUCTION || mode == MODE_ARR) wide_bid(M, w, st, wave_gid, n_waves);
-    else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i, sh_r);
+    // Every kernel of the state machine starts cold (the previous one ran elsewhere): each
+    // dependent global access is a hop of its own.  Whether this wave's row is unmatched (= bids)
+    // is loaded speculatively TOGETHER with the state block (n comes from the host), so a bid
+    // round is {state, match, prices} -> row instead of state -> list -> {row, prices}.
+    // The prices (all of them are needed by every bidder) are staged into LDS the same way, so
+    // a bidder's row can be requested in one go.
+    const bool stage_p = (n_host <= WIDE_PLDS_MAX) && ((n_host & 3) == 0);
+    double2 pst0, pst1, pst2, pst3;     // WIDE_PLDS_MAX / (2 * WT) = 4 double2 per thread
+    {
+        const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
+        const int nn = stage_p ? n_host : 0;
+        pst0 = *reinterpret_cast<const double2*>(w.p + (j0 < nn ? j0 : 0));
+        pst1 = *reinterpret_cast<const double2*>(w.p + (j1 < nn ? j1 : 0));
+        pst2 = *reinterpret_cast<const double2*>(w.p + (j2 < nn ? j2 : 0));
+        pst3 = *reinterpret_cast<const double2*>(w.p + (j3 < nn ? j3 : 0));
+    }
+    int pre_i = (wave_gid < n_host) ? w.a[wave_gid] : 0;
+    int mode = st->mode;
+    int st_nU = st->nU;
+    double st_eps = st->eps;
+    asm volatile("" : "+v"(pre_i), "+v"(pst0.x), "+v"(pst1.x), "+v"(pst2.x), "+v"(pst3.x) : "s"(mode), "s"(st_nU), "s"(st_eps) : "memory");   // all of it in flight
+    if (mode == MODE_DONE || st->error) return;
+    if (mode == MODE_AUCTION || mode == MODE_ARR) {
+        wide_bid(M, w, st, wave_gid, n_waves, pre_i, stage_p, n_host, st_nU, st_eps, pst0, pst1, pst2, pst3, t_kernel_entry);
+    } else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i, sh_r);
     else if (mode == MODE_UMIN) wide_umin(M, w, st, wave_gid, n_waves, false);
     else if (mode == MODE_ROOTMIN) wide_umin(M, w, st, wave_gid, n_waves, true);
     else if (mode == MODE_COLRED) wide_colred(M, w, st, sh_d);
@@ -526,38 +685,51 @@ __device__ void block_argmin(double v, int idx, double* out_v, int* out_i, doubl
 __device__ void ctrl_reset_assignment(const AsgWs& w, AsgState* st) {
     const int n = st->n;
     for (int i = threadIdx.x; i < n; i += CT) {
-        w.a[i] = -1; w.owner[i] = -1; w.listA[i] = i; w.packed[i] = 0ull;
+        w.a[i] = -1; w.owner[i] = -1; w.packed[i] = 0ull;
     }
     if (threadIdx.x == 0) { st->nU = n; st->round = 0; }
     __syncthreads();
 }
 
-// apply winners, rebuild the unassigned list in ascending row order
-__device__ void ctrl_award(const AsgWs& w, AsgState* st, int* sh) {
-    const int n = st->n;
-    for (int j = threadIdx.x; j < n; j += CT) {
-        const unsigned long long key = w.packed[j];
-        if (key != 0ull) {
-            const int i = (int)(key & 0xffffffffull) - 1;
-            const int prev = w.owner[j];
-            w.p[j] = w.bidval[i];
-            w.owner[j] = i;
-            w.a[i] = j;
-            if (prev >= 0) w.a[prev] = -1;
-            w.packed[j] = 0ull;
+// Block sum of one int per thread.
+__device__ int block_sum_i(int v, int* sh /*>=17*/) {
+    v = wave_sum_i(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int q = 0; q < CT / 64; ++q) tot += sh[q];
+    __syncthreads();
+    return tot;
+}
+
+// Apply the winning bids.  There is no bidder list (a row bids iff it is unmatched), so all that
+// is left to maintain is the number of unmatched rows: it drops by one for every object that was
+// free before.  Two global hops: {bids, owners} of the thread's objects, then the winners' exact bids.
+__device__ void ctrl_award(const AsgWs& w, AsgState* st, int* sh, int n, int nU_old) {
+    int newly = 0;
+    for (int j0 = threadIdx.x; j0 < n; j0 += 4 * CT) {
+        unsigned long long key[4]; int ow[4]; double bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q * CT;
+            const bool ok = j < n;
+            key[q] = ok ? w.packed[j] : 0ull; ow[q] = ok ? w.owner[j] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = (key[q] != 0ull) ? w.bidval[(int)(key[q] & 0xffffffffull) - 1] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (key[q] != 0ull) {
+                const int j = j0 + q * CT;
+                const int i = (int)(key[q] & 0xffffffffull) - 1;
+                w.p[j] = bv[q]; w.owner[j] = i; w.a[i] = j; w.packed[j] = 0ull;
+                if (ow[q] >= 0) w.a[ow[q]] = -1; else ++newly;
+            }
         }
     }
-    __syncthreads();
-    int base = 0;
-    for (int i0 = 0; i0 < n; i0 += CT) {
-        const int i = i0 + threadIdx.x;
-        const int f = (i < n && w.a[i] < 0) ? 1 : 0;
-        int tot;
-        const int off = block_scan_excl(f, &tot, sh);
-        if (f) w.listA[base + off] = i;
-        base += tot;
-    }
-    if (threadIdx.x == 0) st->nU = base;
+    const int tot = block_sum_i(newly, sh);
+    if (threadIdx.x == 0) st->nU = nU_old - tot;
     __syncthreads();
 }
 
@@ -607,7 +779,7 @@ __device__ void ctrl_radius(const AsgWs& w, AsgState* st, double* shd, int* shi,
 // Start a multi-source phase: labels unset, one root entry per free row (u_r in bidval[]).
 __device__ void ctrl_ms_begin(const AsgWs& w, AsgState* st) {
     const int n = st->n, nF = st->nF, cur = st->cur;
-    const SList L = w.S[cur];
+    const SList L = slist(w, cur);
     __syncthreads();
     for (int k = threadIdx.x; k < n; k += CT) { w.dist[k] = INFINITY; w.pred[k] = -1; }
     for (int t = threadIdx.x; t < nF; t += CT) {
@@ -628,7 +800,7 @@ __device__ void ctrl_ms_begin(const AsgWs& w, AsgState* st) {
 __device__ void ctrl_ms_merge(const float* __restrict__ M, const AsgWs& w, AsgState* st, int Y) {
     const int n = st->n, cur = st->cur;
     const double dfree = st->dfree;
-    const SList Nx = w.S[cur ^ 1];
+    const SList Nx = slist(w, cur ^ 1);
     for (int k = threadIdx.x; k < n; k += CT) {
         double best = w.part_d[k]; int bi = w.part_i[k], br = w.part_r[k];
         for (int y = 1; y < Y; ++y) {
@@ -653,7 +825,7 @@ __device__ bool ctrl_sap_step(const AsgWs& w, AsgState* st, double* shd, int* sh
     ctrl_radius(w, st, shd, shi, scratch);
     const double dfree = st->dfree;
     const int nN = st->nN, cur = st->cur;
-    const SList Nx = w.S[cur ^ 1];
+    const SList Nx = slist(w, cur ^ 1);
     int any = 0;
     for (int t = threadIdx.x; t < nN; t += CT) any |= (Nx.base[t] < dfree) ? 1 : 0;
     any = __syncthreads_or(any);
@@ -815,7 +987,7 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
         const int arr_round = st->arr_round, arr_cap = st->arr_cap;
         const double eps_cur = st->eps, eps_last = st->eps_last, theta = st->theta;
         __syncthreads();
-        ctrl_award(w, st, sh);
+        ctrl_award(w, st, sh, n, bidders);
         const int nU = st->nU;
         __syncthreads();
         if (threadIdx.x == 0) st->st_total_row_scans += bidders;
@@ -845,7 +1017,18 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
         }
         if (arr_round + 1 < arr_cap) return;
         // -> phase C: snapshot the free rows and the free columns, then column reduction
-        for (int t = threadIdx.x; t < nU; t += CT) w.listF[t] = w.listA[t];
+        {
+            int baseR = 0;
+            for (int i0 = 0; i0 < n; i0 += CT) {
+                const int i = i0 + threadIdx.x;
+                const int f = (i < n && w.a[i] < 0) ? 1 : 0;
+                int tot;
+                const int off = block_scan_excl(f, &tot, sh);
+                if (f) w.listF[baseR + off] = i;
+                baseR += tot;
+            }
+            if (baseR != nU && threadIdx.x == 0) st->error = 4;
+        }
         {
             int base = 0;
             for (int k0 = 0; k0 < n; k0 += CT) {
@@ -974,6 +1157,7 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     h.sparse = (use_sparse && n <= SP_NMAX) ? 1 : 0;
     h.handoff = g_params.handoff; h.ms_q = g_params.ms_q;
     size_t wide_dyn = sizeof(double) * WT + 2 * sizeof(int) * WT;
+    if (n <= WIDE_PLDS_MAX && (size_t)n * sizeof(double) > wide_dyn) wide_dyn = (size_t)n * sizeof(double);
     if (h.sparse) {
         const size_t need = sp_lds_bytes(n);
         if (need > wide_dyn) wide_dyn = need;
@@ -984,7 +1168,7 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
             raised = (e == hipSuccess) ? 1 : -1;
             (void)hipGetLastError();
         }
-        if (raised < 0 && wide_dyn > 64 * 1024) { h.sparse = 0; wide_dyn = sizeof(double) * WT + 2 * sizeof(int) * WT; }
+        if (raised < 0 && wide_dyn > 64 * 1024) { h.sparse = 0; wide_dyn = 64 * 1024; }
     }
     int rc = cfm_hip(hipMemcpyAsync(w.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
     if (rc) return rc;
@@ -999,11 +1183,13 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
 
     int pairs = 0;
     for (;;) {
-        for (int c = 0; c < g_params.chunk; ++c) {
-            hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), wide_dyn, s, M, w);
+        // a typical solve needs 150 - 300 pairs: enqueue most of them before the first poll
+        const int chunk = (pairs == 0 && n >= 1024) ? 3 * g_params.chunk : g_params.chunk;
+        for (int c = 0; c < chunk; ++c) {
+            hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), wide_dyn, s, M, w, n);
             hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, M, w, perm, certified, total_cost, stats);
         }
-        pairs += g_params.chunk;
+        pairs += chunk;
         rc = cfm_status();
         if (rc) return rc;
         rc = cfm_hip(hipMemcpyAsync(g_pinned, w.st, 64, hipMemcpyDeviceToHost, s));

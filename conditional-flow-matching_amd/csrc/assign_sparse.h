@@ -96,7 +96,7 @@ __device__ __forceinline__ int sp_count(const float* __restrict__ r, int nt, flo
 // lives in the wave's LDS strip (lane-major: conflict free).  A threshold tau with
 // count(r < tau) in [32, 64] is found by bisection; members are r < tau, and every
 // non-member satisfies (c + p) >= rowmin + tau * (1 - 2^-22) =: T.
-__device__ void wide_build(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+__device__ __forceinline__ void wide_build(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
                            char* lds) {
     const int n = st->n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -522,7 +522,7 @@ __device__ __forceinline__ double sp_collect(const SpL& L, int plcur, double dfr
 #define SP_TICK(slot) do { } while (0)
 #endif
 
-__device__ void sp_solver(const float* __restrict__ M, const AsgWs& w, AsgState* st, char* lds) {
+__device__ __forceinline__ void sp_solver(const float* __restrict__ M, const AsgWs& w, AsgState* st, char* lds) {
 #ifdef SP_PROFILE
     long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long fbv[6] = {0, 0, 0, 0, 0, 0};
