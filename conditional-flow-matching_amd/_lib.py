@@ -18,7 +18,7 @@ _lock = threading.Lock()
 _lib = None
 
 # ops (include/cfm_gfx950.h)
-OP_SINKHORN, OP_ASSIGN, OP_SAMPLE_DENSE, OP_MLP, OP_ODE = 1, 2, 3, 4, 5
+OP_SINKHORN, OP_ASSIGN, OP_SAMPLE_DENSE, OP_MLP, OP_ODE, OP_UNBALANCED = 1, 2, 3, 4, 5, 6
 VARIANT_ICFM, VARIANT_SB, VARIANT_TARGET, VARIANT_VP = 0, 1, 2, 3
 
 ERRORS = {
@@ -50,6 +50,8 @@ SIGNATURES = {
     "cfm_sinkhorn_potentials_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "cfm_sinkhorn_plan_f64": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),
     "cfm_sinkhorn_cost_f64": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),
+    "cfm_unbalanced_sinkhorn_f64": (_i, [_vp, _i, _i, _d, _d, _i, _d, _vp, _vp, _vp, _vp]),
+    "cfm_partial_entropic_f64": (_i, [_vp, _i, _i, _d, _d, _i, _d, _vp, _vp, _vp, _vp]),
     "cfm_assign_exact_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_perm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cfm_plan_sample_dense": (_i, [_vp, _i, _i, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

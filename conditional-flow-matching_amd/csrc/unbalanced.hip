@@ -1,0 +1,443 @@
+// unbalanced.hip — OTPlanSampler(method="unbalanced" | "partial") on gfx950.
+//
+// Replaces, for uniform marginals a = 1/B0, b = 1/B1 (torchcfm/optimal_transport.py:79),
+//   pot.unbalanced.sinkhorn_knopp_unbalanced(a, b, M, reg, reg_m)     optimal_transport.py:52-53,87
+//   pot.partial.entropic_partial_wasserstein(a, b, M, reg)            optimal_transport.py:54-55,87
+// Both are kernel-space (not log-domain) float64 algorithms in POT, and the reference's wrapper
+// semantics depend on exactly that (underflow of exp(-M/reg) -> "numerical errors" -> previous
+// iterate / uniform-plan fallback, :88-96), so they are kept in kernel space here: the Gibbs
+// kernel K = exp(M / -reg) is built ONCE in fp64 (128 MiB at B = 4096: nothing on a 288 GB
+// part) and every iteration is two streaming fp64 passes over it,
+//     rowdot:  y_i = sum_j K_ij x_j      one wave per row, 16 B loads
+//     coldot:  z_j = sum_i K_ij w_i      lane <-> column strips + finalize
+// i.e. HBM-bound at 2 * 8 * B0 * B1 bytes per iteration.
+//
+// Unbalanced follows the loop of the in-repo statement of POT's algorithm
+// (runner/src/models/components/sinkhorn_knopp_unbalanced.py:134-186 with reg_m_1 = reg_m_2):
+//     u = (a / K v)^fi ; v = (b / K^T u)^fi ; fi = reg_m / (reg_m + reg)
+//     numerical error (K^T u == 0, nan / inf) -> previous (u, v), stop
+//     every 10th iteration: err = (|u-u'|_inf / max(|u|_inf,|u'|_inf,1) + same for v) / 2 <= stopThr
+// Partial is POT's Dykstra loop; its three B0 x B1 correction matrices q1, q2, q3 are constant
+// along rows / columns / everywhere (q1 <- q1 * Kprev / K1 = 1 / r_i, ...), so the iteration is
+// carried on two scaling vectors and a scalar: K = diag(alpha) K0 diag(beta).
+#include "cfm_common.h"
+
+#define UB_NCHUNK_MAX 64
+
+struct UbState {
+    int done, iters, status, final_idx;   // status: 0 ok, 1 numerical error (previous iterate returned)
+    int flag_bad, n_zero, n_nonfinite, pad;
+    double err;
+    double sumK;                // sum of the Gibbs kernel (partial: K *= m / sumK)
+    double sigma;               // partial: q3
+    double total;               // partial: sum_j beta2_j * coldot_j
+    unsigned long long mx[6];   // ordered-double maxima: |u-u'|, |u|, |u'|, |v-v'|, |v|, |v'|
+    double err2;                // partial: || Kprev - K ||_F^2
+    double fold;                // partial: scalar factor sigma * s on its way into alpha2
+};
+
+struct UbWs {
+    UbState* st;
+    double* U[2];     // unbalanced: u ping-pong   | partial: alpha, alpha2
+    double* V[2];     // unbalanced: v ping-pong   | partial: beta, beta2
+    double* rho;      // partial q1 (rows)
+    double* kappa;    // partial q2 (cols)
+    double* rowacc;   // rowdot result
+    double* colacc;   // coldot result
+    double* part;     // [nchunk][B1]
+};
+
+static inline int ub_nchunk(int B0, int B1) {
+    int tiles = (B1 + 255) / 256;
+    int n = (1024 + tiles - 1) / tiles;
+    if (n > UB_NCHUNK_MAX) n = UB_NCHUNK_MAX;
+    int maxn = (B0 + 31) / 32;
+    if (n > maxn) n = maxn;
+    return n < 1 ? 1 : n;
+}
+
+static inline size_t ub_ws_bytes(int B0, int B1) {
+    size_t nchunk = ub_nchunk(B0, B1);
+    return 512 + sizeof(double) * (4 * (size_t)B0 + 5 * (size_t)B1 + nchunk * (size_t)B1) + 256;
+}
+
+static inline UbWs ub_carve(void* ws, int B0, int B1) {
+    UbWs w; char* q = (char*)ws;
+    w.st = (UbState*)q; q += 512;
+    w.U[0] = (double*)q; q += 8 * (size_t)B0;
+    w.U[1] = (double*)q; q += 8 * (size_t)B0;
+    w.rho = (double*)q; q += 8 * (size_t)B0;
+    w.rowacc = (double*)q; q += 8 * (size_t)B0;
+    w.V[0] = (double*)q; q += 8 * (size_t)B1;
+    w.V[1] = (double*)q; q += 8 * (size_t)B1;
+    w.kappa = (double*)q; q += 8 * (size_t)B1;
+    w.colacc = (double*)q; q += 8 * (size_t)B1;
+    w.part = (double*)q;
+    return w;
+}
+
+extern "C" size_t cfm_ub_ws_bytes_internal(int B0, int B1) { return ub_ws_bytes(B0, B1); }
+
+// ---------------------------------------------------------------- Gibbs kernel
+// K = exp(M / -reg) in fp64 (np.divide(M, -reg, out=K); np.exp(K, out=K), runner/...:139-141),
+// its sum, and how many entries underflowed to 0 / are not finite.
+__global__ __launch_bounds__(256) void ub_gibbs(const float* __restrict__ M, size_t n, double neg_reg,
+                                                double* __restrict__ K, UbState* st) {
+    double acc = 0.0; int nz = 0, nf = 0;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const double v = exp((double)M[k] / neg_reg);
+        K[k] = v;
+        acc += v;
+        nz += (v == 0.0) ? 1 : 0;
+        nf += (isfinite(v)) ? 0 : 1;
+    }
+    acc = wave_sum_d(acc); nz = wave_sum_i(nz); nf = wave_sum_i(nf);
+    __shared__ double sd[4]; __shared__ int sz[4], sf[4];
+    if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = acc; sz[threadIdx.x >> 6] = nz; sf[threadIdx.x >> 6] = nf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&st->sumK, sd[0] + sd[1] + sd[2] + sd[3]);
+        const int z = sz[0] + sz[1] + sz[2] + sz[3], f = sf[0] + sf[1] + sf[2] + sf[3];
+        if (z) atomicAdd(&st->n_zero, z);
+        if (f) atomicAdd(&st->n_nonfinite, f);
+    }
+}
+
+__global__ void ub_state_init(UbState* st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        st->done = 0; st->iters = 0; st->status = 0; st->final_idx = 0;
+        st->flag_bad = 0; st->n_zero = 0; st->n_nonfinite = 0;
+        st->err = 1.0; st->sumK = 0.0; st->sigma = 1.0; st->total = 0.0; st->err2 = 0.0;
+        for (int k = 0; k < 6; ++k) st->mx[k] = 0ull;
+    }
+}
+
+// ---------------------------------------------------------------- streaming passes
+// y_i = scale_i * sum_j K_ij x_j  (scale may be null).  One wave per row.
+__global__ __launch_bounds__(256) void ub_rowdot(const double* __restrict__ K, int B0, int B1,
+                                                 const UbState* __restrict__ st,
+                                                 const double* __restrict__ x,
+                                                 double* __restrict__ y) {
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= B0) return;
+    const double* row = K + (size_t)r * B1;
+    double acc = 0.0;
+    if ((B1 & 1) == 0) {
+        for (int j = lane * 2; j < B1; j += 128 * 4) {
+            double2 k2[4], x2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jj = j + 128 * q;
+                k2[q] = (jj < B1) ? *reinterpret_cast<const double2*>(row + jj) : make_double2(0.0, 0.0);
+                x2[q] = (jj < B1) ? *reinterpret_cast<const double2*>(x + jj) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += k2[q].x * x2[q].x + k2[q].y * x2[q].y;
+        }
+    } else {
+        for (int j = lane; j < B1; j += 64) acc += row[j] * x[j];
+    }
+    acc = wave_sum_d(acc);
+    if (lane == 0) y[r] = acc;
+}
+
+// partial column sums over a strip of rows: part[chunk][j] = sum_{i in strip} w_i K_ij
+__global__ __launch_bounds__(256) void ub_coldot(const double* __restrict__ K, int B0, int B1,
+                                                 const UbState* __restrict__ st,
+                                                 const double* __restrict__ w,
+                                                 double* __restrict__ part, int rows_per_chunk) {
+    if (st->done) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(B0, r0 + rows_per_chunk);
+    double acc = 0.0;
+    if (j < B1) {
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            double k8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) k8[q] = K[(size_t)(r + q) * B1 + j];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += k8[q] * w[r + q];
+        }
+        for (; r < r1; ++r) acc += K[(size_t)r * B1 + j] * w[r];
+        part[(size_t)blockIdx.y * B1 + j] = acc;
+    }
+}
+
+__device__ __forceinline__ void ub_atomic_max_abs(unsigned long long* slot, double v) {
+    // |v| >= 0: the bit pattern orders like the value; NaN never wins (flagged separately)
+    atomicMax(slot, (unsigned long long)__double_as_longlong(fabs(v)));
+}
+
+// ---------------------------------------------------------------- unbalanced
+// u_new = (a / Kv)^fi  from rowacc = K v
+__global__ void ub_u_update(int B0, double a, double fi, UbState* st, const double* __restrict__ Kv,
+                            const double* __restrict__ uprev, double* __restrict__ unew, int check) {
+    if (st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B0) return;
+    const double u = pow(a / Kv[i], fi);
+    unew[i] = u;
+    if (isnan(u) || isinf(u)) atomicOr(&st->flag_bad, 1);
+    if (check) {
+        const double up = uprev[i];
+        ub_atomic_max_abs(&st->mx[0], u - up); ub_atomic_max_abs(&st->mx[1], u); ub_atomic_max_abs(&st->mx[2], up);
+    }
+}
+
+// Ktu_j = sum of strips; v_new = (b / Ktu)^fi
+__global__ void ub_v_update(int B1, int nchunk, double b, double fi, UbState* st,
+                            const double* __restrict__ part, const double* __restrict__ vprev,
+                            double* __restrict__ vnew, int check) {
+    if (st->done) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B1) return;
+    double ktu = 0.0;
+    for (int c = 0; c < nchunk; ++c) ktu += part[(size_t)c * B1 + j];
+    const double v = pow(b / ktu, fi);
+    vnew[j] = v;
+    if (ktu == 0.0 || isnan(v) || isinf(v)) atomicOr(&st->flag_bad, 1);
+    if (check) {
+        const double vp = vprev[j];
+        ub_atomic_max_abs(&st->mx[3], v - vp); ub_atomic_max_abs(&st->mx[4], v); ub_atomic_max_abs(&st->mx[5], vp);
+    }
+}
+
+// loop control of iteration `cpt` (runner/...:150-186): numerical error -> previous iterate;
+// every 10th iteration the error; `while err > stopThr and cpt < numItermax`.
+__global__ void ub_decide(UbState* st, int cpt, int max_iter, double stop_thr, int check) {
+    if (st->done) return;
+    if (st->flag_bad) {                      // u, v = uprev, vprev; break
+        st->status = 1; st->final_idx = cpt & 1; st->iters = cpt; st->done = 1;
+        return;
+    }
+    if (check) {
+        const double du = __longlong_as_double((long long)st->mx[0]), mu = __longlong_as_double((long long)st->mx[1]),
+                     mup = __longlong_as_double((long long)st->mx[2]);
+        const double dv = __longlong_as_double((long long)st->mx[3]), mv = __longlong_as_double((long long)st->mx[4]),
+                     mvp = __longlong_as_double((long long)st->mx[5]);
+        const double err_u = du / fmax(fmax(mu, mup), 1.0);
+        const double err_v = dv / fmax(fmax(mv, mvp), 1.0);
+        st->err = 0.5 * (err_u + err_v);
+        for (int k = 0; k < 6; ++k) st->mx[k] = 0ull;
+    }
+    const int next = cpt + 1;
+    st->iters = next; st->final_idx = next & 1;
+    if (!(st->err > stop_thr) || next >= max_iter) st->done = 1;
+}
+
+// plan = u_i K_ij v_j  (in place)
+__global__ __launch_bounds__(256) void ub_plan(double* __restrict__ K, int B0, int B1,
+                                               const UbState* __restrict__ st,
+                                               const double* __restrict__ u0, const double* __restrict__ u1,
+                                               const double* __restrict__ v0, const double* __restrict__ v1,
+                                               int nan_if_zero) {
+    const double* u = st->final_idx ? u1 : u0;
+    const double* v = st->final_idx ? v1 : v0;
+    const bool poison = nan_if_zero && (st->n_zero > 0 || st->n_nonfinite > 0);
+    const size_t n = (size_t)B0 * B1;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const int i = (int)(k / B1), j = (int)(k - (size_t)i * B1);
+        K[k] = poison ? __longlong_as_double(0x7ff8000000000000ll) : u[i] * K[k] * v[j];
+    }
+}
+
+__global__ void ub_fill(double* x, int n, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+__global__ void ub_info(const UbState* st, int* info) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && info) {
+        info[0] = st->iters; info[1] = st->status; info[2] = st->n_zero; info[3] = st->n_nonfinite;
+    }
+}
+
+extern "C" int cfm_unbalanced_sinkhorn_f64(const float* M, int B0, int B1, double reg, double reg_m,
+                                           int max_iter, double stop_thr, double* plan, int* info,
+                                           void* ws, void* stream) {
+    if (!M || !plan || !ws || B0 <= 0 || B1 <= 0 || !(reg > 0.0) || !(reg_m > 0.0) || max_iter < 0)
+        return CFM_EINVAL;
+    if (((uintptr_t)ws & 15) != 0 || ((uintptr_t)plan & 15) != 0) return CFM_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    UbWs w = ub_carve(ws, B0, B1);
+    const size_t n = (size_t)B0 * B1;
+    const int nchunk = ub_nchunk(B0, B1);
+    const int rows_per_chunk = (B0 + nchunk - 1) / nchunk;
+    const double a = 1.0 / B0, b = 1.0 / B1, fi = reg_m / (reg_m + reg);
+    hipLaunchKernelGGL(ub_state_init, dim3(1), dim3(64), 0, s, w.st);
+    hipLaunchKernelGGL(ub_gibbs, dim3(2048), dim3(256), 0, s, M, n, -reg, plan, w.st);
+    hipLaunchKernelGGL(ub_fill, dim3((B0 + 255) / 256), dim3(256), 0, s, w.U[0], B0, 1.0 / B0);
+    hipLaunchKernelGGL(ub_fill, dim3((B1 + 255) / 256), dim3(256), 0, s, w.V[0], B1, 1.0 / B1);
+    for (int cpt = 0; cpt < max_iter; ++cpt) {
+        const int check = (cpt % 10 == 0) ? 1 : 0;
+        const int p = cpt & 1, q = p ^ 1;
+        hipLaunchKernelGGL(ub_rowdot, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], w.rowacc);
+        hipLaunchKernelGGL(ub_u_update, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, a, fi, w.st, w.rowacc,
+                           w.U[p], w.U[q], check);
+        hipLaunchKernelGGL(ub_coldot, dim3((B1 + 255) / 256, nchunk), dim3(256), 0, s, plan, B0, B1, w.st,
+                           w.U[q], w.part, rows_per_chunk);
+        hipLaunchKernelGGL(ub_v_update, dim3((B1 + 255) / 256), dim3(256), 0, s, B1, nchunk, b, fi, w.st,
+                           w.part, w.V[p], w.V[q], check);
+        hipLaunchKernelGGL(ub_decide, dim3(1), dim3(1), 0, s, w.st, cpt, max_iter, stop_thr, check);
+    }
+    hipLaunchKernelGGL(ub_plan, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[0], w.U[1], w.V[0], w.V[1], 0);
+    hipLaunchKernelGGL(ub_info, dim3(1), dim3(64), 0, s, w.st, info);
+    return cfm_status();
+}
+
+// ---------------------------------------------------------------- partial (Dykstra)
+// K0 <- K * (m / sum(K));  alpha = beta = rho = kappa = 1
+__global__ __launch_bounds__(256) void pt_scale(double* __restrict__ K, size_t n, double m, const UbState* st) {
+    const double f = m / st->sumK;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) K[k] *= f;
+}
+
+// rows: alpha1 = alpha * rho; rowsum = alpha1 * (K0 beta); r = min(a / rowsum, 1);
+//       alpha2 = r * alpha1; rho <- rho * alpha / alpha2
+__global__ void pt_row_update(int B0, double a, const UbState* st, const double* __restrict__ Kb,
+                              const double* __restrict__ alpha, double* __restrict__ rho,
+                              double* __restrict__ alpha2) {
+    if (st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B0) return;
+    const double al = alpha[i], a1 = al * rho[i];
+    const double rowsum = a1 * Kb[i];
+    const double r = fmin(a / rowsum, 1.0);
+    const double a2 = r * a1;
+    alpha2[i] = a2;
+    rho[i] = rho[i] * al / a2;
+}
+
+// cols: beta1 = beta * kappa; colsum = beta1 * (K0^T alpha2); c = min(b / colsum, 1);
+//       beta2 = c * beta1; kappa <- kappa * beta / beta2; total += beta2 * (K0^T alpha2)
+__global__ void pt_col_update(int B1, int nchunk, double b, UbState* st, const double* __restrict__ part,
+                              const double* __restrict__ beta, double* __restrict__ kappa,
+                              double* __restrict__ beta2) {
+    if (st->done) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double contrib = 0.0;
+    if (j < B1) {
+        double kta = 0.0;
+        for (int c = 0; c < nchunk; ++c) kta += part[(size_t)c * B1 + j];
+        const double be = beta[j], b1 = be * kappa[j];
+        const double colsum = b1 * kta;
+        const double cc = fmin(b / colsum, 1.0);
+        const double b2 = cc * b1;
+        beta2[j] = b2;
+        kappa[j] = kappa[j] * be / b2;
+        contrib = b2 * kta;
+    }
+    contrib = wave_sum_d(contrib);
+    if ((threadIdx.x & 63) == 0 && contrib != 0.0) atomicAdd(&st->total, contrib);
+}
+
+// || diag(alpha) K0 diag(beta) - diag(alpha2) K0 diag(beta2) ||_F^2 (alpha2 already carries sigma * s)
+__global__ __launch_bounds__(256) void pt_err(const double* __restrict__ K, int B0, int B1, UbState* st,
+                                              const double* __restrict__ alpha, const double* __restrict__ beta,
+                                              const double* __restrict__ alpha2, const double* __restrict__ beta2) {
+    if (st->done) return;
+    const size_t n = (size_t)B0 * B1;
+    double acc = 0.0;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const int i = (int)(k / B1), j = (int)(k - (size_t)i * B1);
+        const double d = K[k] * (alpha[i] * beta[j] - alpha2[i] * beta2[j]);
+        acc += d * d;
+    }
+    acc = wave_sum_d(acc);
+    __shared__ double sd[4];
+    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&st->err2, sd[0] + sd[1] + sd[2] + sd[3]);
+}
+
+// scalar step: K = K2 * q3 * (m / sum(K2 * q3)); q3 <- q3 * K2prev / K = 1 / s; folds the factor
+// sigma * s into alpha2 (kernel pt_fold) — here only the scalars.
+__global__ void pt_scalar(UbState* st, double m) {
+    if (st->done) return;
+    const double S = st->sigma * st->total;      // sum(K2 * q3)
+    const double s = m / S;
+    st->fold = st->sigma * s;                    // the scalar factor of this iteration, folded into alpha2
+    st->sigma = 1.0 / s;
+    st->total = 0.0;
+}
+
+__global__ void pt_fold(int B0, const UbState* st, double* __restrict__ alpha2) {
+    if (st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B0) {
+        alpha2[i] *= st->fold;
+    }
+}
+
+__global__ void pt_flags(int B0, int B1, UbState* st, const double* __restrict__ alpha2,
+                         const double* __restrict__ beta2) {
+    if (st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    if (i < B0 && !isfinite(alpha2[i])) bad = 1;
+    if (i < B1 && !isfinite(beta2[i])) bad = 1;
+    if (bad) atomicOr(&st->flag_bad, 1);
+}
+
+// loop control (POT entropic_partial_wasserstein): nan / inf in K -> warning, break (K kept);
+// cpt % 10 == 0: err = ||Kprev - K||_F; `while err > stopThr and cpt < numItermax`.
+__global__ void pt_decide(UbState* st, int cpt, int max_iter, double stop_thr, int check, double* errbuf) {
+    if (st->done) return;
+    const int next = cpt + 1;
+    if (st->flag_bad) { st->status = 1; st->final_idx = next & 1; st->iters = cpt; st->done = 1; return; }
+    double err = *errbuf;
+    if (check) { err = sqrt(st->err2); *errbuf = err; st->err2 = 0.0; }
+    st->iters = next; st->final_idx = next & 1;
+    if (!(err > stop_thr) || next >= max_iter) st->done = 1;
+}
+
+extern "C" int cfm_partial_entropic_f64(const float* M, int B0, int B1, double reg, double m,
+                                        int max_iter, double stop_thr, double* plan, int* info,
+                                        void* ws, void* stream) {
+    if (!M || !plan || !ws || B0 <= 0 || B1 <= 0 || !(reg > 0.0) || max_iter < 0) return CFM_EINVAL;
+    // POT: m must lie in [0, min(sum a, sum b)] = [0, 1]
+    if (!(m >= 0.0) || m > 1.0 + 1e-15) return CFM_EINVAL;
+    if (((uintptr_t)ws & 15) != 0 || ((uintptr_t)plan & 15) != 0) return CFM_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    UbWs w = ub_carve(ws, B0, B1);
+    const size_t n = (size_t)B0 * B1;
+    const int nchunk = ub_nchunk(B0, B1);
+    const int rows_per_chunk = (B0 + nchunk - 1) / nchunk;
+    const double a = 1.0 / B0, b = 1.0 / B1;
+    const int nmax = B0 > B1 ? B0 : B1;
+    hipLaunchKernelGGL(ub_state_init, dim3(1), dim3(64), 0, s, w.st);
+    hipLaunchKernelGGL(ub_gibbs, dim3(2048), dim3(256), 0, s, M, n, -reg, plan, w.st);
+    hipLaunchKernelGGL(pt_scale, dim3(2048), dim3(256), 0, s, plan, n, m, w.st);
+    hipLaunchKernelGGL(ub_fill, dim3((B0 + 255) / 256), dim3(256), 0, s, w.U[0], B0, 1.0);
+    hipLaunchKernelGGL(ub_fill, dim3((B1 + 255) / 256), dim3(256), 0, s, w.V[0], B1, 1.0);
+    hipLaunchKernelGGL(ub_fill, dim3((B0 + 255) / 256), dim3(256), 0, s, w.rho, B0, 1.0);
+    hipLaunchKernelGGL(ub_fill, dim3((B1 + 255) / 256), dim3(256), 0, s, w.kappa, B1, 1.0);
+    // err lives in colacc[0] between checks (initial value 1: the loop always starts)
+    hipLaunchKernelGGL(ub_fill, dim3(1), dim3(64), 0, s, w.colacc, 1, 1.0);
+    for (int cpt = 0; cpt < max_iter; ++cpt) {
+        const int check = (cpt % 10 == 0) ? 1 : 0;
+        const int p = cpt & 1, q = p ^ 1;    // (alpha, beta) = (U[p], V[p]) -> (U[q], V[q])
+        hipLaunchKernelGGL(ub_rowdot, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], w.rowacc);
+        hipLaunchKernelGGL(pt_row_update, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, a, w.st, w.rowacc,
+                           w.U[p], w.rho, w.U[q]);
+        hipLaunchKernelGGL(ub_coldot, dim3((B1 + 255) / 256, nchunk), dim3(256), 0, s, plan, B0, B1, w.st,
+                           w.U[q], w.part, rows_per_chunk);
+        hipLaunchKernelGGL(pt_col_update, dim3((B1 + 255) / 256), dim3(256), 0, s, B1, nchunk, b, w.st, w.part,
+                           w.V[p], w.kappa, w.V[q]);
+        hipLaunchKernelGGL(pt_scalar, dim3(1), dim3(1), 0, s, w.st, m);
+        hipLaunchKernelGGL(pt_fold, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, w.st, w.U[q]);
+        hipLaunchKernelGGL(pt_flags, dim3((nmax + 255) / 256), dim3(256), 0, s, B0, B1, w.st, w.U[q], w.V[q]);
+        if (check)
+            hipLaunchKernelGGL(pt_err, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[p], w.V[p], w.U[q], w.V[q]);
+        hipLaunchKernelGGL(pt_decide, dim3(1), dim3(1), 0, s, w.st, cpt, max_iter, stop_thr, check, w.colacc);
+    }
+    // POT keeps the NaN matrix when K had zeros (0 / 0 in the q updates poisons every entry within
+    // two iterations): reproduce it so the caller's diagnostics (optimal_transport.py:88-92) fire
+    hipLaunchKernelGGL(ub_plan, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[0], w.U[1], w.V[0], w.V[1], 1);
+    hipLaunchKernelGGL(ub_info, dim3(1), dim3(64), 0, s, w.st, info);
+    return cfm_status();
+}

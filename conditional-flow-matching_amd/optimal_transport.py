@@ -114,6 +114,34 @@ def sinkhorn_plan(r):
     return pi
 
 
+_UNBALANCED_MAX_ITER, _UNBALANCED_STOP_THR = 1000, 1e-6   # POT sinkhorn_knopp_unbalanced defaults
+_PARTIAL_MAX_ITER, _PARTIAL_STOP_THR = 1000, 1e-100         # POT entropic_partial_wasserstein defaults
+
+
+def _kernel_space_plan(fn_name, M, reg, second, max_iter, stop_thr):
+    lib = _lib.load()
+    B0, B1 = M.shape
+    dev = M.device
+    plan = torch.empty((B0, B1), dtype=torch.float64, device=dev)
+    info = torch.zeros(4, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(_lib.OP_UNBALANCED, B0, B1, 0, dev)
+    check(getattr(lib, fn_name)(ptr(M), B0, B1, float(reg), float(second), int(max_iter), float(stop_thr),
+                                ptr(plan), ptr(info), ptr(ws), stream_ptr()), fn_name)
+    return plan, info
+
+
+def unbalanced_plan(M, reg, reg_m, max_iter=_UNBALANCED_MAX_ITER, stop_thr=_UNBALANCED_STOP_THR):
+    """fp64 plan of pot.unbalanced.sinkhorn_knopp_unbalanced (ref:52-53,87) on the GPU.
+    Returns (plan [B0,B1] device fp64, info int32[4] = iterations, status, zeros / non-finite in K)."""
+    return _kernel_space_plan("cfm_unbalanced_sinkhorn_f64", M, reg, reg_m, max_iter, stop_thr)
+
+
+def partial_plan(M, reg, m=1.0, max_iter=_PARTIAL_MAX_ITER, stop_thr=_PARTIAL_STOP_THR):
+    """fp64 plan of pot.partial.entropic_partial_wasserstein (ref:54-55,87) on the GPU
+    (m = min(|a|, |b|) = 1 for the uniform marginals of get_map)."""
+    return _kernel_space_plan("cfm_partial_entropic_f64", M, reg, m, max_iter, stop_thr)
+
+
 def _u01_to_device(u, dev):
     return torch.from_numpy(np.ascontiguousarray(u, dtype=np.float64)).to(dev)
 
@@ -202,12 +230,16 @@ class OTPlanSampler:
         return dev, M
 
     def _solve(self, x0, x1):
-        """-> ("perm", perm) or ("dense", SinkhornResult)."""
-        if self.method in ("unbalanced", "partial"):
-            raise NotImplementedError(
-                f"OTPlanSampler(method={self.method!r}) is not built on the gfx950 backend yet "
-                "(SURVEY.md §8(f) rank 4); use 'exact' or 'sinkhorn'.")
+        """-> ("perm", perm), ("dense", SinkhornResult) or ("plan", device fp64 plan)."""
         dev, M = self._prepare(x0, x1)
+        if self.method == "unbalanced":
+            plan, info = unbalanced_plan(M, self.reg, self.reg_m)
+            self._last = info
+            return "plan", plan, M
+        if self.method == "partial":
+            plan, info = partial_plan(M, self.reg)
+            self._last = info
+            return "plan", plan, M
         if self.method == "exact":
             perm, info = assign_exact(M, return_info=True)
             self._last = info
@@ -226,6 +258,10 @@ class OTPlanSampler:
             B = M.shape[0]
             p = np.zeros((B, B), dtype=np.float64)
             p[np.arange(B), sol.cpu().numpy().astype(np.int64)] = 1.0 / B
+        elif kind == "plan":
+            p = sol.cpu().numpy()
+            if int(self._last[1].item()) == 1:     # POT warns and keeps the last usable iterate
+                warnings.warn("Numerical errors at iteration %d" % int(self._last[0].item()))
         else:
             p = sinkhorn_plan(sol).cpu().numpy()
         if not np.all(np.isfinite(p)):   # ref:88-92
@@ -286,6 +322,23 @@ class OTPlanSampler:
             return torch.from_numpy(i).to(dev), torch.from_numpy(j).to(dev)
         kind, sol, M = self._solve(x0, x1)
         dev = M.device
+        if kind == "plan":
+            # get_map's diagnostics (ref:88-96) on the device plan, then sample_map (ref:116-121)
+            finite = bool(torch.isfinite(sol).all())
+            total = float(sol.sum()) if finite else float("nan")
+            if not finite:
+                print("ERROR: p is not finite")
+                print(sol)
+                print("Cost mean, max", M.mean(), M.max())
+                print(x0, x1)
+                raise ValueError("probabilities contain NaN")   # what np.random.choice raises, ref:118
+            u = _u01_to_device(np.random.random_sample(n), dev)
+            if abs(total) < 1e-8:
+                if self.warn:
+                    warnings.warn("Numerical errors in OT plan, reverting to uniform plan.")
+                flat = torch.clamp((u * (M.shape[0] * M.shape[1])).floor().long(), max=M.numel() - 1)
+                return flat // M.shape[1], flat % M.shape[1]
+            return sample_pi(sol, u)
         if kind == "dense":
             # NaN guard of get_map (ref:88-96): a non-finite potential -> uniform plan
             fin = bool(torch.isfinite(sol.f).all() and torch.isfinite(sol.g).all())

@@ -45,6 +45,7 @@ extern "C" {
 #define CFM_OP_SAMPLE_DENSE  3
 #define CFM_OP_MLP           4
 #define CFM_OP_ODE           5
+#define CFM_OP_UNBALANCED    6   /* also the partial (Dykstra) solver */
 
 /* variants for cfm_sample_xt_ut_f32 (reference class in parentheses) */
 #define CFM_VARIANT_ICFM   0  /* ConditionalFlowMatcher / ExactOT...          */
@@ -103,6 +104,36 @@ int cfm_sinkhorn_plan_f64(const float* M, int B0, int B1, double reg, const void
  * out: one double. */
 int cfm_sinkhorn_cost_f64(const float* M, int B0, int B1, double reg, const void* ws,
                           double* out, void* stream);
+
+/* K5u — unbalanced entropic OT, uniform marginals, kernel space, fp64.
+ * Replaces  pot.unbalanced.sinkhorn_knopp_unbalanced(a, b, M, reg, reg_m)
+ *                                   torchcfm/optimal_transport.py:52-53,87
+ * following the in-repo statement of POT's loop
+ * (runner/src/models/components/sinkhorn_knopp_unbalanced.py:113-201, reg_m_1 = reg_m_2):
+ *   K = exp(M / -reg);  u = (a / K v)^fi,  v = (b / K^T u)^fi,  fi = reg_m / (reg_m + reg);
+ *   numerical error (K^T u == 0, nan, inf) -> the previous (u, v) and stop;
+ *   every 10th iteration err = mean of the relative sup-norm changes of u and v; stop at
+ *   err <= stop_thr or after max_iter iterations (POT defaults 1000, 1e-6).
+ * plan [B0,B1] fp64 receives u_i K_ij v_j (what get_map() returns, :87).
+ * info (device int32[4], may be NULL): {iterations, status (1 = numerical error, previous
+ * iterate returned), zeros in K, non-finite entries in K}.
+ * ws: cfm_workspace_bytes(CFM_OP_UNBALANCED,B0,B1,0) bytes, 16-byte aligned. */
+int cfm_unbalanced_sinkhorn_f64(const float* M, int B0, int B1, double reg, double reg_m,
+                                int max_iter, double stop_thr, double* plan, int* info,
+                                void* ws, void* stream);
+
+/* K5p — entropic partial OT (Dykstra), uniform marginals, transported mass m, fp64.
+ * Replaces  pot.partial.entropic_partial_wasserstein(a, b, M, reg)
+ *                                   torchcfm/optimal_transport.py:54-55,87
+ * (m = min(sum a, sum b) = 1 when the reference calls it; POT defaults numItermax = 1000,
+ * stopThr = 1e-100, error ||K_prev - K||_F every 10th iteration).  The three B0 x B1
+ * Dykstra corrections are constant along rows / columns / everywhere, so the iteration is
+ * carried on two scaling vectors and a scalar over K0 = exp(M / -reg) * m / sum.
+ * If K0 has zeros POT's 0/0 poisons the plan with NaN; so does this (info[2] counts them).
+ * plan, info, ws as for cfm_unbalanced_sinkhorn_f64. */
+int cfm_partial_entropic_f64(const float* M, int B0, int B1, double reg, double m,
+                             int max_iter, double stop_thr, double* plan, int* info,
+                             void* ws, void* stream);
 
 /* K4 — exact optimal assignment for uniform, equal-size marginals.
  * Replaces  pot.emd(a, b, M)                torchcfm/optimal_transport.py:49,87

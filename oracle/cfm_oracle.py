@@ -222,6 +222,91 @@ def sinkhorn_knopp(M, reg, numItermax=1000, stopThr=1e-9):
     return u.reshape(-1, 1) * K * v.reshape(1, -1)
 
 
+def sinkhorn_knopp_unbalanced(M, reg, reg_m, numItermax=1000, stopThr=1e-6, a=None, b=None, log=False):
+    """pot.unbalanced.sinkhorn_knopp_unbalanced(a, b, M, reg, reg_m) (optimal_transport.py:52-53)
+    as the reference authors restate it in runner/src/models/components/
+    sinkhorn_knopp_unbalanced.py:113-201 (reg_m_1 = reg_m_2 = reg_m); float64, uniform marginals
+    unless given.  KAT of its docstring (:88-94): a=b=[.5,.5], M=[[0,1],[1,0]], reg=reg_m=1 ->
+    [[0.51122814, 0.18807032], [0.18807032, 0.51122814]]."""
+    M = np.asarray(M, dtype=np.float64)
+    dim_a, dim_b = M.shape
+    a = np.full(dim_a, 1.0 / dim_a) if a is None else np.asarray(a, dtype=np.float64)
+    b = np.full(dim_b, 1.0 / dim_b) if b is None else np.asarray(b, dtype=np.float64)
+    u = np.ones(dim_a) / dim_a
+    v = np.ones(dim_b) / dim_b
+    K = np.empty(M.shape, dtype=M.dtype)
+    np.divide(M, -reg, out=K)
+    np.exp(K, out=K)
+    fi = reg_m / (reg_m + reg)
+    cpt, err, status = 0, 1.0, 0
+    while err > stopThr and cpt < numItermax:
+        uprev, vprev = u, v
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            Kv = K.dot(v)
+            u = (a / Kv) ** fi
+            Ktu = K.T.dot(u)
+            v = (b / Ktu) ** fi
+        if (np.any(Ktu == 0.0) or np.any(np.isnan(u)) or np.any(np.isnan(v))
+                or np.any(np.isinf(u)) or np.any(np.isinf(v))):
+            warnings.warn("Numerical errors at iteration %s" % cpt)
+            u, v, status = uprev, vprev, 1
+            break
+        if cpt % 10 == 0:
+            err_u = abs(u - uprev).max() / max(abs(u).max(), abs(uprev).max(), 1.0)
+            err_v = abs(v - vprev).max() / max(abs(v).max(), abs(vprev).max(), 1.0)
+            err = 0.5 * (err_u + err_v)
+        cpt += 1
+    G = u[:, None] * K * v[None, :]
+    return (G, {"iters": cpt, "status": status, "err": err}) if log else G
+
+
+def entropic_partial_wasserstein(M, reg, m=None, numItermax=1000, stopThr=1e-100, a=None, b=None,
+                                 log=False):
+    """pot.partial.entropic_partial_wasserstein(a, b, M, reg) (optimal_transport.py:54-55):
+    POT's Dykstra loop written out with its three full correction matrices q1, q2, q3
+    ([RECALLED] from POT 0.8/0.9 ot/partial.py — POT is absent from the reference tree and not
+    installable here: parity unpinned); float64, uniform marginals unless given."""
+    M = np.asarray(M, dtype=np.float64)
+    dim_a, dim_b = M.shape
+    a = np.full(dim_a, 1.0 / dim_a) if a is None else np.asarray(a, dtype=np.float64)
+    b = np.full(dim_b, 1.0 / dim_b) if b is None else np.asarray(b, dtype=np.float64)
+    dx, dy = np.ones(dim_a), np.ones(dim_b)
+    if m is None:
+        m = min(np.sum(a), np.sum(b)) * 1.0
+    if m < 0:
+        raise ValueError("Problem infeasible. Parameter m should be greater than 0.")
+    if m > min(np.sum(a), np.sum(b)) * (1 + 1e-15):
+        raise ValueError("Problem infeasible. Parameter m should lower or equal than min(|a|_1, |b|_1).")
+    K = np.empty(M.shape, dtype=M.dtype)
+    np.divide(M, -reg, out=K)
+    np.exp(K, out=K)
+    np.multiply(K, m / np.sum(K), out=K)
+    err, cpt, status = 1, 0, 0
+    q1, q2, q3 = np.ones(K.shape), np.ones(K.shape), np.ones(K.shape)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        while err > stopThr and cpt < numItermax:
+            Kprev = K
+            K = K * q1
+            K1 = np.dot(np.diag(np.minimum(a / np.sum(K, axis=1), dx)), K)
+            q1 = q1 * Kprev / K1
+            K1prev = K1
+            K1 = K1 * q2
+            K2 = np.dot(K1, np.diag(np.minimum(b / np.sum(K1, axis=0), dy)))
+            q2 = q2 * K1prev / K2
+            K2prev = K2
+            K2 = K2 * q3
+            K = K2 * (m / np.sum(K2))
+            q3 = q3 * K2prev / K
+            if np.any(np.isnan(K)) or np.any(np.isinf(K)):
+                print("Warning: numerical errors at iteration", cpt)
+                status = 1
+                break
+            if cpt % 10 == 0:
+                err = np.linalg.norm(Kprev - K)
+            cpt = cpt + 1
+    return (K, {"iters": cpt, "status": status, "err": err}) if log else K
+
+
 # ----------------------------------------------------------------------------- xt / ut (K8)
 def pad_t_like_x(t, x):
     if isinstance(t, (float, int)):

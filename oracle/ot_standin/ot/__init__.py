@@ -5,7 +5,8 @@ infrastructure like the rest of oracle/.
 
 emd/emd2: uniform equal-size marginals only -> permutation plan from SciPy's LSAP (the solver
 the reference itself uses at torchcfm/optimal_transport.py:170,179).  sinkhorn/sinkhorn2:
-POT's default Sinkhorn-Knopp restated.
+POT's default Sinkhorn-Knopp restated.  unbalanced / partial: the loops of
+cfm_oracle.sinkhorn_knopp_unbalanced / entropic_partial_wasserstein.
 """
 import os
 import sys
@@ -54,5 +55,17 @@ class _NS:
         return _f
 
 
-unbalanced = _NS("unbalanced")
-partial = _NS("partial")
+class _Unbalanced(_NS):
+    @staticmethod
+    def sinkhorn_knopp_unbalanced(a, b, M, reg, reg_m, numItermax=1000, stopThr=1e-6, **kw):
+        return _o.sinkhorn_knopp_unbalanced(M, reg, reg_m, numItermax, stopThr, a=a, b=b)
+
+
+class _Partial(_NS):
+    @staticmethod
+    def entropic_partial_wasserstein(a, b, M, reg, m=None, numItermax=1000, stopThr=1e-100, **kw):
+        return _o.entropic_partial_wasserstein(M, reg, m, numItermax, stopThr, a=a, b=b)
+
+
+unbalanced = _Unbalanced("unbalanced")
+partial = _Partial("partial")

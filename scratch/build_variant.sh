@@ -4,6 +4,6 @@ set -e
 R=/root/repo; C=$R/conditional-flow-matching_amd/csrc
 mkdir -p $R/scratch/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $2 -c $C/assign.hip -o /tmp/assign_$1.o
-objs=""; for f in abi cost sinkhorn sample elem mlp ode; do objs="$objs $C/obj/$f.o"; done
+objs=""; for f in abi cost sinkhorn sample elem mlp ode unbalanced; do objs="$objs $C/obj/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/assign_$1.o -o $R/scratch/variants/$1.so
 echo built $1

@@ -14,6 +14,8 @@ Fixture provenance
                       real, solver = stand-in).
   sinkhorn_cases.npz  oracle float64 log-domain Sinkhorn (POT loop semantics) + restated Knopp.
   ode_cases.npz       oracle torchdyn-style euler / dopri5 on a seeded MLP field.
+  ub_cases.npz        reference OTPlanSampler("unbalanced" / "partial") wrapper over the restated
+                      POT loops (in-repo unbalanced statement; recalled partial Dykstra loop).
 """
 import os
 import sys
@@ -143,8 +145,42 @@ def ode_cases():
     return out
 
 
+def ub_cases(ot):
+    """Reference OTPlanSampler(method="unbalanced" | "partial") wrapper (real code) over the
+    stand-in's restated POT loops, plus the docstring KAT of the in-repo unbalanced statement."""
+    out = {}
+    B = 96
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(B, 3, generator=g)
+    x1 = torch.randn(B, 3, generator=g) * 0.8 + 0.7
+    out["x0"], out["x1"] = x0.numpy(), x1.numpy()
+    for reg, reg_m in ((0.5, 1.0), (1.0, 0.2), (0.3, 5.0)):
+        s = ot.OTPlanSampler(method="unbalanced", reg=reg, reg_m=reg_m)
+        out[f"unb_pi_{reg}_{reg_m}"] = s.get_map(x0, x1)
+        np.random.seed(3)
+        i, j = s.sample_map(out[f"unb_pi_{reg}_{reg_m}"], B)
+        out[f"unb_i_{reg}_{reg_m}"], out[f"unb_j_{reg}_{reg_m}"] = i, j
+    for reg in (0.5, 2.0):
+        s = ot.OTPlanSampler(method="partial", reg=reg)
+        out[f"par_pi_{reg}"] = s.get_map(x0, x1)
+        np.random.seed(4)
+        i, j = s.sample_map(out[f"par_pi_{reg}"], B)
+        out[f"par_i_{reg}"], out[f"par_j_{reg}"] = i, j
+    # rectangular
+    x2 = torch.randn(64, 3, generator=g) + 0.3
+    out["x2"] = x2.numpy()
+    out["unb_rect"] = ot.OTPlanSampler(method="unbalanced", reg=0.7, reg_m=1.0).get_map(x0, x2)
+    out["par_rect"] = ot.OTPlanSampler(method="partial", reg=0.7).get_map(x0, x2)
+    # partial with m < 1 (POT API below the wrapper)
+    M = oracle.ref_cost_f32(x0, x1)
+    out["par_m06"] = oracle.entropic_partial_wasserstein(M, 0.5, m=0.6)
+    out["kat_unbalanced"] = oracle.sinkhorn_knopp_unbalanced([[0.0, 1.0], [1.0, 0.0]], 1.0, 1.0, a=[0.5, 0.5], b=[0.5, 0.5])
+    return out
+
+
 def main():
     cfm, ot = ref_import.import_reference()
+    np.savez_compressed(os.path.join(HERE, "ub_cases.npz"), **ub_cases(ot))
     np.savez_compressed(os.path.join(HERE, "fm_cases.npz"), **fm_cases(cfm))
     np.savez_compressed(os.path.join(HERE, "ot_cases.npz"), **ot_cases(ot))
     np.savez_compressed(os.path.join(HERE, "sinkhorn_cases.npz"), **sinkhorn_cases())

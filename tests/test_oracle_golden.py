@@ -150,3 +150,47 @@ def test_oracle_ode(golden_dir):
     assert np.abs(mine[-1].ravel() - sol.y[:, -1]).max() < 1e-4
     eul = oracle.euler_trajectory(f, d["x"], d["t_span"])
     np.testing.assert_allclose(eul, d["euler"], rtol=1e-12)
+
+
+# ----------------------------------------------------------------------------- unbalanced / partial
+def test_unbalanced_docstring_kat():
+    """KAT of runner/src/models/components/sinkhorn_knopp_unbalanced.py:88-94 (printed to 8
+    digits by a POT build whose stopping point differs in the 7th: 5e-7)."""
+    G = oracle.sinkhorn_knopp_unbalanced([[0.0, 1.0], [1.0, 0.0]], 1.0, 1.0, a=[0.5, 0.5], b=[0.5, 0.5])
+    assert np.abs(G - np.array([[0.51122814, 0.18807032], [0.18807032, 0.51122814]])).max() < 5e-7
+
+
+def test_unbalanced_partial_fixtures_reproduce(golden_dir):
+    d = np.load(os.path.join(golden_dir, "ub_cases.npz"))
+    M = oracle.ref_cost_f32(d["x0"], d["x1"])
+    assert np.array_equal(oracle.sinkhorn_knopp_unbalanced(M, 0.5, 1.0), d["unb_pi_0.5_1.0"])
+    assert np.array_equal(oracle.entropic_partial_wasserstein(M, 2.0), d["par_pi_2.0"])
+    P = d["par_m06"]
+    assert abs(P.sum() - 0.6) < 1e-12 and (P.sum(1) <= 1 / 96 + 1e-12).all() and (P.sum(0) <= 1 / 96 + 1e-12).all()
+
+
+def test_partial_vector_form_equals_matrix_form():
+    """The device solver carries POT's three full Dykstra correction matrices as two vectors and a
+    scalar; the algebra (q1 row-constant, q2 column-constant, q3 constant) is checked here."""
+    rng = np.random.default_rng(1)
+    M = rng.uniform(0, 3, size=(40, 28))
+    ref = oracle.entropic_partial_wasserstein(M, 0.7, m=0.8, numItermax=60)
+    n0, n1 = M.shape
+    a, b, m = 1.0 / n0, 1.0 / n1, 0.8
+    K0 = np.exp(M / -0.7); K0 *= m / K0.sum()
+    al, be, rho, ka, sig = np.ones(n0), np.ones(n1), np.ones(n0), np.ones(n1), 1.0
+    for _ in range(60):
+        a1 = al * rho
+        r = np.minimum(a / (a1 * (K0 @ be)), 1.0)
+        a2 = r * a1
+        rho = rho * al / a2
+        b1 = be * ka
+        kta = K0.T @ a2
+        c = np.minimum(b / (b1 * kta), 1.0)
+        b2 = c * b1
+        ka = ka * be / b2
+        S = sig * np.sum(b2 * kta)
+        s = m / S
+        al, be, sig = a2 * (sig * s), b2, 1.0 / s
+    P = al[:, None] * K0 * be[None, :]
+    assert np.abs(P - ref).max() <= 1e-12 * np.abs(ref).max()
