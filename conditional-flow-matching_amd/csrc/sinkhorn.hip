@@ -333,6 +333,12 @@ __device__ __forceinline__ void sk_row_trip(const float4 (&c)[U], int j0, double
 }
 
 #define SK_ROW_PRE 16   // float4 per lane in flight per 4096-column segment
+#ifndef SK_RPW
+#define SK_RPW 4         // rows per workgroup of the fast row pass (4 waves)
+#endif
+#ifndef SK_ROW_OCC
+#define SK_ROW_OCC 3     // workgroups per CU the fast row pass is compiled for
+#endif
 
 // One wave per row; the row's first segment was loaded BEFORE v was staged into LDS (the two
 // latencies overlap), later segments of a longer row are loaded 16 float4 at a time.
@@ -371,7 +377,7 @@ __device__ __forceinline__ void sk_row_fast(const float* __restrict__ row, int B
 // Row pass: u_i = log a - LSE_j(v_j - M_ij/reg); also the convergence decision
 // for the previous iteration (every workgroup derives it from the same data).
 template <bool FAST>
-__global__ __launch_bounds__(256, FAST ? 3 : 4) void sk_row_pass(const float* __restrict__ M, int B0, int B1,
+__global__ __launch_bounds__(256, FAST ? SK_ROW_OCC : 4) void sk_row_pass(const float* __restrict__ M, int B0, int B1,
                                                       double inv_reg, double loga,
                                                       SkState* __restrict__ st,
                                                       const double* __restrict__ v,
@@ -403,24 +409,63 @@ __global__ __launch_bounds__(256, FAST ? 3 : 4) void sk_row_pass(const float* __
 
     extern __shared__ __attribute__((aligned(16))) double vs[];
     if (FAST) {
-        // rows_per_wg == 4: one row per wave, v always staged in LDS
+        // SK_RPW rows per workgroup, SK_RPW / 4 consecutive rows per wave, v staged in LDS once per
+        // workgroup.  The first row is requested BEFORE v is staged (the two latencies overlap); with
+        // more than one row per wave the next row is requested before the current one is reduced.
+        constexpr int RPWV = SK_RPW / 4;
         const int lane = threadIdx.x & 63;
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar row base
-        const int r = blockIdx.x * 4 + wv;
-        const bool have = r < B0;
-        const float* row = M + (size_t)(have ? r : 0) * B1;
-        float4 pre[SK_ROW_PRE];
+        const int r0 = blockIdx.x * SK_RPW + wv * RPWV;
+        float4 preA[SK_ROW_PRE];
+        {
+            const float* row = M + (size_t)(r0 < B0 ? r0 : 0) * B1;
 #pragma unroll
-        for (int k = 0; k < SK_ROW_PRE; ++k) {
-            const int j = lane * 4 + 256 * k;
-            pre[k] = (j < B1) ? *reinterpret_cast<const float4*>(row + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < SK_ROW_PRE; ++k) {
+                const int j = lane * 4 + 256 * k;
+                preA[k] = (j < B1) ? *reinterpret_cast<const float4*>(row + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         for (int j = threadIdx.x * 2; j < B1; j += 512)
             *reinterpret_cast<double2*>(vs + j) = *reinterpret_cast<const double2*>(v + j);
         __syncthreads();
-        if (have) {
-            if (precise) sk_row_fast<true>(row, B1, inv_reg, loga, vs, u + r, pre);
-            else         sk_row_fast<false>(row, B1, inv_reg, loga, vs, u + r, pre);
+        if (RPWV == 1) {
+            if (r0 < B0) {
+                const float* row = M + (size_t)r0 * B1;
+                if (precise) sk_row_fast<true>(row, B1, inv_reg, loga, vs, u + r0, preA);
+                else         sk_row_fast<false>(row, B1, inv_reg, loga, vs, u + r0, preA);
+            }
+        } else {
+            float4 preB[SK_ROW_PRE];
+#pragma unroll
+            for (int rr = 0; rr < RPWV; rr += 2) {
+                const int ra = r0 + rr, rb = r0 + rr + 1, rc = r0 + rr + 2;
+                if (rr + 1 < RPWV && rb < B0) {
+                    const float* row = M + (size_t)rb * B1;
+#pragma unroll
+                    for (int k = 0; k < SK_ROW_PRE; ++k) {
+                        const int j = lane * 4 + 256 * k;
+                        preB[k] = (j < B1) ? *reinterpret_cast<const float4*>(row + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                if (ra < B0) {
+                    const float* row = M + (size_t)ra * B1;
+                    if (precise) sk_row_fast<true>(row, B1, inv_reg, loga, vs, u + ra, preA);
+                    else         sk_row_fast<false>(row, B1, inv_reg, loga, vs, u + ra, preA);
+                }
+                if (rr + 2 < RPWV && rc < B0) {
+                    const float* row = M + (size_t)rc * B1;
+#pragma unroll
+                    for (int k = 0; k < SK_ROW_PRE; ++k) {
+                        const int j = lane * 4 + 256 * k;
+                        preA[k] = (j < B1) ? *reinterpret_cast<const float4*>(row + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                if (rr + 1 < RPWV && rb < B0) {
+                    const float* row = M + (size_t)rb * B1;
+                    if (precise) sk_row_fast<true>(row, B1, inv_reg, loga, vs, u + rb, preB);
+                    else         sk_row_fast<false>(row, B1, inv_reg, loga, vs, u + rb, preB);
+                }
+            }
         }
     } else {
         if (v_in_lds) {
@@ -466,7 +511,7 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, 
     const double loga = log(a), logb = log(b);
     // fast row pass: whole 1024-column trips, 16-byte aligned rows, v fits in LDS
     const bool row_fast = vec && (B1 % 1024 == 0) && ((size_t)B1 * 8 <= 128 * 1024);
-    const int rows_per_wg = row_fast ? 4 : 8;
+    const int rows_per_wg = row_fast ? SK_RPW : 8;
     const int row_wgs = (B0 + rows_per_wg - 1) / rows_per_wg;
     int v_in_lds = ((size_t)B1 * 8 <= 128 * 1024) ? 1 : 0;
     if (v_in_lds && (size_t)B1 * 8 > 48 * 1024) {
