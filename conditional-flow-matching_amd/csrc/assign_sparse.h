@@ -516,6 +516,105 @@ __device__ __forceinline__ double sp_collect(const SpL& L, int plcur, double dfr
     return delta;
 }
 
+// The same bookkeeping by ALL 16 waves (sp_collect's single wave was 40 % of a batch): every
+// thread owns up to SP_IPT entries of the near list, the waves exchange (min, max, count) and then
+// their selection counts through LDS, two barriers in all.  Entries are taken in (wave, slot,
+// lane) order instead of list order — the list order is arbitrary anyway (atomic appends).
+// Every thread returns the same adapted delta; nS / list length / far_thr are published in LDS.
+#define SP_RI_WANT 16    // 16 per-wave selection counts
+#define SP_RI_KEEP 96    // 16 per-wave keep counts
+__device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double dfree, double delta,
+                                                 double far_thr) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int npl = L.ri[SP_RI_NPL];
+    const unsigned short* src = plcur ? L.pl[1] : L.pl[0];
+    unsigned short* dst = plcur ? L.pl[0] : L.pl[1];
+    int kk[SP_IPT]; double dd[SP_IPT]; bool have[SP_IPT], live[SP_IPT];
+    double lmin = INFINITY, lmax = 0.0; int np = 0;
+#pragma unroll
+    for (int e = 0; e < SP_IPT; ++e) {
+        const int t = e * SP_T + tid;
+        have[e] = t < npl; kk[e] = 0; dd[e] = INFINITY; live[e] = false;
+        if (have[e]) {
+            kk[e] = src[t];
+            dd[e] = L.dist[kk[e]];
+            L.pred[kk[e]] |= SP_STALE;
+            live[e] = dd[e] < dfree;
+            if (live[e]) { lmin = fmin(lmin, dd[e]); lmax = fmax(lmax, dd[e]); ++np; }
+        }
+    }
+    {
+        const double wmin = sp_wave_min(lmin), wmax = sp_wave_max(lmax);
+        const int wnp = sp_wave_total(np);
+        if (lane == 0) { L.rd[wv] = wmin; L.rd[16 + wv] = wmax; L.ri[wv] = wnp; }
+    }
+    sp_sync();
+    const double dmin = sp_wave_min(lane < SP_NW ? L.rd[lane] : INFINITY);
+    const double dmax = sp_wave_max(lane < SP_NW ? L.rd[16 + lane] : 0.0);
+    const int npend = sp_wave_total(lane < SP_NW ? L.ri[lane] : 0);
+    if (!(far_thr < INFINITY) && delta < INFINITY && npend > 2 * SP_CAP) far_thr = dmin + 8.0 * delta;
+    const double tau = dmin + delta;
+    bool want[SP_IPT], keep[SP_IPT]; int wpos[SP_IPT], kpos[SP_IPT];
+    int wtot = 0, ktot = 0;
+#pragma unroll
+    for (int e = 0; e < SP_IPT; ++e) {
+        want[e] = live[e] && dd[e] <= tau;
+        keep[e] = live[e] && !want[e] && dd[e] <= far_thr;
+        const int winc = sp_wave_scan(want[e] ? 1 : 0), kinc = sp_wave_scan(keep[e] ? 1 : 0);
+        wpos[e] = wtot + winc - 1; kpos[e] = ktot + kinc - 1;
+        wtot += __builtin_amdgcn_readlane(winc, 63); ktot += __builtin_amdgcn_readlane(kinc, 63);
+    }
+    if (lane == 0) { L.ri[SP_RI_WANT + wv] = wtot; L.ri[SP_RI_KEEP + wv] = ktot; }
+    sp_sync();
+    int woff, koff, nsel, nkeep;
+    {
+        const int wc = (lane < SP_NW) ? L.ri[SP_RI_WANT + lane] : 0, kc = (lane < SP_NW) ? L.ri[SP_RI_KEEP + lane] : 0;
+        const int ws = sp_wave_scan(wc), ks = sp_wave_scan(kc);
+        nsel = __builtin_amdgcn_readlane(ws, 63); nkeep = __builtin_amdgcn_readlane(ks, 63);
+        woff = __shfl(ws - wc, wv, 64); koff = __shfl(ks - kc, wv, 64);
+    }
+    if (nsel > SP_CAP) {
+        // over the cap (rare: delta halves below): the wants past SP_CAP stay pending
+        sp_sync();                                   // everybody has read the first keep counts
+        ktot = 0;
+#pragma unroll
+        for (int e = 0; e < SP_IPT; ++e) {
+            const bool sel = want[e] && (woff + wpos[e]) < SP_CAP;
+            keep[e] = live[e] && !sel && dd[e] <= far_thr;
+            want[e] = sel;
+            const int kinc = sp_wave_scan(keep[e] ? 1 : 0);
+            kpos[e] = ktot + kinc - 1;
+            ktot += __builtin_amdgcn_readlane(kinc, 63);
+        }
+        if (lane == 0) L.ri[SP_RI_KEEP + wv] = ktot;
+        sp_sync();
+        const int kc = (lane < SP_NW) ? L.ri[SP_RI_KEEP + lane] : 0;
+        const int ks = sp_wave_scan(kc);
+        nkeep = __builtin_amdgcn_readlane(ks, 63);
+        koff = __shfl(ks - kc, wv, 64);
+    }
+#pragma unroll
+    for (int e = 0; e < SP_IPT; ++e) {
+        if (!have[e]) continue;
+        const int k = kk[e];
+        if (want[e]) {
+            const int spos = woff + wpos[e];
+            L.lcol[spos] = (unsigned short)k; L.lbase[spos] = dd[e]; L.inl[k] = 0;
+        } else if (keep[e]) {
+            dst[koff + kpos[e]] = (unsigned short)k;
+        } else {
+            L.inl[k] = live[e] ? 2 : 0;
+        }
+    }
+    if (tid == 0) {
+        L.ri[SP_RI_NS] = nsel < SP_CAP ? nsel : SP_CAP; L.ri[SP_RI_NPL] = nkeep; L.rd[SP_RD_FAR] = far_thr;
+    }
+    // adapt the window: aim at 32 .. 64 entries per batch
+    if (nsel > SP_CAP) delta = 0.5 * fmin(delta, dmax - dmin);
+    else if (nsel < SP_CAP / 2 && npend > nsel) delta = fmax(2.0 * delta, (dmax - dmin) * (1.0 / 64.0));
+    return delta;
+}
+
 #ifdef SP_PROFILE
 #define SP_TICK(slot) do { if (tid == 0) { const long long t_ = clock64(); dbg[slot] += t_ - tlast; tlast = t_; } } while (0)
 #else
@@ -607,7 +706,7 @@ __device__ __forceinline__ void sp_solver(const float* __restrict__ M, const Asg
 #endif
             }
             dfree = L.rd[SP_RD_DFREE];
-            if (wv == 0) delta = sp_collect(L, plcur, dfree, delta, far_thr, lane);
+            delta = sp_collect_all(L, plcur, dfree, delta, far_thr);
             sp_sync();
             nS = L.ri[SP_RI_NS]; far_thr = L.rd[SP_RD_FAR]; plcur ^= 1; any_dense = false;
             SP_TICK(2);
@@ -648,7 +747,7 @@ __device__ __forceinline__ void sp_solver(const float* __restrict__ M, const Asg
                     }
                     if (tid == 0) { L.ri[SP_RI_NPL] = nmove; L.rd[SP_RD_FAR] = far_thr; }
                     sp_sync();
-                    if (wv == 0) delta = sp_collect(L, plcur, dfree, delta, far_thr, lane);
+                    delta = sp_collect_all(L, plcur, dfree, delta, far_thr);
                     sp_sync();
                     nS = L.ri[SP_RI_NS]; far_thr = L.rd[SP_RD_FAR]; plcur ^= 1;
                     SP_TICK(2);
