@@ -44,7 +44,9 @@ enum { MODE_INIT = 0, MODE_AUCTION = 1, MODE_ARR = 2, MODE_SAP = 3, MODE_CERT = 
        MODE_BUILD = 6, MODE_SAP1 = 7, MODE_SAP1_DONE = 8,
        MODE_UMIN = 9,      // u_i = min_k (c_ik + p_k) for every row (before the column reduction)
        MODE_COLRED = 10,   // lower the price of every free column until it is tight
-       MODE_ROOTMIN = 11 };// u_r for the free rows of the next multi-source phase
+       MODE_ROOTMIN = 11,  // u_r for the free rows of the next multi-source phase
+       MODE_UMIN0 = 12,    // initial dual: u_i = min_j c_ij
+       MODE_INITRED = 13 };// initial prices: p_j = max_i (u_i - c_ij)   (row + column reduction)
 
 struct AsgParams {
     double theta;          // epsilon reduction factor
@@ -60,7 +62,7 @@ struct AsgParams {
     double ms_q;           // radius of a multi-source phase: quantile of the free-column labels
 };
 
-static AsgParams g_params = {5.0, 0.2, 1e-6, 0.02, 4000, 15, 64, 400000, 1, 6, 1.0};
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 64, 400000, 1, 6, 1.0};
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
                                       double stop_frac, int round_cap, int arr_cap, int chunk) {
@@ -298,8 +300,9 @@ __device__ __forceinline__ void bid_commit(const AsgWs& w, Top2 best, int i, dou
         const double bv = (use_plds ? p_lds[jwin] : w.p[jwin]) + incr;
         w.bidcol[i] = jwin;
         w.bidval[i] = bv;
+        // prices may be negative (they start from the row + column reduction): ordered float bits
         const unsigned long long key =
-            ((unsigned long long)__float_as_uint((float)bv) << 32) | (unsigned)(i + 1);
+            ((unsigned long long)f2ord((float)bv) << 32) | (unsigned)(i + 1);
         atomicMax(&w.packed[jwin], key);
     }
 }
@@ -493,6 +496,47 @@ __device__ __forceinline__ void wide_colred(const float* __restrict__ M, const A
     }
 }
 
+// Initial prices by row + column reduction (the classical Jonker-Volgenant start): with
+// u_i = min_j c_ij (bidval[], MODE_UMIN0) the price p_j = max_i (u_i - c_ij) <= 0 is the largest
+// one that keeps every row's minimum where it is, and it makes every column tight for some row.
+// The auction then starts two epsilon phases later (eps0 = 8e-3 instead of 0.2 of the cost range):
+// 78 rounds instead of 113 on the C3 data.  Lane <-> column, the grid splits the rows, partial
+// maxima through one ordered-double atomicMax per column and workgroup (packed[] is the scratch).
+__device__ __forceinline__ void wide_initred(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+                                             double* sh_d, int n) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n_groups = (n + 63) / 64;
+    int Y = gridDim.x / n_groups; Y = Y < 1 ? 1 : Y;
+    constexpr int NW = WT / 64, Q = 8;
+    for (int unit = blockIdx.x; unit < n_groups * Y; unit += gridDim.x) {
+        const int g = unit % n_groups, y = unit / n_groups;
+        const int k = g * 64 + lane;
+        const bool ok = k < n;
+        const int r_beg = (int)((long long)n * y / Y), r_end = (int)((long long)n * (y + 1) / Y);
+        double m = -INFINITY;
+        for (int r0 = r_beg + wv * Q; r0 < r_end; r0 += NW * Q) {
+            float c[Q]; double u[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int r = r0 + q;
+                const bool v = ok && r < r_end;
+                c[q] = v ? M[(size_t)r * n + k] : 0.f;
+                u[q] = (r < r_end) ? w.bidval[r] : -INFINITY;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) m = fmax(m, u[q] - (double)c[q]);
+        }
+        sh_d[wv * 64 + lane] = m;
+        __syncthreads();
+        if (wv == 0 && ok) {
+#pragma unroll
+            for (int q = 1; q < NW; ++q) m = fmax(m, sh_d[q * 64 + lane]);
+            atomicMax(&w.packed[k], d2ord(m));
+        }
+        __syncthreads();
+    }
+}
+
 // How many workgroups share one column group in a relax round of nS entries.
 __device__ __forceinline__ int ms_split(int nS, int n_groups, int blocks) {
     if (nS <= MS_SPLIT_MIN) return 1;
@@ -628,7 +672,8 @@ __global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgW
     if (mode == MODE_AUCTION || mode == MODE_ARR) {
         wide_bid(M, w, st, wave_gid, n_waves, pre_i, stage_p, n_host, st_nU, st_eps, pst0, pst1, pst2, pst3, t_kernel_entry);
     } else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i, sh_r);
-    else if (mode == MODE_UMIN) wide_umin(M, w, st, wave_gid, n_waves, false);
+    else if (mode == MODE_UMIN || mode == MODE_UMIN0) wide_umin(M, w, st, wave_gid, n_waves, false);
+    else if (mode == MODE_INITRED) wide_initred(M, w, st, sh_d, n_host);
     else if (mode == MODE_ROOTMIN) wide_umin(M, w, st, wave_gid, n_waves, true);
     else if (mode == MODE_COLRED) wide_colred(M, w, st, sh_d);
     else if (mode == MODE_CERT) wide_cert(M, w, st, wave_gid, n_waves);
@@ -974,9 +1019,19 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
             st->eps = cr * st->eps;          // eps/eps_last hold the fractions on entry
             st->eps_last = cr * st->eps_last;
             st->stop = (int)(st->stop_frac * n);
-            st->mode = MODE_AUCTION; st->phase = 0;
+            st->mode = MODE_UMIN0; st->phase = 0;
         }
-        for (int k = threadIdx.x; k < n; k += CT) w.p[k] = 0.0;
+        for (int k = threadIdx.x; k < n; k += CT) { w.p[k] = 0.0; w.packed[k] = 0ull; }
+        return;
+    }
+    if (mode == MODE_UMIN0) {          // bidval[i] = min_j c_ij
+        if (threadIdx.x == 0) { st->mode = MODE_INITRED; st->st_total_row_scans += n; }
+        return;
+    }
+    if (mode == MODE_INITRED) {        // packed[k] = ordered max_i (u_i - c_ik)
+        for (int k = threadIdx.x; k < n; k += CT) w.p[k] = ord2d(w.packed[k]);
+        __syncthreads();
+        if (threadIdx.x == 0) { st->mode = MODE_AUCTION; st->st_total_row_scans += n; }
         ctrl_reset_assignment(w, st);
         return;
     }
