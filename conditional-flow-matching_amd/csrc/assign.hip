@@ -312,11 +312,15 @@ __device__ __forceinline__ void bid_commit(const AsgWs& w, Top2 best, int i, dou
 // is requested BEFORE the prices are written to LDS and the workgroup barrier, so the staging
 // hides behind the row's latency.
 __device__ __forceinline__ void wide_bid(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
-                         int wave_gid, int n_waves, int pre_a, bool stage_p, int n_host, int nU, double eps,
+                         int wave_gid, int n_waves, int pre_a, bool stage_p, int n_host,
                          double2 pst0, double2 pst1, double2 pst2, double2 pst3, long long t_entry) {
     extern __shared__ __attribute__((aligned(16))) char wide_lds_bid[];   // = the kernel's dynamic LDS
     double* p_lds = reinterpret_cast<double*>(wide_lds_bid);
     const int n = n_host;
+    const double eps = st->eps;        // same 128-byte line as st->mode: an L1 hit by now
+#ifdef BID_PROFILE
+    const int nU = st->nU;
+#endif
     const int lane = threadIdx.x & 63;
     const bool vec = ((n & 3) == 0);
     const bool fast = stage_p && (n & 4095) == 0;
@@ -665,12 +669,10 @@ __global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgW
     }
     int pre_i = (wave_gid < n_host) ? w.a[wave_gid] : 0;
     int mode = st->mode;
-    int st_nU = st->nU;
-    double st_eps = st->eps;
-    asm volatile("" : "+v"(pre_i), "+v"(pst0.x), "+v"(pst1.x), "+v"(pst2.x), "+v"(pst3.x) : "s"(mode), "s"(st_nU), "s"(st_eps) : "memory");   // all of it in flight
+    asm volatile("" : "+v"(pre_i), "+v"(pst0.x), "+v"(pst1.x), "+v"(pst2.x), "+v"(pst3.x) : "s"(mode) : "memory");   // all of it in flight
     if (mode == MODE_DONE || st->error) return;
     if (mode == MODE_AUCTION || mode == MODE_ARR) {
-        wide_bid(M, w, st, wave_gid, n_waves, pre_i, stage_p, n_host, st_nU, st_eps, pst0, pst1, pst2, pst3, t_kernel_entry);
+        wide_bid(M, w, st, wave_gid, n_waves, pre_i, stage_p, n_host, pst0, pst1, pst2, pst3, t_kernel_entry);
     } else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i, sh_r);
     else if (mode == MODE_UMIN || mode == MODE_UMIN0) wide_umin(M, w, st, wave_gid, n_waves, false);
     else if (mode == MODE_INITRED) wide_initred(M, w, st, sh_d, n_host);
