@@ -82,6 +82,34 @@ def assign_exact(M, return_info=False):
     return (perm, info) if return_info else perm
 
 
+_RECT_EXACT_MAX = 8192   # largest lcm(B0, B1) the rectangular exact path expands to
+
+
+def exact_plan_rect(M):
+    """Exact OT plan between uniform marginals of DIFFERENT sizes (what pot.emd returns for
+    x0.shape[0] != x1.shape[0], ref:49,79,87) as a device fp64 [B0,B1] tensor, with its cost.
+
+    With L = lcm(B0, B1) every source carries L/B0 units and every target L/B1 units of mass 1/L,
+    so the transportation problem is the L x L assignment problem on the cost matrix with rows /
+    columns repeated; the device assignment solver does the work, the expansion / folding are
+    index plumbing.  The optimal COST is unique; the plan need not be (neither is POT's)."""
+    B0, B1 = M.shape
+    L = B0 * B1 // math.gcd(B0, B1)
+    if L > _RECT_EXACT_MAX:
+        raise NotImplementedError(
+            f"exact OT between batches of {B0} and {B1} samples expands to an assignment problem of "
+            f"size lcm = {L} > {_RECT_EXACT_MAX}; use equal batch sizes (or sizes with a small lcm)")
+    dev = M.device
+    ri = torch.arange(B0, device=dev).repeat_interleave(L // B0)
+    ci = torch.arange(B1, device=dev).repeat_interleave(L // B1)
+    Mx = M[ri][:, ci].contiguous()
+    perm, info = assign_exact(Mx, return_info=True)
+    pi = torch.zeros((B0, B1), dtype=torch.float64, device=dev)
+    pi.index_put_((ri, ci[perm.long()]), torch.full((L,), 1.0 / L, dtype=torch.float64, device=dev),
+                  accumulate=True)
+    return pi, info["total_cost"] / L
+
+
 class SinkhornResult:
     __slots__ = ("f", "g", "iters", "err", "ws", "reg", "M")
 
@@ -241,6 +269,10 @@ class OTPlanSampler:
             self._last = info
             return "plan", plan, M
         if self.method == "exact":
+            if M.shape[0] != M.shape[1]:
+                plan, _ = exact_plan_rect(M)
+                self._last = torch.zeros(4, dtype=torch.int32)
+                return "plan", plan, M
             perm, info = assign_exact(M, return_info=True)
             self._last = info
             return "perm", perm, M
@@ -432,7 +464,9 @@ def wasserstein(
     a = _lib.to_dev_f32(_flatten2(x0), dev)
     b = _lib.to_dev_f32(_flatten2(x1), dev)
     M = cost_matrix(a, b, squared=(power == 2))
-    if exact:
+    if exact and M.shape[0] != M.shape[1]:
+        _, ret = exact_plan_rect(M)
+    elif exact:
         perm, info = assign_exact(M, return_info=True)
         ret = info["total_cost"] / M.shape[0]
     else:

@@ -121,6 +121,22 @@ def exact_perm(M):
     return c.astype(np.int64)
 
 
+def exact_plan_rect(M):
+    """pot.emd(unif(B0), unif(B1), M) for B0 != B1 (optimal_transport.py:49,79,87): the
+    transportation problem with masses 1/B0, 1/B1 is the assignment problem on the cost matrix
+    expanded to lcm(B0, B1) unit masses; solved with SciPy's LSAP in float64.  Returns (plan, cost);
+    the cost is unique, the plan need not be."""
+    M = np.asarray(M, dtype=np.float64)
+    B0, B1 = M.shape
+    L = B0 * B1 // math.gcd(B0, B1)
+    ri = np.repeat(np.arange(B0), L // B0)
+    ci = np.repeat(np.arange(B1), L // B1)
+    r, c = linear_sum_assignment(M[ri][:, ci])
+    pi = np.zeros((B0, B1))
+    np.add.at(pi, (ri[r], ci[c]), 1.0 / L)
+    return pi, float((pi * M).sum())
+
+
 def perm_plan(perm):
     """pot.emd's plan for uniform equal marginals: 1/B on the optimal permutation."""
     B = len(perm)

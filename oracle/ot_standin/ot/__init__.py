@@ -23,8 +23,10 @@ def unif(n, type_as=None):
 
 def emd(a, b, M, numItermax=100000, log=False, center_dual=True, numThreads=1, **kw):
     a, b, M = np.asarray(a, np.float64), np.asarray(b, np.float64), np.asarray(M, np.float64)
-    if len(a) != len(b) or not (np.allclose(a, a[0]) and np.allclose(b, b[0])):
-        raise NotImplementedError("ot stand-in: emd supports uniform equal-size marginals only")
+    if not (np.allclose(a, a[0]) and np.allclose(b, b[0])):
+        raise NotImplementedError("ot stand-in: emd supports uniform marginals only")
+    if len(a) != len(b):
+        return _o.exact_plan_rect(M)[0] * a.sum()
     return _o.perm_plan(_o.exact_perm(M)) * a.sum()
 
 

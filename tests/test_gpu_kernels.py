@@ -192,6 +192,37 @@ def test_assign_degenerate_costs(dev):
         ot.assign_exact(torch.zeros(4, 5, device=dev))
 
 
+@pytest.mark.parametrize("B0,B1", [(128, 64), (96, 64), (60, 100), (7, 3)])
+def test_exact_rectangular_plan(dev, B0, B1):
+    """Unequal batch sizes (pot.emd on unif(B0), unif(B1), ref:49,79): the plan is a transportation
+    plan, not a permutation.  The optimal cost is unique (checked against SciPy on the lcm-expanded
+    matrix built from the SAME fp32 costs); the plan itself must be feasible."""
+    from cfm_amd.optimal_transport import OTPlanSampler, wasserstein
+    ot = _ot()
+    x0, x1 = _rand(B0, 3, 11), _rand(B1, 3, 12, scale=1.3) + 0.4
+    M = ot.cost_matrix(x0.to(dev), x1.to(dev))
+    s = OTPlanSampler(method="exact")
+    pi = s.get_map(x0, x1)
+    assert pi.shape == (B0, B1) and pi.dtype == np.float64
+    assert np.abs(pi.sum(1) - 1.0 / B0).max() < 1e-12 and np.abs(pi.sum(0) - 1.0 / B1).max() < 1e-12
+    Mnp = M.cpu().numpy().astype(np.float64)
+    ref_pi, ref_cost = oracle.exact_plan_rect(Mnp)
+    assert abs((pi * Mnp).sum() - ref_cost) <= 1e-12 * max(1.0, abs(ref_cost))
+    assert abs(wasserstein(x0, x1, "exact") - np.sqrt(ref_cost)) <= 1e-9 * np.sqrt(ref_cost)
+    np.random.seed(2)
+    a, b = s.sample_plan(x0, x1)
+    assert a.shape == x0.shape and b.shape == (B0,) + tuple(x1.shape[1:])
+    np.random.seed(2)
+    i, j = s.sample_map(pi, B0)
+    assert torch.equal(a, x0[i]) and torch.equal(b, x1[j])
+
+
+def test_exact_rectangular_large_lcm_refused(dev):
+    from cfm_amd.optimal_transport import OTPlanSampler
+    with pytest.raises(NotImplementedError):
+        OTPlanSampler(method="exact").get_map(_rand(127, 2, 1), _rand(128, 2, 2))
+
+
 # ------------------------------------------------------------------ K6 sampling
 @pytest.mark.parametrize("B", [100, 128, 1000, 1023, 4096])
 def test_sample_perm_bit_exact(dev, B):

@@ -194,3 +194,19 @@ def test_partial_vector_form_equals_matrix_form():
         al, be, sig = a2 * (sig * s), b2, 1.0 / s
     P = al[:, None] * K0 * be[None, :]
     assert np.abs(P - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_rectangular_exact_oracle_is_a_transport_plan():
+    rng = np.random.default_rng(3)
+    M = rng.uniform(0, 2, size=(6, 4))
+    pi, cost = oracle.exact_plan_rect(M)
+    assert np.allclose(pi.sum(1), 1 / 6) and np.allclose(pi.sum(0), 1 / 4)
+    # brute-force check against a tiny LP (scipy.optimize.linprog, HiGHS)
+    from scipy.optimize import linprog
+    A = np.zeros((10, 24))
+    for i in range(6):
+        A[i, i * 4:(i + 1) * 4] = 1
+    for j in range(4):
+        A[6 + j, j::4] = 1
+    res = linprog(M.ravel(), A_eq=A, b_eq=np.r_[np.full(6, 1 / 6), np.full(4, 1 / 4)], bounds=(0, None))
+    assert abs(res.fun - cost) < 1e-10
