@@ -1181,7 +1181,9 @@ __global__ void asg_trivial(const float* M, int n, int* perm, int* certified, do
     }
 }
 
-static int* g_pinned = nullptr;
+// poll buffer (pinned host memory): one per host thread, concurrent solves on different streams
+// must not share it
+static thread_local int* g_pinned = nullptr;
 
 static int asg_run(const float* M, int B, int* perm, int* certified, double* total_cost, int* stats,
                    void* ws, void* stream, int use_sparse, int* cert_out) {
