@@ -113,7 +113,11 @@ def main():
     from cfm_amd.conditional_flow_matching import ExactOptimalTransportConditionalFlowMatcher
     import cfm_amd.optimal_transport as ot
 
-    _lib.load()
+    lib_ = _lib.load()
+    if os.environ.get("CFM_ASG_BLOCKS"):     # experiment knob: grid cap of the assignment's wide kernel
+        lib_.cfm_assign_set_wide_blocks(int(os.environ["CFM_ASG_BLOCKS"]))
+    if os.environ.get("CFM_ASG_DENSE"):      # experiment knob: no candidate-list solver (small LDS launches)
+        lib_.cfm_assign_set_mode(0)
     rank, local, world = D.init_from_env()
     if world != args.gpus and rank == 0:
         print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)

@@ -69,6 +69,7 @@ EXTRA_SIGNATURES = {
     "cfm_assign_set_params": (None, [_d, _d, _d, _d, _i, _i, _i]),
     "cfm_assign_set_mode": (None, [_i]),
     "cfm_assign_set_handoff": (None, [_i]),
+    "cfm_assign_set_wide_blocks": (None, [_i]),
     "cfm_assign_set_ms_quantile": (None, [_d]),
     "cfm_plan_zero_entries_f64": (_i, [_vp, _vp, _i, _vp]),
 }

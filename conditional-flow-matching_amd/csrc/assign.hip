@@ -76,11 +76,19 @@ extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps
 }
 
 extern "C" void cfm_assign_set_mode(int sparse) { g_params.sparse = sparse ? 1 : 0; }
+// Upper bound on the workgroups of asg_wide (0 = none).  The kernel runs one 1024-thread workgroup
+// per CU (128 VGPRs), so a 256-workgroup launch needs the whole chip; with several couplings in
+// flight on different streams a smaller grid lets their kernels run side by side.
+static int g_wide_blocks_cap = 0;
+extern "C" void cfm_assign_set_wide_blocks(int cap) { g_wide_blocks_cap = cap > 0 ? cap : 0; }
 extern "C" void cfm_assign_set_handoff(int handoff) { if (handoff >= 0) g_params.handoff = handoff; }
 extern "C" void cfm_assign_set_ms_quantile(double q) { if (q > 0.0 && q <= 1.0) g_params.ms_q = q; }
 
 struct AsgState {
     int mode, n, phase, round;
+    // [offset 16] the cost matrix: kernels take it from here (same cache line as `mode`) so that their
+    // launch arguments depend on the workspace only and the kernel pairs can be replayed as a hipGraph
+    const float* Mptr;
     int nU, stop, arr_round, error;
     int nF, fidx, i0, nS;
     int jfree, certified, cert_bad, nN;
@@ -122,6 +130,8 @@ struct AsgWs {
     int* listFC;      // free columns during SAP
     int* pred;
     int* tcol;        // per tree: accepted free column of the phase (or -1)
+    int* out_perm;    // [n] result, exported to the caller's buffers once the solve is done
+    int* out_misc;    // [16]: certified, stats[8], pad, total_cost (double at [12])
     double* part_d;   // [MS_YMAX][n] partial minima of a split relax round
     int* part_i;      // [MS_YMAX][n] their rows
     int* part_r;      // [MS_YMAX][n] their trees
@@ -147,7 +157,7 @@ __device__ __forceinline__ SList slist(const AsgWs& w, int c) {
 static inline size_t asg_ws_bytes(int n) {
     size_t N = (size_t)n;
     size_t lists = (n <= 4096) ? N * 64 * 8 + 8 * N : 0;
-    return 512 + 8 * N * (4 + 4) + 4 * N * (8 + 6) + 16 * N * MS_YMAX + lists + 256;
+    return 512 + 8 * N * (4 + 4) + 4 * N * (9 + 6) + 64 + 16 + 16 * N * MS_YMAX + lists + 256;
 }
 
 static inline AsgWs asg_carve(void* ws, int n) {
@@ -169,6 +179,9 @@ static inline AsgWs asg_carve(void* ws, int n) {
     for (int c = 0; c < 2; ++c) {
         w.S[c].col = (int*)q; q += 4 * N; w.S[c].row = (int*)q; q += 4 * N; w.S[c].root = (int*)q; q += 4 * N;
     }
+    w.out_perm = (int*)q; q += 4 * N;
+    w.out_misc = (int*)q; q += 64;
+    q = (char*)(((uintptr_t)q + 15) & ~(uintptr_t)15);
     w.part_d = (double*)q; q += 8 * N * MS_YMAX;
     w.part_i = (int*)q; q += 4 * N * MS_YMAX;
     w.part_r = (int*)q; q += 4 * N * MS_YMAX;
@@ -641,7 +654,7 @@ __device__ __forceinline__ void wide_cert(const float* __restrict__ M, const Asg
 
 #include "assign_sparse.h"
 
-__global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgWs w, int n_host) {
+__global__ __launch_bounds__(WT) void asg_wide(AsgWs w, int n_host) {
     extern __shared__ __attribute__((aligned(16))) char wide_lds[];   // modes are exclusive
     double* sh_d = reinterpret_cast<double*>(wide_lds);
     int* sh_i = reinterpret_cast<int*>(wide_lds + sizeof(double) * WT);
@@ -669,6 +682,7 @@ __global__ __launch_bounds__(WT) void asg_wide(const float* __restrict__ M, AsgW
     }
     int pre_i = (wave_gid < n_host) ? w.a[wave_gid] : 0;
     int mode = st->mode;
+    const float* __restrict__ M = st->Mptr;
     asm volatile("" : "+v"(pre_i), "+v"(pst0.x), "+v"(pst1.x), "+v"(pst2.x), "+v"(pst3.x) : "s"(mode) : "memory");   // all of it in flight
     if (mode == MODE_DONE || st->error) return;
     if (mode == MODE_AUCTION || mode == MODE_ARR) {
@@ -997,8 +1011,7 @@ __device__ void ctrl_enter_cert(AsgState* st) {
     }
 }
 
-__global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgWs w, int* perm,
-                                               int* certified, double* total_cost, int* stats) {
+__global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
     extern __shared__ __attribute__((aligned(16))) int dyn[];   // 2*n ints for the path walk
     __shared__ int sh[32];
     __shared__ double shd[32];
@@ -1006,6 +1019,11 @@ __global__ __launch_bounds__(CT) void asg_ctrl(const float* __restrict__ M, AsgW
     AsgState* st = w.st;
     const int n = st->n;
     int mode = st->mode;
+    const float* __restrict__ M = st->Mptr;
+    int* perm = w.out_perm;
+    int* certified = w.out_misc;
+    int* stats = w.out_misc + 1;
+    double* total_cost = reinterpret_cast<double*>(w.out_misc + 12);
     const bool use_lds = (n <= 6144);
     if (mode == MODE_DONE || st->error) return;
     __syncthreads();
@@ -1181,6 +1199,33 @@ __global__ void asg_trivial(const float* M, int n, int* perm, int* certified, do
     }
 }
 
+// copy the workspace-resident results to the caller's buffers
+__global__ void asg_export(AsgWs w, int n, int* perm, int* certified, double* total_cost, int* stats) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) perm[i] = w.out_perm[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (certified) *certified = w.out_misc[0];
+        if (total_cost) *total_cost = *reinterpret_cast<const double*>(w.out_misc + 12);
+        if (stats) for (int k = 0; k < 8; ++k) stats[k] = w.out_misc[1 + k];
+    }
+}
+
+// The (asg_wide, asg_ctrl) pairs take only workspace-derived arguments, so a chunk of them is
+// captured once per host thread / workspace into a hipGraph and replayed: a solve is ~400 kernel
+// launches, and with several couplings in flight on different streams the host launch rate
+// (~2.7 us per launch across threads) was the limit.  Falls back to plain launches when the stream
+// cannot be captured (the legacy default stream) or CFM_ASG_GRAPH=0.
+struct AsgGraph {
+    void* ws = nullptr; int n = 0, pairs = 0; size_t wide_dyn = 0;
+    hipGraphExec_t exec = nullptr; hipStream_t stream = nullptr; int disabled = 0;
+};
+static thread_local AsgGraph g_graph;
+
+static int asg_graph_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CFM_ASG_GRAPH"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
 // poll buffer (pinned host memory): one per host thread, concurrent solves on different streams
 // must not share it
 static thread_local int* g_pinned = nullptr;
@@ -1204,12 +1249,13 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     }
     int wide_blocks = (n + 15) / 16;        // one wave per row when everything bids
     if (wide_blocks > 512) wide_blocks = 512;
+    if (g_wide_blocks_cap > 0 && wide_blocks > g_wide_blocks_cap) wide_blocks = g_wide_blocks_cap;
     if (wide_blocks < (n + 63) / 64) wide_blocks = (n + 63) / 64;
     if (wide_blocks < 1) wide_blocks = 1;
     AsgState h;
     memset(&h, 0, sizeof(h));
     h.wide_blocks = wide_blocks;
-    h.mode = MODE_INIT; h.n = n;
+    h.mode = MODE_INIT; h.n = n; h.Mptr = M;
     h.eps = g_params.eps0_frac; h.eps_last = g_params.eps_last_frac; h.theta = g_params.theta;
     h.stop_frac = g_params.stop_frac; h.round_cap = g_params.round_cap; h.arr_cap = g_params.arr_cap;
     h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
@@ -1236,31 +1282,65 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     hipLaunchKernelGGL(asg_minmax, dim3(mm_blocks), dim3(256), 0, s, M, n2, w.st);
     // path walks in LDS (2 n ints, n <= 6144); never less than the 1024 doubles of ctrl_radius
     const size_t dyn = (n <= 6144) ? (size_t)2 * n * sizeof(int) : (size_t)CT * sizeof(double);
-    hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, M, w, perm, certified, total_cost, stats);
+    hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, w);
     rc = cfm_status();
     if (rc) return rc;
+
+    // one hipGraph of `chunk` pairs per (thread, workspace, n), replayed
+    const int gchunk = g_params.chunk;
+    AsgGraph& G = g_graph;
+    bool use_graph = asg_graph_enabled() && !G.disabled && n >= 256;
+    if (use_graph && !(G.exec && G.ws == ws && G.n == n && G.pairs == gchunk && G.wide_dyn == wide_dyn && G.stream == s)) {
+        if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            for (int c = 0; c < gchunk; ++c) {
+                hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), wide_dyn, s, w, n);
+                hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, w);
+            }
+            e = hipStreamEndCapture(s, &graph);
+            if (e == hipSuccess && graph) e = hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        if (e != hipSuccess || !G.exec) {
+            (void)hipGetLastError();
+            G.exec = nullptr; G.disabled = 1; use_graph = false;     // e.g. the legacy default stream
+        } else {
+            G.ws = ws; G.n = n; G.pairs = gchunk; G.wide_dyn = wide_dyn; G.stream = s;
+        }
+    }
 
     int pairs = 0;
     for (;;) {
         // a typical solve needs 150 - 300 pairs: enqueue most of them before the first poll
-        const int chunk = (pairs == 0 && n >= 1024) ? 3 * g_params.chunk : g_params.chunk;
-        for (int c = 0; c < chunk; ++c) {
-            hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), wide_dyn, s, M, w, n);
-            hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, M, w, perm, certified, total_cost, stats);
+        const int reps = (pairs == 0 && n >= 1024) ? 3 : 1;
+        for (int r = 0; r < reps; ++r) {
+            if (use_graph) {
+                rc = cfm_hip(hipGraphLaunch(G.exec, s));
+                if (rc) return rc;
+            } else {
+                for (int c = 0; c < gchunk; ++c) {
+                    hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), wide_dyn, s, w, n);
+                    hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, w);
+                }
+            }
         }
-        pairs += chunk;
+        pairs += reps * gchunk;
         rc = cfm_status();
         if (rc) return rc;
         rc = cfm_hip(hipMemcpyAsync(g_pinned, w.st, 64, hipMemcpyDeviceToHost, s));
         if (rc) return rc;
         rc = cfm_hip(hipStreamSynchronize(s));
         if (rc) return rc;
-        const int mode = g_pinned[0], err = g_pinned[7];
+        const int mode = g_pinned[0], err = g_pinned[9];
         if (err) return CFM_ENOCONV;
-        if (mode == MODE_DONE) { if (cert_out) *cert_out = g_pinned[13]; break; }
+        if (mode == MODE_DONE) { if (cert_out) *cert_out = g_pinned[15]; break; }
         if (pairs >= g_params.max_pairs) return CFM_ETIMEOUT;
     }
-    return 0;
+    hipLaunchKernelGGL(asg_export, dim3((n + 1023) / 1024 < 64 ? (n + 1023) / 1024 : 64), dim3(1024), 0, s, w, n,
+                       perm, certified, total_cost, stats);
+    return cfm_status();
 }
 
 extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,

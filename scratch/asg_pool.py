@@ -16,6 +16,10 @@ if len(sys.argv)>3: lib.cfm_assign_set_params(theta,0.0,elast,stop,0,int(sys.arg
 import cfm_oracle as oracle
 if os.environ.get('MSQ'): lib.cfm_assign_set_ms_quantile(float(os.environ['MSQ']))
 pool=bench.synth_batches(4096,784,nb,1000,dev)
+side=torch.cuda.Stream() if os.environ.get('SIDE') else torch.cuda.current_stream()
+torch.cuda.synchronize()
+ctx=torch.cuda.stream(side)
+ctx.__enter__()
 for k,(x0,x1) in enumerate(pool):
     M=ot.cost_matrix(x0,x1)
     for r in range(2):
