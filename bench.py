@@ -214,7 +214,10 @@ def main():
     scans = [s[5] for s in stats_log]
     # algorithmic bytes of the assignment: every row scan reads one fp32 cost row + the fp64 prices
     asg_bytes = [sc * (4 * B + 8 * B) for sc in scans]
-    asg_gbs = sum(asg_bytes) / (sum(asg_ms) * 1e-3) / 1e9 if asg_ms else 0.0
+    asg_gbs_solve = sum(asg_bytes) / (sum(asg_ms) * 1e-3) / 1e9 if asg_ms else 0.0
+    # with several couplings in flight the solves overlap in time: the rate the chip sustains on this
+    # kernel family is all their bytes over the wall time of the timed region (model steps included)
+    asg_gbs = sum(asg_bytes) / elapsed / 1e9 if (args.pipeline and asg_ms) else asg_gbs_solve
     out = {
         "metric": "OT-CFM train-step samples/sec (B=4096,d=784)", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -228,10 +231,13 @@ def main():
                    "parallelism": f"dp{world}" if world > 1 else "single"},
         "roofline": {"bound": "hbm", "achieved": asg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": asg_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "per_solve_GBps": asg_gbs_solve,
                      "kernel": "asg_wide+asg_ctrl (cfm_assign_exact_f32)",
                      "note": "algorithmic bytes = row scans x (4B cost row + 8B prices); irregular, latency-bound; "
-                             "durations are per solve (HIP events on the solve's stream) and overlap in time when "
-                             "several couplings are in flight"},
+                             "achieved = bytes of all solves / wall time of the timed region when couplings are "
+                             "pipelined (solves overlap in time), per_solve_GBps = bytes / HIP-event duration of a "
+                             "solve on its own stream; traffic: see profiles/*pmc_FETCH_SIZE.csv (x2-corrected "
+                             "fetch 1.8 GB per solve < 5.5 GB algorithmic: rows are re-read from L2 / MALL)"},
         "assign_ms_per_step": float(np.mean(asg_ms)) if asg_ms else None,
         "ms_per_step_sequential": seq_ms,
         "assign_stats_mean": [float(x) for x in np.mean(np.array(stats_log), axis=0)] if stats_log else None,
