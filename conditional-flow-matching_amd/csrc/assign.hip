@@ -858,26 +858,38 @@ __device__ void ctrl_ms_begin(const AsgWs& w, AsgState* st) {
 
 // A split relax round left Y partial minima per column: merge (ties -> lowest row, as inside a
 // workgroup), lower the label, list the improved assigned columns.
-__device__ void ctrl_ms_merge(const float* __restrict__ M, const AsgWs& w, AsgState* st, int Y) {
+__device__ void ctrl_ms_merge(const float* __restrict__ M, const AsgWs& w, AsgState* st, int Y, int* sh) {
     const int n = st->n, cur = st->cur;
     const double dfree = st->dfree;
     const SList Nx = slist(w, cur ^ 1);
-    for (int k = threadIdx.x; k < n; k += CT) {
-        double best = w.part_d[k]; int bi = w.part_i[k], br = w.part_r[k];
-        for (int y = 1; y < Y; ++y) {
-            const double c2 = w.part_d[(size_t)y * n + k]; const int i2 = w.part_i[(size_t)y * n + k];
-            if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = w.part_r[(size_t)y * n + k]; }
-        }
-        if (best < w.dist[k]) {
-            w.dist[k] = best; w.pred[k] = bi;
-            const int ow = w.owner[k];
-            if (ow >= 0 && best < dfree) {
-                const int idx = atomicAdd(&st->nN, 1);
-                Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = br;
-                Nx.rj[idx] = (double)M[(size_t)ow * n + k] + w.p[k];
+    int base = st->nN;                         // 0: a split round appends nothing itself
+    for (int k0 = 0; k0 < n; k0 += CT) {
+        const int k = k0 + threadIdx.x;
+        int f = 0, ow = -1, br = -1; double best = INFINITY, pk = 0.0;
+        if (k < n) {
+            best = w.part_d[k]; int bi = w.part_i[k]; br = w.part_r[k];
+            for (int y = 1; y < Y; ++y) {
+                const double c2 = w.part_d[(size_t)y * n + k]; const int i2 = w.part_i[(size_t)y * n + k];
+                if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = w.part_r[(size_t)y * n + k]; }
+            }
+            if (best < w.dist[k]) {
+                w.dist[k] = best; w.pred[k] = bi;
+                ow = w.owner[k]; pk = w.p[k];
+                f = (ow >= 0 && best < dfree) ? 1 : 0;
             }
         }
+        // order-preserving compaction of the improved assigned columns (a block scan instead of
+        // thousands of same-address atomics from one workgroup)
+        int tot;
+        const int off = block_scan_excl(f, &tot, sh);
+        if (f) {
+            const int idx = base + off;
+            Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = br;
+            Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
+        }
+        base += tot;
     }
+    if (threadIdx.x == 0) st->nN = base;
     __syncthreads();
 }
 
@@ -1150,7 +1162,7 @@ __global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
         __syncthreads();
         if (threadIdx.x == 0) { st->st_sap_batches++; st->st_sap_row_scans += scanned; st->st_total_row_scans += scanned; }
         const int Y = ms_split(scanned, (n + 63) / 64, st->wide_blocks);
-        if (Y > 1) ctrl_ms_merge(M, w, st, Y);
+        if (Y > 1) ctrl_ms_merge(M, w, st, Y, sh);
         if (ctrl_sap_step(w, st, shd, shi, reinterpret_cast<double*>(dyn))) return;
         // converged below the radius: accept one path per tree
         ctrl_ms_finish(w, st, dyn, dyn + n, use_lds, shd, shi, sh);
