@@ -416,27 +416,69 @@ class OTPlanSampler:
             gather_rows(y1.detach().to(dev), j).to(y1.device) if y1 is not None else None,
         )
 
+    def _solve_many(self, pairs, workers=3):
+        """Solve independent couplings concurrently: one host thread + one HIP stream per worker
+        (the exact solver is a chain of small latency-bound kernels; three in flight double the
+        throughput).  Returns the ``_solve`` results in order, usable on the caller's stream."""
+        import concurrent.futures as cf
+        import threading
+        dev = _lib.require_gpu()
+        if len(pairs) <= 1 or workers <= 1:
+            return [self._solve(a, b) for a, b in pairs]
+        tls = threading.local()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        last = self._last
+
+        def work(a, b):
+            torch.cuda.set_device(dev)
+            if not hasattr(tls, "stream"):
+                tls.stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(tls.stream):
+                tls.stream.wait_event(ready)
+                out = self._solve(a, b)
+                done = torch.cuda.Event()
+                done.record(tls.stream)
+            return out, done
+
+        with cf.ThreadPoolExecutor(max_workers=min(workers, len(pairs))) as pool:
+            res = list(pool.map(lambda ab: work(*ab), pairs))
+        cur = torch.cuda.current_stream(dev)
+        outs = []
+        for out, done in res:
+            cur.wait_event(done)
+            outs.append(out)
+        self._last = last
+        return outs
+
     def sample_trajectory(self, X):
         """OT trajectories across consecutive time slices (ref:221-251).
 
-        One plan per pair of slices (device solve); the per-row draws consume the global
-        ``np.random`` stream exactly like the reference's per-row ``np.random.choice(p=pi[i])``.
+        The times-1 couplings are independent of each other, so they are solved concurrently on
+        side streams (SURVEY §8f "multi-marginal batching") and stay on the device; only the
+        per-row draws are chained in time order, consuming the global ``np.random`` stream exactly
+        like the reference's per-row ``np.random.choice(p=pi[i] / pi[i].sum())`` (one uniform per
+        row, rows in order, slices in order).
         """
         times = X.shape[1]
         dev = _lib.require_gpu()
-        indices = [np.arange(X.shape[0])]
-        for t in range(times - 1):
-            pi = self.get_map(X[:, t], X[:, t + 1])
-            B1 = pi.shape[1]
-            rows = indices[-1]
-            # row-conditional plan: pi[i] / pi[i].sum(); one uniform per row, in row order
-            u = np.random.random_sample(len(rows))
-            sub = np.ascontiguousarray(pi[rows])
-            sub = sub / sub.sum(axis=1, keepdims=True)
-            # flattened cdf trick: row r occupies [r, r+1) after adding r to its cdf
-            flat_u = (np.arange(len(rows)) + u) / len(rows)
-            pi_dev = torch.from_numpy(sub / len(rows)).to(dev)
-            _, j = sample_pi(pi_dev, _u01_to_device(flat_u, dev))
+        n = X.shape[0]
+        sols = self._solve_many([(X[:, t], X[:, t + 1]) for t in range(times - 1)])
+        indices = [np.arange(n)]
+        for kind, sol, M in sols:
+            rows = torch.from_numpy(np.ascontiguousarray(indices[-1])).to(dev)
+            u = np.random.random_sample(len(indices[-1]))
+            if kind == "perm":
+                # a permutation plan: row i has the single nonzero pi[i, perm[i]] (the draw is consumed)
+                j = sol.long()[rows]
+            else:
+                plan = sinkhorn_plan(sol) if kind == "dense" else sol
+                sub = plan[rows]
+                sub = sub / sub.sum(dim=1, keepdim=True)
+                # flattened cdf trick: row r occupies [r, r+1) / len after scaling by 1 / len
+                m = sub.shape[0]
+                flat_u = (np.arange(m) + u) / m
+                _, j = sample_pi((sub / m).contiguous(), _u01_to_device(flat_u, dev))
             indices.append(j.cpu().numpy())
         to_return = []
         for t in range(times):

@@ -104,3 +104,23 @@ def test_sample_trajectory_shape_and_rng(golden_dir):
         perm = oracle.exact_perm(oracle.ref_cost_f32(X[:, t], X[:, t + 1]))
         idx = perm[idx]
         assert np.array_equal(out[:, t + 1], X[:, t + 1].numpy()[idx])
+
+
+def test_sample_trajectory_sinkhorn_matches_host_chain():
+    """Entropic plans: the concurrent, device-resident chain draws the same indices as the
+    reference's loop (get_map per slice, then np.random.choice(p=pi[i] / pi[i].sum()) per row)
+    run on the plans this backend returns."""
+    from cfm_amd.optimal_transport import OTPlanSampler
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(64, 4, 3, generator=g)
+    s = OTPlanSampler(method="sinkhorn", reg=1.0)
+    np.random.seed(1)
+    out = s.sample_trajectory(X)
+    np.random.seed(1)
+    idx = [np.arange(64)]
+    for t in range(3):
+        pi = s.get_map(X[:, t], X[:, t + 1])
+        idx.append(np.array([np.random.choice(64, p=pi[i] / pi[i].sum()) for i in idx[-1]]))
+    ref = np.stack([X[:, t].numpy()[idx[t]] for t in range(4)], axis=1)
+    assert out.shape == (64, 4, 3)
+    assert np.array_equal(out, ref)
