@@ -116,6 +116,8 @@ def main():
     lib_ = _lib.load()
     if os.environ.get("CFM_ASG_BLOCKS"):     # experiment knob: grid cap of the assignment's wide kernel
         lib_.cfm_assign_set_wide_blocks(int(os.environ["CFM_ASG_BLOCKS"]))
+    if os.environ.get("CFM_ASG_STOPE"):
+        lib_.cfm_assign_set_stop_early(float(os.environ["CFM_ASG_STOPE"]))
     if os.environ.get("CFM_ASG_DENSE"):      # experiment knob: no candidate-list solver (small LDS launches)
         lib_.cfm_assign_set_mode(0)
     rank, local, world = D.init_from_env()

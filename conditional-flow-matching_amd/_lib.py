@@ -71,6 +71,7 @@ EXTRA_SIGNATURES = {
     "cfm_assign_set_handoff": (None, [_i]),
     "cfm_assign_set_wide_blocks": (None, [_i]),
     "cfm_assign_set_ms_quantile": (None, [_d]),
+    "cfm_assign_set_stop_early": (None, [_d]),
     "cfm_plan_zero_entries_f64": (_i, [_vp, _vp, _i, _vp]),
 }
 

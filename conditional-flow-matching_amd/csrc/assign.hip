@@ -60,9 +60,11 @@ struct AsgParams {
     int sparse;            // 1: the last free rows go to the one-workgroup candidate-list solver (n <= 4096)
     int handoff;           // ... once at most this many free rows are left
     double ms_q;           // radius of a multi-source phase: quantile of the free-column labels
+    double stop_early;     // stop_frac of every epsilon phase but the last (0 = same as stop_frac; a looser
+                           // cut saves auction rounds but measured slower overall: 5.9 vs 4.8 ms at 0.05)
 };
 
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 64, 400000, 1, 6, 1.0};
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 64, 400000, 1, 6, 1.0, 0.0};
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
                                       double stop_frac, int round_cap, int arr_cap, int chunk) {
@@ -82,6 +84,7 @@ extern "C" void cfm_assign_set_mode(int sparse) { g_params.sparse = sparse ? 1 :
 static int g_wide_blocks_cap = 0;
 extern "C" void cfm_assign_set_wide_blocks(int cap) { g_wide_blocks_cap = cap > 0 ? cap : 0; }
 extern "C" void cfm_assign_set_handoff(int handoff) { if (handoff >= 0) g_params.handoff = handoff; }
+extern "C" void cfm_assign_set_stop_early(double f) { if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
 extern "C" void cfm_assign_set_ms_quantile(double q) { if (q > 0.0 && q <= 1.0) g_params.ms_q = q; }
 
 struct AsgState {
@@ -104,6 +107,7 @@ struct AsgState {
     int st_dense_fallbacks, handoff;
     int st_ms_phases, st_ms_augmented;
     double ms_q;
+    double stop_early;
     int wide_blocks, parts;   // grid of asg_wide; split factor of the relax round just run
 };
 
@@ -1050,7 +1054,9 @@ __global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
             if (!(cr > 0.0)) cr = 1.0;
             st->eps = cr * st->eps;          // eps/eps_last hold the fractions on entry
             st->eps_last = cr * st->eps_last;
-            st->stop = (int)(st->stop_frac * n);
+            // every phase but the last is cut earlier: it only has to shape the prices
+            const bool first_is_last = (st->eps / st->theta) < st->eps_last;
+            st->stop = (int)((first_is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
             st->mode = MODE_UMIN0; st->phase = 0;
         }
         for (int k = threadIdx.x; k < n; k += CT) { w.p[k] = 0.0; w.packed[k] = 0ull; }
@@ -1087,7 +1093,11 @@ __global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
                 if (e2 < eps_last) {
                     if (threadIdx.x == 0) { st->mode = MODE_ARR; st->eps = 0.0; st->arr_round = 0; }
                 } else {
-                    if (threadIdx.x == 0) { st->eps = e2; st->phase++; }
+                    if (threadIdx.x == 0) {
+                        st->eps = e2; st->phase++;
+                        const bool is_last = (e2 / theta) < eps_last;
+                        st->stop = (int)((is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
+                    }
                 }
                 __syncthreads();
                 ctrl_reset_assignment(w, st);
@@ -1272,7 +1282,7 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     h.stop_frac = g_params.stop_frac; h.round_cap = g_params.round_cap; h.arr_cap = g_params.arr_cap;
     h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
     h.sparse = (use_sparse && n <= SP_NMAX) ? 1 : 0;
-    h.handoff = g_params.handoff; h.ms_q = g_params.ms_q;
+    h.handoff = g_params.handoff; h.ms_q = g_params.ms_q; h.stop_early = g_params.stop_early;
     size_t wide_dyn = sizeof(double) * WT + 2 * sizeof(int) * WT;
     if (n <= WIDE_PLDS_MAX && (size_t)n * sizeof(double) > wide_dyn) wide_dyn = (size_t)n * sizeof(double);
     if (h.sparse) {

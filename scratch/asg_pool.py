@@ -14,6 +14,7 @@ theta=float(sys.argv[5]) if len(sys.argv)>5 else 0.0
 elast=float(sys.argv[6]) if len(sys.argv)>6 else 0.0
 if len(sys.argv)>3: lib.cfm_assign_set_params(theta,0.0,elast,stop,0,int(sys.argv[3]),0)
 import cfm_oracle as oracle
+if os.environ.get('STOPE'): lib.cfm_assign_set_stop_early(float(os.environ['STOPE']))
 if os.environ.get('MSQ'): lib.cfm_assign_set_ms_quantile(float(os.environ['MSQ']))
 pool=bench.synth_batches(4096,784,nb,1000,dev)
 side=torch.cuda.Stream() if os.environ.get('SIDE') else torch.cuda.current_stream()
