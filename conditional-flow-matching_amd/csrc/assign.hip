@@ -134,6 +134,7 @@ struct AsgWs {
     int* listFC;      // free columns during SAP
     int* pred;
     int* tcol;        // per tree: accepted free column of the phase (or -1)
+    int* grp_ticket;  // [n/64] arrival counters of a split relax round (one per column group)
     int* out_perm;    // [n] result, exported to the caller's buffers once the solve is done
     int* out_misc;    // [16]: certified, stats[8], pad, total_cost (double at [12])
     double* part_d;   // [MS_YMAX][n] partial minima of a split relax round
@@ -161,7 +162,7 @@ __device__ __forceinline__ SList slist(const AsgWs& w, int c) {
 static inline size_t asg_ws_bytes(int n) {
     size_t N = (size_t)n;
     size_t lists = (n <= 4096) ? N * 64 * 8 + 8 * N : 0;
-    return 512 + 8 * N * (4 + 4) + 4 * N * (9 + 6) + 64 + 16 + 16 * N * MS_YMAX + lists + 256;
+    return 512 + 8 * N * (4 + 4) + 4 * N * (10 + 6) + 64 + 16 + 16 * N * MS_YMAX + lists + 256;
 }
 
 static inline AsgWs asg_carve(void* ws, int n) {
@@ -183,6 +184,7 @@ static inline AsgWs asg_carve(void* ws, int n) {
     for (int c = 0; c < 2; ++c) {
         w.S[c].col = (int*)q; q += 4 * N; w.S[c].row = (int*)q; q += 4 * N; w.S[c].root = (int*)q; q += 4 * N;
     }
+    w.grp_ticket = (int*)q; q += 4 * N;
     w.out_perm = (int*)q; q += 4 * N;
     w.out_misc = (int*)q; q += 64;
     q = (char*)(((uintptr_t)q + 15) & ~(uintptr_t)15);
@@ -629,6 +631,43 @@ __device__ __forceinline__ void wide_relax(const float* __restrict__ M, const As
             }
         }
         __syncthreads();
+        if (Y > 1) {
+            // The Y workgroups of a column group hand their partial minima to the LAST one to arrive,
+            // which merges them and finalises the group's 64 columns exactly as an unsplit round does
+            // (one CU merging all 4096 columns in asg_ctrl was bound by that CU's bandwidth: ~20 us).
+            // Hand-off: plain stores -> barrier -> lane 0: agent release, drained, device-scope ticket;
+            // last arriver: agent acquire -> barrier -> plain loads.
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int t = atomicAdd(&w.grp_ticket[g], 1);
+                const int last = (t == Y - 1) ? 1 : 0;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    w.grp_ticket[g] = 0;          // next use is in a later kernel
+                }
+                sh_i[0] = last;
+            }
+            __syncthreads();
+            const int last = sh_i[0];
+            if (last && wv == 0 && ok) {
+                double mb = w.part_d[k]; int mi = w.part_i[k], mr = w.part_r[k];
+                for (int yy = 1; yy < Y; ++yy) {
+                    const double c2 = w.part_d[(size_t)yy * n + k]; const int i2 = w.part_i[(size_t)yy * n + k];
+                    if (c2 < mb || (c2 == mb && i2 < mi)) { mb = c2; mi = i2; mr = w.part_r[(size_t)yy * n + k]; }
+                }
+                if (mb < w.dist[k]) {
+                    w.dist[k] = mb; w.pred[k] = mi;
+                    const int ow = w.owner[k];
+                    if (ow >= 0 && mb < dfree) {
+                        const int idx = atomicAdd(&st->nN, 1);
+                        Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = mb; Nx.root[idx] = mr;
+                        Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -847,6 +886,7 @@ __device__ void ctrl_ms_begin(const AsgWs& w, AsgState* st) {
     const SList L = slist(w, cur);
     __syncthreads();
     for (int k = threadIdx.x; k < n; k += CT) { w.dist[k] = INFINITY; w.pred[k] = -1; }
+    for (int g = threadIdx.x; g < (n + 63) / 64; g += CT) w.grp_ticket[g] = 0;
     for (int t = threadIdx.x; t < nF; t += CT) {
         const int r = w.listF[t];
         L.col[t] = -1; L.row[t] = r; L.base[t] = 0.0; L.rj[t] = w.bidval[r]; L.root[t] = t;
@@ -867,29 +907,42 @@ __device__ void ctrl_ms_merge(const float* __restrict__ M, const AsgWs& w, AsgSt
     const double dfree = st->dfree;
     const SList Nx = slist(w, cur ^ 1);
     int base = st->nN;                         // 0: a split round appends nothing itself
-    for (int k0 = 0; k0 < n; k0 += CT) {
-        const int k = k0 + threadIdx.x;
-        int f = 0, ow = -1, br = -1; double best = INFINITY, pk = 0.0;
-        if (k < n) {
-            best = w.part_d[k]; int bi = w.part_i[k]; br = w.part_r[k];
+    // four columns per thread and trip, every load of a hop issued together:
+    // hop 1 {partials, label, owner, price}, hop 2 {cost of the matched edge}, then ONE block scan
+    for (int k0 = 0; k0 < n; k0 += 4 * CT) {
+        double best[4], dk[4], pk[4]; int bi[4], br[4], ow[4], kq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + threadIdx.x * 4 + q;        // consecutive columns: coalesced 16 / 32-byte loads
+            kq[q] = k;
+            const bool ok = k < n;
+            const int kc = ok ? k : 0;
+            best[q] = ok ? w.part_d[kc] : INFINITY; bi[q] = w.part_i[kc]; br[q] = w.part_r[kc];
             for (int y = 1; y < Y; ++y) {
-                const double c2 = w.part_d[(size_t)y * n + k]; const int i2 = w.part_i[(size_t)y * n + k];
-                if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = w.part_r[(size_t)y * n + k]; }
+                const double c2 = ok ? w.part_d[(size_t)y * n + kc] : INFINITY;
+                const int i2 = w.part_i[(size_t)y * n + kc];
+                if (c2 < best[q] || (c2 == best[q] && i2 < bi[q])) { best[q] = c2; bi[q] = i2; br[q] = w.part_r[(size_t)y * n + kc]; }
             }
-            if (best < w.dist[k]) {
-                w.dist[k] = best; w.pred[k] = bi;
-                ow = w.owner[k]; pk = w.p[k];
-                f = (ow >= 0 && best < dfree) ? 1 : 0;
-            }
+            dk[q] = ok ? w.dist[kc] : -INFINITY; ow[q] = w.owner[kc]; pk[q] = w.p[kc];
         }
-        // order-preserving compaction of the improved assigned columns (a block scan instead of
-        // thousands of same-address atomics from one workgroup)
+        int f[4], cnt = 0; float cm[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool imp = best[q] < dk[q];
+            f[q] = (imp && ow[q] >= 0 && best[q] < dfree) ? 1 : 0;
+            cm[q] = f[q] ? M[(size_t)ow[q] * n + kq[q]] : 0.f;
+            if (imp) { w.dist[kq[q]] = best[q]; w.pred[kq[q]] = bi[q]; }
+            cnt += f[q];
+        }
         int tot;
-        const int off = block_scan_excl(f, &tot, sh);
-        if (f) {
-            const int idx = base + off;
-            Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = br;
-            Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
+        int off = base + block_scan_excl(cnt, &tot, sh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (f[q]) {
+                Nx.col[off] = kq[q]; Nx.row[off] = ow[q]; Nx.base[off] = best[q]; Nx.root[off] = br[q];
+                Nx.rj[off] = (double)cm[q] + pk[q];
+                ++off;
+            }
         }
         base += tot;
     }
@@ -1171,8 +1224,6 @@ __global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
         const int scanned = st->nS;
         __syncthreads();
         if (threadIdx.x == 0) { st->st_sap_batches++; st->st_sap_row_scans += scanned; st->st_total_row_scans += scanned; }
-        const int Y = ms_split(scanned, (n + 63) / 64, st->wide_blocks);
-        if (Y > 1) ctrl_ms_merge(M, w, st, Y, sh);
         if (ctrl_sap_step(w, st, shd, shi, reinterpret_cast<double*>(dyn))) return;
         // converged below the radius: accept one path per tree
         ctrl_ms_finish(w, st, dyn, dyn + n, use_lds, shd, shi, sh);
