@@ -356,3 +356,32 @@ def test_ode_euler_and_dopri5_vs_golden(dev, golden_dir):
     assert node.n_steps == int(d["dopri5_steps"]) and node.nfe == int(d["dopri5_nfe"]), (node.n_steps, node.nfe)
     assert np.abs(tr - d["dopri5"]).max() <= 1e-5 * np.abs(d["dopri5"]).max(), np.abs(tr - d["dopri5"]).max()
     np.testing.assert_array_equal(tr[0], d["x"])
+
+
+@pytest.mark.parametrize("B,d,w,n_t", [(300, 2, 64, 25), (257, 50, 64, 12), (64, 63, 33, 4)])
+def test_ode_fused_small_field_equals_layer_path(dev, B, d, w, n_t):
+    """Small vector fields (every width <= 64) take the fused drivers (one kernel per dopri5 step
+    attempt with the controller on the device; the whole t_span in one launch for euler).  Same MFMA
+    instruction, k order and epilogues as the layer-per-kernel path: the trajectories are bit-equal."""
+    import cfm_amd
+    from cfm_amd import _lib
+    from cfm_amd.ode import NeuralODE
+    from cfm_amd.utils import torch_wrapper
+    lib = _lib.load()
+    torch.manual_seed(3)
+    model = cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev)
+    x = _rand(B, d, 9).to(dev)
+    ts = torch.linspace(0, 1, n_t, device=dev)
+    out = {}
+    try:
+        for fused in (1, 0):
+            lib.cfm_ode_set_fused(fused)
+            for solver in ("dopri5", "euler"):
+                node = NeuralODE(torch_wrapper(model), solver=solver, atol=1e-4, rtol=1e-4)
+                with torch.no_grad():
+                    out[(fused, solver)] = (node.trajectory(x, ts).cpu(), node.nfe, node.n_steps)
+    finally:
+        lib.cfm_ode_set_fused(1)
+    for solver in ("dopri5", "euler"):
+        a, b = out[(1, solver)], out[(0, solver)]
+        assert torch.equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], solver
