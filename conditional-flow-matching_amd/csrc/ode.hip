@@ -443,12 +443,12 @@ __device__ __forceinline__ f32x16 sm_field(const f32x16& y, float t, const SmArg
     return acc;
 }
 
-__global__ __launch_bounds__(256) void ode_sm_step(SmArgs A, int B, int d, const SmState* __restrict__ st_all,
+__global__ __launch_bounds__(256) void ode_small_step(SmArgs A, int B, int d, const SmState* __restrict__ st_all,
                                                    int attempt, float* __restrict__ xbuf, float* __restrict__ kbuf,
                                                    const float* __restrict__ tspan, int n_t, float atol, float rtol,
                                                    double* __restrict__ red) {
-    extern __shared__ __attribute__((aligned(16))) float sm_lds[];
-    float* Wl = sm_lds;                              // [4][64][65]
+    extern __shared__ __attribute__((aligned(16))) float small_lds[];
+    float* Wl = small_lds;                              // [4][64][65]
     float* bl = Wl + 4 * SM_W * SM_LD;               // [4][64]
     float* wt = bl + 4 * SM_W;                       // [64] time column of layer 0
     float* Ab0 = wt + SM_W;                          // [64][65]
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void ode_sm_step(SmArgs A, int B, int d, const
 
 // accept / reject, next step size, trajectory landing (every workgroup derives the same decision
 // from the same inputs; workgroup 0 publishes the next state)
-__global__ __launch_bounds__(256) void ode_sm_ctrl(int B, int d, SmState* __restrict__ st_all, int attempt,
+__global__ __launch_bounds__(256) void ode_small_ctrl(int B, int d, SmState* __restrict__ st_all, int attempt,
                                                    const float* __restrict__ xbuf, const float* __restrict__ tspan,
                                                    int n_t, float* __restrict__ traj, double* __restrict__ red) {
     const SmState st = st_all[attempt & 1];
@@ -586,7 +586,7 @@ static int ode_dopri5_small(const float* const* W, const float* const* b, const 
     const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_W * SM_LD);
     static int raised = 0;
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)ode_sm_step, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)ode_small_step, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         raised = (e == hipSuccess) ? 1 : -1;
         (void)hipGetLastError();
     }
@@ -610,9 +610,9 @@ static int ode_dopri5_small(const float* const* W, const float* const* b, const 
     for (;;) {
         const int chunk = (attempt == 0) ? (n_t - 1) + 4 : 8;
         for (int c = 0; c < chunk; ++c, ++attempt) {
-            hipLaunchKernelGGL(ode_sm_step, dim3(grid), dim3(256), lds, s, A, B, d, st, attempt, xbuf, kbuf, tspan_dev,
+            hipLaunchKernelGGL(ode_small_step, dim3(grid), dim3(256), lds, s, A, B, d, st, attempt, xbuf, kbuf, tspan_dev,
                                n_t, atol, rtol, red_dev);
-            hipLaunchKernelGGL(ode_sm_ctrl, dim3(copy_grid), dim3(256), 0, s, B, d, st, attempt, xbuf, tspan_dev, n_t,
+            hipLaunchKernelGGL(ode_small_ctrl, dim3(copy_grid), dim3(256), 0, s, B, d, st, attempt, xbuf, tspan_dev, n_t,
                                traj, red_dev);
         }
         rc = cfm_status();
@@ -631,10 +631,10 @@ static int ode_dopri5_small(const float* const* W, const float* const* b, const 
 
 // Fixed-step Euler for the same small fields: x_{k+1} = x_k + dt_k f(t_k, x_k), every step of the
 // tile inside one launch (same arithmetic as ode_combine: fmaf(dt, 1.f * k, x)).
-__global__ __launch_bounds__(256) void ode_sm_euler(SmArgs A, int B, int d, const float* __restrict__ tspan, int n_t,
+__global__ __launch_bounds__(256) void ode_small_euler(SmArgs A, int B, int d, const float* __restrict__ tspan, int n_t,
                                                     float* __restrict__ traj) {
-    extern __shared__ __attribute__((aligned(16))) float sm_lds[];
-    float* Wl = sm_lds;
+    extern __shared__ __attribute__((aligned(16))) float small_lds[];
+    float* Wl = small_lds;
     float* bl = Wl + 4 * SM_W * SM_LD;
     float* wt = bl + 4 * SM_W;
     float* Ab0 = wt + SM_W;
@@ -681,7 +681,7 @@ static int ode_euler_small(const float* const* W, const float* const* b, const i
     const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_W * SM_LD);
     static int raised = 0;
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)ode_sm_euler, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)ode_small_euler, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         raised = (e == hipSuccess) ? 1 : -1;
         (void)hipGetLastError();
     }
@@ -689,6 +689,6 @@ static int ode_euler_small(const float* const* W, const float* const* b, const i
     int rc = cfm_hip(hipMemcpyAsync(tspan_dev, t_span, sizeof(float) * n_t, hipMemcpyHostToDevice, s));
     if (rc) return rc;
     const int tiles = (B + SM_W - 1) / SM_W;
-    hipLaunchKernelGGL(ode_sm_euler, dim3(tiles < 2048 ? tiles : 2048), dim3(256), lds, s, A, B, d, tspan_dev, n_t, traj);
+    hipLaunchKernelGGL(ode_small_euler, dim3(tiles < 2048 ? tiles : 2048), dim3(256), lds, s, A, B, d, tspan_dev, n_t, traj);
     return cfm_status();
 }
