@@ -397,9 +397,15 @@ __device__ __forceinline__ f32x16 sm_gemm(const float* __restrict__ Abuf, const 
     const int fr = lane & 31, fk = lane >> 5;
     const float* ap = Abuf + (wm * 32 + fr) * SM_LD + fk;
     const float* bp = Wl + (wn * 32 + fr) * SM_LD + fk;
+    // software pipeline: the operands of k-step kk+2 are read from LDS while the MFMA of kk runs (the read
+    // past the last step stays inside the padded 65-float row)
     const int Kp = (K + 1) & ~1;
-    for (int kk = 0; kk < Kp; kk += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+    float a = ap[0], b = bp[0];
+    for (int kk = 0; kk < Kp; kk += 2) {
+        const float an = ap[kk + 2], bn = bp[kk + 2];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        a = an; b = bn;
+    }
     return acc;
 }
 
