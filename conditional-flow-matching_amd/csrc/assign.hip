@@ -8,11 +8,18 @@
 // MI355X design.  The 64 MiB (B=4096) cost matrix is Infinity-Cache resident, a
 // full sweep costs ~15-25 us, kernel boundaries ~1.5 us: the algorithm is built
 // from wide, cheap sweeps and a tiny sequential control step, all device
-// resident (the host only pumps a fixed kernel pair and polls 4 bytes):
+// resident.  The host only pumps a fixed (asg_wide, asg_ctrl) kernel pair — replayed
+// as a hipGraph, the kernels take nothing but the workspace — and polls 64 bytes.
+// Every kernel of the chain starts cold, so each is organised as two dependent global
+// hops (everything a hop needs is requested together, speculatively if need be).
 //
-//   phase A  epsilon-scaling forward auction, Jacobi rounds (one wave64 per
-//            bidding row: 16 coalesced float4 loads per lane, fp64 reduced
-//            costs, DPP/shuffle top-2 reduction, one 64-bit atomicMax per bid).
+//   init     Jonker-Volgenant row + column reduction: u_i = min_j c_ij,
+//            p_j = max_i (u_i - c_ij) (every column tight for some row) — the auction
+//            then starts at eps = 8e-3 of the cost range instead of 0.2.
+//   phase A  epsilon-scaling forward auction, Jacobi rounds (wave <-> row, a row bids
+//            iff it is unmatched; prices staged in LDS, the bidder's 16 float4 per
+//            lane in flight before the barrier, branch-free fp64 top-2, DPP wave
+//            reduction, one 64-bit atomicMax per bid).
 //            Each epsilon phase is cut when <= 2 % of the rows are unassigned —
 //            the phases only have to produce good prices.
 //   phase B  the same rounds with epsilon = 0 (Jonker-Volgenant "augmenting row
@@ -108,7 +115,7 @@ struct AsgState {
     int st_ms_phases, st_ms_augmented;
     double ms_q;
     double stop_early;
-    int wide_blocks, parts;   // grid of asg_wide; split factor of the relax round just run
+    int wide_blocks, pad5;    // grid of asg_wide
 };
 
 // SAP scan list entry arrays (two copies: current / next)
@@ -332,20 +339,14 @@ __device__ __forceinline__ void bid_commit(const AsgWs& w, Top2 best, int i, dou
 // hides behind the row's latency.
 __device__ __forceinline__ void wide_bid(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
                          int wave_gid, int n_waves, int pre_a, bool stage_p, int n_host,
-                         double2 pst0, double2 pst1, double2 pst2, double2 pst3, long long t_entry) {
+                         double2 pst0, double2 pst1, double2 pst2, double2 pst3) {
     extern __shared__ __attribute__((aligned(16))) char wide_lds_bid[];   // = the kernel's dynamic LDS
     double* p_lds = reinterpret_cast<double*>(wide_lds_bid);
     const int n = n_host;
     const double eps = st->eps;        // same 128-byte line as st->mode: an L1 hit by now
-#ifdef BID_PROFILE
-    const int nU = st->nU;
-#endif
     const int lane = threadIdx.x & 63;
     const bool vec = ((n & 3) == 0);
     const bool fast = stage_p && (n & 4095) == 0;
-#ifdef BID_PROFILE
-    long long tq[6]; tq[0] = clock64(); tq[1] = tq[2] = tq[3] = tq[4] = tq[0];
-#endif
     // No bidder list: wave <-> row, a row bids iff it is unmatched (pre_a = a[wave_gid] came with
     // the state block).  Rows beyond the first of a wave (n > number of waves) are checked as they come.
     int i = wave_gid;
@@ -362,26 +363,13 @@ __device__ __forceinline__ void wide_bid(const float* __restrict__ M, const AsgW
         if (j1 < n_host) *reinterpret_cast<double2*>(p_lds + j1) = pst1;
         if (j2 < n_host) *reinterpret_cast<double2*>(p_lds + j2) = pst2;
         if (j3 < n_host) *reinterpret_cast<double2*>(p_lds + j3) = pst3;
-#ifdef BID_PROFILE
-        tq[1] = clock64();
-#endif
         __syncthreads();
     }
-#ifdef BID_PROFILE
-    tq[2] = clock64();
-#endif
     if (fast) {
         while (i < n) {
             if (bids) {
                 Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
-#ifdef BID_PROFILE
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                tq[3] = clock64();
-#endif
                 bid_segment(best, c, p_lds + lane * 4, lane * 4);
-#ifdef BID_PROFILE
-                tq[4] = clock64();
-#endif
                 for (int seg = 4096; seg < n; seg += 4096) {
                     const float* rs = M + (size_t)i * n + seg + lane * 4;
 #pragma unroll
@@ -389,14 +377,6 @@ __device__ __forceinline__ void wide_bid(const float* __restrict__ M, const AsgW
                     bid_segment(best, c, p_lds + seg + lane * 4, seg + lane * 4);
                 }
                 bid_commit(w, best, i, eps, p_lds, true);
-#ifdef BID_PROFILE
-                if (wave_gid == 0 && lane == 0 && nU < 600) {
-                    long long* out = reinterpret_cast<long long*>(reinterpret_cast<char*>(w.st) + 400);
-                    const long long t5 = clock64();
-                    out[0] += tq[0] - t_entry; out[1] += tq[1] - tq[0]; out[2] += tq[2] - tq[1]; out[3] += tq[3] - tq[2];
-                    out[4] += tq[4] - tq[3]; out[5] += t5 - tq[4]; out[6] += 1;
-                }
-#endif
             }
             i += n_waves;
             bids = (i < n) && (w.a[i] < 0);
@@ -572,7 +552,7 @@ __device__ __forceinline__ int ms_split(int nS, int n_groups, int blocks) {
 // list, 8 independent row loads in flight per lane, LDS merge.  The writer lane
 // appends improved assigned columns to the NEXT list (one atomic per append).  A big round
 // is split over Y workgroups per column group (every Y-th slice of the list each); they write
-// per-column partial minima and asg_ctrl merges them (ctrl_ms_merge).
+// per-column partial minima and the last of them to arrive merges them (see the end of the loop body).
 __device__ __forceinline__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState* st,
                            double* sh_d, int* sh_i, int* sh_r) {
     const int n = st->n, nS = st->nS, cur = st->cur;
@@ -703,7 +683,6 @@ __global__ __launch_bounds__(WT) void asg_wide(AsgWs w, int n_host) {
     int* sh_i = reinterpret_cast<int*>(wide_lds + sizeof(double) * WT);
     int* sh_r = sh_i + WT;
     AsgState* st = w.st;
-    const long long t_kernel_entry = clock64();
     // consecutive work items go to different workgroups (different CUs)
     const int wave_gid = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
     const int n_waves = gridDim.x * (WT / 64);
@@ -729,7 +708,7 @@ __global__ __launch_bounds__(WT) void asg_wide(AsgWs w, int n_host) {
     asm volatile("" : "+v"(pre_i), "+v"(pst0.x), "+v"(pst1.x), "+v"(pst2.x), "+v"(pst3.x) : "s"(mode) : "memory");   // all of it in flight
     if (mode == MODE_DONE || st->error) return;
     if (mode == MODE_AUCTION || mode == MODE_ARR) {
-        wide_bid(M, w, st, wave_gid, n_waves, pre_i, stage_p, n_host, pst0, pst1, pst2, pst3, t_kernel_entry);
+        wide_bid(M, w, st, wave_gid, n_waves, pre_i, stage_p, n_host, pst0, pst1, pst2, pst3);
     } else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i, sh_r);
     else if (mode == MODE_UMIN || mode == MODE_UMIN0) wide_umin(M, w, st, wave_gid, n_waves, false);
     else if (mode == MODE_INITRED) wide_initred(M, w, st, sh_d, n_host);
@@ -897,56 +876,6 @@ __device__ void ctrl_ms_begin(const AsgWs& w, AsgState* st) {
         st->nS = nF; st->nN = 0; st->dfree = INFINITY; st->jfree = -1; st->mode = MODE_SAP;
         st->st_ms_phases++;
     }
-    __syncthreads();
-}
-
-// A split relax round left Y partial minima per column: merge (ties -> lowest row, as inside a
-// workgroup), lower the label, list the improved assigned columns.
-__device__ void ctrl_ms_merge(const float* __restrict__ M, const AsgWs& w, AsgState* st, int Y, int* sh) {
-    const int n = st->n, cur = st->cur;
-    const double dfree = st->dfree;
-    const SList Nx = slist(w, cur ^ 1);
-    int base = st->nN;                         // 0: a split round appends nothing itself
-    // four columns per thread and trip, every load of a hop issued together:
-    // hop 1 {partials, label, owner, price}, hop 2 {cost of the matched edge}, then ONE block scan
-    for (int k0 = 0; k0 < n; k0 += 4 * CT) {
-        double best[4], dk[4], pk[4]; int bi[4], br[4], ow[4], kq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + threadIdx.x * 4 + q;        // consecutive columns: coalesced 16 / 32-byte loads
-            kq[q] = k;
-            const bool ok = k < n;
-            const int kc = ok ? k : 0;
-            best[q] = ok ? w.part_d[kc] : INFINITY; bi[q] = w.part_i[kc]; br[q] = w.part_r[kc];
-            for (int y = 1; y < Y; ++y) {
-                const double c2 = ok ? w.part_d[(size_t)y * n + kc] : INFINITY;
-                const int i2 = w.part_i[(size_t)y * n + kc];
-                if (c2 < best[q] || (c2 == best[q] && i2 < bi[q])) { best[q] = c2; bi[q] = i2; br[q] = w.part_r[(size_t)y * n + kc]; }
-            }
-            dk[q] = ok ? w.dist[kc] : -INFINITY; ow[q] = w.owner[kc]; pk[q] = w.p[kc];
-        }
-        int f[4], cnt = 0; float cm[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool imp = best[q] < dk[q];
-            f[q] = (imp && ow[q] >= 0 && best[q] < dfree) ? 1 : 0;
-            cm[q] = f[q] ? M[(size_t)ow[q] * n + kq[q]] : 0.f;
-            if (imp) { w.dist[kq[q]] = best[q]; w.pred[kq[q]] = bi[q]; }
-            cnt += f[q];
-        }
-        int tot;
-        int off = base + block_scan_excl(cnt, &tot, sh);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (f[q]) {
-                Nx.col[off] = kq[q]; Nx.row[off] = ow[q]; Nx.base[off] = best[q]; Nx.root[off] = br[q];
-                Nx.rj[off] = (double)cm[q] + pk[q];
-                ++off;
-            }
-        }
-        base += tot;
-    }
-    if (threadIdx.x == 0) st->nN = base;
     __syncthreads();
 }
 
