@@ -123,7 +123,8 @@ def main():
     rank, local, world = D.init_from_env()
     if world != args.gpus and rank == 0:
         print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
-    dev = torch.device("cuda", local)
+    dev_index = local % torch.cuda.device_count()     # one rank per GPU on a real node (identity there)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     B, d = args.batch, args.dim
 
@@ -132,7 +133,7 @@ def main():
     torch.manual_seed(0)
     model = cfm_amd.MLP(dim=d, time_varying=True, w=args.width).to(dev)
     if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index])
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     np.random.seed(D.shard_seed(1, rank)); torch.manual_seed(D.shard_seed(1, rank))
 

@@ -18,14 +18,15 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # CFM_DIST_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box
+            backend = os.environ.get("CFM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % torch.cuda.device_count())
     return rank, local, world
 
 
