@@ -6,19 +6,19 @@ import torch
 
 
 def eight_normal_sample(n, dim, scale=1, var=1):
-    """ref: torchcfm/utils.py:11-32 (same RNG consumption: MVN noise, then multinomial)."""
-    m = torch.distributions.multivariate_normal.MultivariateNormal(
-        torch.zeros(dim), math.sqrt(var) * torch.eye(dim)
-    )
-    centers = [
-        (1, 0), (-1, 0), (0, 1), (0, -1),
-        (1.0 / np.sqrt(2), 1.0 / np.sqrt(2)), (1.0 / np.sqrt(2), -1.0 / np.sqrt(2)),
-        (-1.0 / np.sqrt(2), 1.0 / np.sqrt(2)), (-1.0 / np.sqrt(2), -1.0 / np.sqrt(2)),
-    ]
-    centers = torch.tensor(centers) * scale
-    noise = m.sample((n,))
-    multi = torch.multinomial(torch.ones(8), n, replacement=True)
-    return centers[multi] + noise
+    """Mixture of eight Gaussians on the unit circle (axis points first, then the diagonals), as
+    torchcfm/utils.py:11-32 draws it: one MVN draw of the noise for all n points, then ONE
+    multinomial draw of the component labels — the same two RNG calls in the same order, so a
+    seeded run yields the reference's points; the per-point Python loop of the reference is a
+    single gather here."""
+    h = 1.0 / np.sqrt(2)
+    axis_pts = [(1, 0), (-1, 0), (0, 1), (0, -1)]
+    diag_pts = [(sx * h, sy * h) for sx in (1, -1) for sy in (1, -1)]
+    centers = torch.tensor(axis_pts + diag_pts) * scale
+    cov = math.sqrt(var) * torch.eye(dim)
+    noise = torch.distributions.multivariate_normal.MultivariateNormal(torch.zeros(dim), cov).sample((n,))
+    component = torch.multinomial(torch.ones(len(centers)), n, replacement=True)
+    return centers.index_select(0, component) + noise
 
 
 def generate_moons(n_samples=100, noise=1e-4):
@@ -63,15 +63,19 @@ class torch_wrapper(torch.nn.Module):
         return self.model(torch.cat([x, t.repeat(x.shape[0])[:, None]], 1))
 
 
-def plot_trajectories(traj):
-    """ref: torchcfm/utils.py:55-65 (matplotlib imported lazily)."""
+def plot_trajectories(traj, n=2000):
+    """Scatter plot of a [T, B, >=2] trajectory: start points, the flow, end points
+    (counterpart of torchcfm/utils.py:55-65; matplotlib is imported lazily)."""
     import matplotlib.pyplot as plt
-    n = 2000
-    plt.figure(figsize=(6, 6))
-    plt.scatter(traj[0, :n, 0], traj[0, :n, 1], s=10, alpha=0.8, c="black")
-    plt.scatter(traj[:, :n, 0], traj[:, :n, 1], s=0.2, alpha=0.2, c="olive")
-    plt.scatter(traj[-1, :n, 0], traj[-1, :n, 1], s=4, alpha=1, c="blue")
-    plt.legend(["Prior sample z(S)", "Flow", "z(0)"])
-    plt.xticks([])
-    plt.yticks([])
+    fig, ax = plt.subplots(figsize=(6, 6))
+    layers = (
+        (traj[0, :n], dict(s=10, alpha=0.8, c="black", label="Prior sample z(S)")),
+        (traj[:, :n].reshape(-1, traj.shape[-1]), dict(s=0.2, alpha=0.2, c="olive", label="Flow")),
+        (traj[-1, :n], dict(s=4, alpha=1, c="blue", label="z(0)")),
+    )
+    for pts, style in layers:
+        ax.scatter(pts[:, 0], pts[:, 1], **style)
+    ax.legend()
+    ax.set_xticks([])
+    ax.set_yticks([])
     plt.show()

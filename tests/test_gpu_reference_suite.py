@@ -27,47 +27,60 @@ SIGMA_CONDITION = {"sb_cfm": lambda x: x <= 0}
 
 
 def random_samples(shape, batch_size=TEST_BATCH_SIZE):
-    if isinstance(shape, int):
-        shape = [shape]
-    return [torch.randn(batch_size, *shape), torch.randn(batch_size, *shape)]
+    dims = [shape] if isinstance(shape, int) else list(shape)
+    return [torch.randn(batch_size, *dims) for _ in range(2)]
+
+
+def _interp(x0, x1, t):
+    return t * x1 + (1 - t) * x0
+
+
+# The closed forms the reference's test asserts against (tests/test_conditional_flow_matcher.py:35-68),
+# one entry per probability path: method -> (mu_t, sigma_t, u_t).  The operation order inside every
+# expression is the reference's (the comparison below is bitwise).
+_HALF_PI = math.pi / 2
+_PATHS = {
+    "vp_cfm": (
+        lambda x0, x1, t, s: torch.cos(_HALF_PI * t) * x0 + torch.sin(_HALF_PI * t) * x1,
+        lambda t, s: s,
+        lambda x0, x1, t, s, xt, sig_t: _HALF_PI * (torch.cos(_HALF_PI * t) * x1 - torch.sin(_HALF_PI * t) * x0),
+    ),
+    "t_cfm": (
+        lambda x0, x1, t, s: t * x1,
+        lambda t, s: 1 - (1 - s) * t,
+        lambda x0, x1, t, s, xt, sig_t: (x1 - (1 - s) * xt) / sig_t,
+    ),
+    "sb_cfm": (
+        lambda x0, x1, t, s: _interp(x0, x1, t),
+        lambda t, s: s * torch.sqrt(t * (1 - t)),
+        lambda x0, x1, t, s, xt, sig_t: (1 - 2 * t) / (2 * t * (1 - t) + 1e-8) * (xt - _interp(x0, x1, t)) + x1 - x0,
+    ),
+    "i_cfm": (
+        lambda x0, x1, t, s: _interp(x0, x1, t),
+        lambda t, s: s,
+        lambda x0, x1, t, s, xt, sig_t: x1 - x0,
+    ),
+}
+_PATHS["exact_ot_cfm"] = _PATHS["i_cfm"]
+
+_MATCHERS = {
+    "vp_cfm": lambda sigma: VariancePreservingConditionalFlowMatcher(sigma=sigma),
+    "t_cfm": lambda sigma: TargetConditionalFlowMatcher(sigma=sigma),
+    "sb_cfm": lambda sigma: SchrodingerBridgeConditionalFlowMatcher(sigma=sigma, ot_method="sinkhorn"),
+    "exact_ot_cfm": lambda sigma: ExactOptimalTransportConditionalFlowMatcher(sigma=sigma),
+    "i_cfm": lambda sigma: ConditionalFlowMatcher(sigma=sigma),
+}
 
 
 def compute_xt_ut(method, x0, x1, t_given, sigma, epsilon):
-    # verbatim closed forms of reference tests/test_conditional_flow_matcher.py:35-68
-    if method == "vp_cfm":
-        sigma_t = sigma
-        mu_t = torch.cos(math.pi / 2 * t_given) * x0 + torch.sin(math.pi / 2 * t_given) * x1
-        computed_xt = mu_t + sigma_t * epsilon
-        computed_ut = (math.pi / 2 * (torch.cos(math.pi / 2 * t_given) * x1 - torch.sin(math.pi / 2 * t_given) * x0))
-    elif method == "t_cfm":
-        sigma_t = 1 - (1 - sigma) * t_given
-        mu_t = t_given * x1
-        computed_xt = mu_t + sigma_t * epsilon
-        computed_ut = (x1 - (1 - sigma) * computed_xt) / sigma_t
-    elif method == "sb_cfm":
-        sigma_t = sigma * torch.sqrt(t_given * (1 - t_given))
-        mu_t = t_given * x1 + (1 - t_given) * x0
-        computed_xt = mu_t + sigma_t * epsilon
-        computed_ut = ((1 - 2 * t_given) / (2 * t_given * (1 - t_given) + 1e-8)
-                       * (computed_xt - (t_given * x1 + (1 - t_given) * x0)) + x1 - x0)
-    elif method in ["exact_ot_cfm", "i_cfm"]:
-        sigma_t = sigma
-        mu_t = t_given * x1 + (1 - t_given) * x0
-        computed_xt = mu_t + sigma_t * epsilon
-        computed_ut = x1 - x0
-    return computed_xt, computed_ut
+    mu, sig, flow = _PATHS[method]
+    sigma_t = sig(t_given, sigma)
+    computed_xt = mu(x0, x1, t_given, sigma) + sigma_t * epsilon
+    return computed_xt, flow(x0, x1, t_given, sigma, computed_xt, sigma_t)
 
 
 def get_flow_matcher(method, sigma):
-    if method == "vp_cfm":
-        return VariancePreservingConditionalFlowMatcher(sigma=sigma)
-    if method == "t_cfm":
-        return TargetConditionalFlowMatcher(sigma=sigma)
-    if method == "sb_cfm":
-        return SchrodingerBridgeConditionalFlowMatcher(sigma=sigma, ot_method="sinkhorn")
-    if method == "exact_ot_cfm":
-        return ExactOptimalTransportConditionalFlowMatcher(sigma=sigma)
-    return ConditionalFlowMatcher(sigma=sigma)
+    return _MATCHERS[method](sigma)
 
 
 def sample_plan(method, x0, x1, sigma):
