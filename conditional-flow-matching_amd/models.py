@@ -18,17 +18,16 @@ class MLP(torch.nn.Module):
     def __init__(self, dim, out_dim=None, w=64, time_varying=False):
         super().__init__()
         self.time_varying = time_varying
-        if out_dim is None:
-            out_dim = dim
-        self.net = torch.nn.Sequential(
-            torch.nn.Linear(dim + (1 if time_varying else 0), w),
-            torch.nn.SELU(),
-            torch.nn.Linear(w, w),
-            torch.nn.SELU(),
-            torch.nn.Linear(w, w),
-            torch.nn.SELU(),
-            torch.nn.Linear(w, out_dim),
-        )
+        # in -> w -> w -> w -> out with SELU between the linear layers; the layers are created in
+        # order (same parameter-init RNG consumption) and sit at net[0], net[2], net[4], net[6], so the
+        # reference's state_dicts load unchanged
+        widths = [dim + int(bool(time_varying)), w, w, w, dim if out_dim is None else out_dim]
+        layers = []
+        for k, (fan_in, fan_out) in enumerate(zip(widths[:-1], widths[1:])):
+            if k:
+                layers.append(torch.nn.SELU())
+            layers.append(torch.nn.Linear(fan_in, fan_out))
+        self.net = torch.nn.Sequential(*layers)
 
     # ---- HIP path -----------------------------------------------------------
     def _linears(self):
@@ -92,13 +91,17 @@ class MLP(torch.nn.Module):
 
 
 class GradModel(torch.nn.Module):
-    """Action-matching helper (ref: torchcfm/models/models.py:24-32); autograd only."""
+    """Vector field as the gradient of a scalar potential: ``forward(x)`` differentiates
+    ``sum(action(x))`` w.r.t. ``x`` (graph kept, so the result can be trained through) and drops
+    the last (time) column.  Counterpart of the action-matching helper at
+    torchcfm/models/models.py:24-32; pure autograd, nothing to accelerate."""
 
     def __init__(self, action):
         super().__init__()
         self.action = action
 
     def forward(self, x):
-        x = x.requires_grad_(True)
-        grad = torch.autograd.grad(torch.sum(self.action(x)), x, create_graph=True)[0]
-        return grad[:, :-1]
+        inp = x.requires_grad_(True)
+        potential = self.action(inp).sum()
+        (dpot,) = torch.autograd.grad(potential, inp, create_graph=True)
+        return dpot[..., :-1] if dpot.dim() != 2 else dpot[:, :-1]
