@@ -21,6 +21,7 @@
 // Convergence is decided on the device (no host sync): every kernel of the
 // pre-enqueued sequence reads the state block and exits if `done` is set.
 #include "cfm_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 #define SK_NEG (-1.0e300)
@@ -94,17 +95,22 @@ __device__ __forceinline__ float4 sk_load4(const float* __restrict__ row, int j,
     return r;
 }
 
+#define SK_COL_U 8    // rows per wave and trip of the column pass
+
 // Column pass: partial LSE_i(u_i - M_ij/reg) over a strip of rows.
-// PRECISE = false: exponent formed in fp64, exp() in fp32 (fast, HBM-bound).
-// PRECISE = true : exp() and the running sums in fp64 (engaged near convergence,
+// precise == 0: exponent formed in fp64, exp() in fp32 (fast, HBM-bound).
+// precise != 0: exp() and the running sums in fp64 (engaged near convergence,
 // where the fp32 exp noise floor ~1e-7 would hide a 1e-9 marginal violation).
-template <bool PRECISE>
-__device__ __forceinline__ void sk_col_body(const float* __restrict__ M, int B0, int B1,
-                                            double inv_reg, const double* __restrict__ u,
-                                            double* __restrict__ pm, double* __restrict__ ps,
-                                            int rows_per_chunk, int vec, double (*sm)[256],
-                                            double (*ss)[256]) {
-    typedef typename std::conditional<PRECISE, double, float>::type acc_t;
+// The state block (done / precise) is read AFTER the first trip's rows have been requested: a
+// kernel starts cold, and the state would otherwise be a dependent hop in front of the matrix.
+__global__ __launch_bounds__(256) void sk_col_pass(const float* __restrict__ M, int B0, int B1,
+                                                   double inv_reg, const SkState* __restrict__ st,
+                                                   const double* __restrict__ u,
+                                                   double* __restrict__ pm,
+                                                   double* __restrict__ ps, int rows_per_chunk,
+                                                   int vec) {
+    __shared__ double sm[4][256];
+    __shared__ double ss[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 256 + lane * 4;
     const int chunk = blockIdx.y;
@@ -114,10 +120,11 @@ __device__ __forceinline__ void sk_col_body(const float* __restrict__ M, int B0,
     const bool v4 = vec && (j + 3 < B1);
 
     double m[4] = {SK_NEG, SK_NEG, SK_NEG, SK_NEG};
-    acc_t s[4] = {0, 0, 0, 0};
+    double s[4] = {0, 0, 0, 0};     // the fp32 path keeps its sums in float: the round trip is exact
+    int precise = 0;
 
-    constexpr int U = 8;
-    for (int r0 = r_beg + wv * U; r0 < r_end; r0 += 4 * U) {
+    constexpr int U = SK_COL_U;
+    for (int r0 = r_beg + wv * U, first = 1; r0 < r_end || first; r0 += 4 * U) {
         float4 c[U];
         double ui[U];
 #pragma unroll
@@ -126,6 +133,12 @@ __device__ __forceinline__ void sk_col_body(const float* __restrict__ M, int B0,
             const bool ok = active && r < r_end;
             c[k] = ok ? sk_load4(M + (size_t)r * B1, j, B1, v4) : make_float4(0.f, 0.f, 0.f, 0.f);
             ui[k] = (r < r_end) ? u[r] : SK_NEG;  // wave-uniform
+        }
+        if (first) {
+            first = 0;
+            if (st->done) return;
+            precise = st->precise;
+            if (r0 >= r_end) break;            // a wave without rows still joins the merge below
         }
         double x[U][4];
         double mx[4] = {m[0], m[1], m[2], m[3]};
@@ -138,49 +151,40 @@ __device__ __forceinline__ void sk_col_body(const float* __restrict__ M, int B0,
 #pragma unroll
             for (int q = 0; q < 4; ++q) mx[q] = fmax(mx[q], x[k][q]);
         }
+        if (precise) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (PRECISE) {
-                double acc = (double)s[q] * exp(m[q] - mx[q]);
+            for (int q = 0; q < 4; ++q) {
+                double acc = s[q] * exp(m[q] - mx[q]);
 #pragma unroll
                 for (int k = 0; k < U; ++k) acc += exp(x[k][q] - mx[q]);
-                s[q] = (acc_t)acc;
-            } else {
+                s[q] = acc;
+                m[q] = mx[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
                 float acc = (float)s[q] * __expf((float)(m[q] - mx[q]));
 #pragma unroll
                 for (int k = 0; k < U; ++k) acc += __expf((float)(x[k][q] - mx[q]));
-                s[q] = (acc_t)acc;
+                s[q] = (double)acc;
+                m[q] = mx[q];
             }
-            m[q] = mx[q];
         }
     }
     // merge the 4 waves of the workgroup (same columns, different rows)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { sm[wv][lane * 4 + q] = m[q]; ss[wv][lane * 4 + q] = (double)s[q]; }
+    for (int q = 0; q < 4; ++q) { sm[wv][lane * 4 + q] = m[q]; ss[wv][lane * 4 + q] = s[q]; }
     __syncthreads();
-    const int c = threadIdx.x;  // one column per thread
-    const int jc = blockIdx.x * 256 + c;
+    const int tc = threadIdx.x;  // one column per thread
+    const int jc = blockIdx.x * 256 + tc;
     if (jc < B1) {
-        double mm = fmax(fmax(sm[0][c], sm[1][c]), fmax(sm[2][c], sm[3][c]));
+        double mm = fmax(fmax(sm[0][tc], sm[1][tc]), fmax(sm[2][tc], sm[3][tc]));
         double tot = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) tot += ss[w][c] * exp(sm[w][c] - mm);
+        for (int w = 0; w < 4; ++w) tot += ss[w][tc] * exp(sm[w][tc] - mm);
         pm[(size_t)chunk * B1 + jc] = mm;
         ps[(size_t)chunk * B1 + jc] = tot;
     }
-}
-
-__global__ __launch_bounds__(256) void sk_col_pass(const float* __restrict__ M, int B0, int B1,
-                                                   double inv_reg, const SkState* __restrict__ st,
-                                                   const double* __restrict__ u,
-                                                   double* __restrict__ pm,
-                                                   double* __restrict__ ps, int rows_per_chunk,
-                                                   int vec) {
-    __shared__ double sm[4][256];
-    __shared__ double ss[4][256];
-    if (st->done) return;
-    if (st->precise) sk_col_body<true>(M, B0, B1, inv_reg, u, pm, ps, rows_per_chunk, vec, sm, ss);
-    else             sk_col_body<false>(M, B0, B1, inv_reg, u, pm, ps, rows_per_chunk, vec, sm, ss);
 }
 
 // Merge strip partials -> v_new; accumulate the previous iteration's marginal
@@ -197,17 +201,18 @@ __global__ __launch_bounds__(256) void sk_col_finalize(int B1, int nchunk, doubl
                                                        int slot) {
     __shared__ double sm[4][64];
     __shared__ double ss[4][64];
-    if (st->done) return;
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
     double m[SK_FIN_MAXPER], sv[SK_FIN_MAXPER];
 #pragma unroll
-    for (int q = 0; q < SK_FIN_MAXPER; ++q) {
+    for (int q = 0; q < SK_FIN_MAXPER; ++q) {     // requested before the state block is looked at
         const int c = part + 4 * q;
         const bool ok = (j < B1) && (c < nchunk);
         m[q] = ok ? pm[(size_t)c * B1 + j] : SK_NEG;
         sv[q] = ok ? ps[(size_t)c * B1 + j] : 0.0;
     }
+    const double vo = (check && j < B1) ? v_old[j] : 0.0;
+    if (st->done) return;
     double mm = SK_NEG;
 #pragma unroll
     for (int q = 0; q < SK_FIN_MAXPER; ++q) mm = fmax(mm, m[q]);
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void sk_col_finalize(int B1, int nchunk, doubl
             const double vn = logb - (m4 + log(t4));
             v_new[j] = vn;
             if (check) {
-                const double e = b * exp(v_old[j] - vn) - b;
+                const double e = b * exp(vo - vn) - b;
                 e2 = e * e;
             }
         }
@@ -333,12 +338,16 @@ __device__ __forceinline__ void sk_row_trip(const float4 (&c)[U], int j0, double
 }
 
 #define SK_ROW_PRE 16   // float4 per lane in flight per 4096-column segment
+#ifndef SK_ROW_WAVES
+#define SK_ROW_WAVES 4   // waves per workgroup of the fast row pass
+#endif
 #ifndef SK_RPW
-#define SK_RPW 4         // rows per workgroup of the fast row pass (4 waves)
+#define SK_RPW 4         // rows per workgroup of the fast row pass (a multiple of SK_ROW_WAVES)
 #endif
 #ifndef SK_ROW_OCC
-#define SK_ROW_OCC 3     // workgroups per CU the fast row pass is compiled for
+#define SK_ROW_OCC 3     // waves per SIMD the fast row pass is compiled for
 #endif
+#define SK_ROW_THREADS (64 * SK_ROW_WAVES)
 
 // One wave per row; the row's first segment was loaded BEFORE v was staged into LDS (the two
 // latencies overlap), later segments of a longer row are loaded 16 float4 at a time.
@@ -377,7 +386,7 @@ __device__ __forceinline__ void sk_row_fast(const float* __restrict__ row, int B
 // Row pass: u_i = log a - LSE_j(v_j - M_ij/reg); also the convergence decision
 // for the previous iteration (every workgroup derives it from the same data).
 template <bool FAST>
-__global__ __launch_bounds__(256, FAST ? SK_ROW_OCC : 4) void sk_row_pass(const float* __restrict__ M, int B0, int B1,
+__global__ __launch_bounds__(FAST ? SK_ROW_THREADS : 256, FAST ? SK_ROW_OCC : 4) void sk_row_pass(const float* __restrict__ M, int B0, int B1,
                                                       double inv_reg, double loga,
                                                       SkState* __restrict__ st,
                                                       const double* __restrict__ v,
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(256, FAST ? SK_ROW_OCC : 4) void sk_row_pass(const 
         // SK_RPW rows per workgroup, SK_RPW / 4 consecutive rows per wave, v staged in LDS once per
         // workgroup.  The first row is requested BEFORE v is staged (the two latencies overlap); with
         // more than one row per wave the next row is requested before the current one is reduced.
-        constexpr int RPWV = SK_RPW / 4;
+        constexpr int RPWV = SK_RPW / SK_ROW_WAVES;
         const int lane = threadIdx.x & 63;
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar row base
         const int r0 = blockIdx.x * SK_RPW + wv * RPWV;
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256, FAST ? SK_ROW_OCC : 4) void sk_row_pass(const 
                 preA[k] = (j < B1) ? *reinterpret_cast<const float4*>(row + j) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        for (int j = threadIdx.x * 2; j < B1; j += 512)
+        for (int j = threadIdx.x * 2; j < B1; j += 2 * SK_ROW_THREADS)
             *reinterpret_cast<double2*>(vs + j) = *reinterpret_cast<const double2*>(v + j);
         __syncthreads();
         if (RPWV == 1) {
@@ -478,6 +487,135 @@ __global__ __launch_bounds__(256, FAST ? SK_ROW_OCC : 4) void sk_row_pass(const 
     }
 }
 
+// ---- streaming row pass ------------------------------------------------------
+// A persistent grid (about two workgroups per CU): v is staged into LDS once per workgroup, every
+// wave walks its rows in 4096-column units and re-requests each pair of float4 registers for the
+// NEXT unit as soon as the current unit's trip has consumed them, so the loads of one unit are in
+// flight while the previous one is reduced.  Measured on the 64 MiB matrix (scratch/probe): a
+// one-shot "request the row, stage v, reduce" workgroup shape takes 18 us where the bare reads take
+// 10.7 us — all of the exp/LDS work lands behind the last load — a streaming shape 11.7 us.
+#ifndef SK_STREAM_WAVES
+#define SK_STREAM_WAVES 8
+#endif
+#ifndef SK_STREAM_UNIT
+#define SK_STREAM_UNIT 4         // float4 per lane and unit at most (256 columns each); 8, 16: 2 % and 9 % slower
+#endif
+#ifndef SK_STREAM_OCC
+#define SK_STREAM_OCC 2          // waves per SIMD the streaming row pass is compiled for
+#endif
+#define SK_STREAM_THREADS (64 * SK_STREAM_WAVES)
+
+// One 256*NF4-column unit: reduce the registers trip by trip; with NEXT, each trip's registers are
+// re-requested for the next unit right after they were consumed.  No branch in here: a conditional
+// load makes the compiler wait for ALL outstanding loads (vmcnt(0)) at every join, which serialises
+// the stream.
+template <bool PRECISE, int NF4, bool NEXT>
+__device__ __forceinline__ void sk_stream_unit(float4 (&c)[SK_ROW_PRE], const float* __restrict__ nxt, int col0,
+                                               double inv_reg, const double* __restrict__ vs, double& m,
+                                               typename std::conditional<PRECISE, double, float>::type& s) {
+    constexpr int UT = PRECISE ? 1 : 2;
+#pragma unroll
+    for (int t = 0; t < NF4 / UT; ++t) {
+        float4 c4[UT];
+#pragma unroll
+        for (int k = 0; k < UT; ++k) c4[k] = c[UT * t + k];
+        sk_row_trip<PRECISE, UT>(c4, col0 + 256 * UT * t, inv_reg, vs, m, s);
+        if (NEXT) {
+#pragma unroll
+            for (int k = 0; k < UT; ++k) c[UT * t + k] = *reinterpret_cast<const float4*>(nxt + 256 * (UT * t + k));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool PRECISE, int NF4>
+__device__ __forceinline__ void sk_stream_rows(const float* __restrict__ M, int B0, int B1, double inv_reg,
+                                               double loga, const double* __restrict__ vs,
+                                               double* __restrict__ u, float4 (&c)[SK_ROW_PRE],
+                                               int r, int r_stride) {
+    typedef typename std::conditional<PRECISE, double, float>::type acc_t;
+    const int lane = threadIdx.x & 63;
+    constexpr int UW = 256 * NF4;      // columns per unit; B1 is a multiple of it
+    int seg = 0;
+    double m = SK_NEG;
+    acc_t s = 0;
+    if (r >= B0) return;
+    for (;;) {
+        int rn = r, segn = seg + UW;
+        if (segn >= B1) { segn = 0; rn = r + r_stride; }
+        const bool has_next = rn < B0;
+        if (has_next)
+            sk_stream_unit<PRECISE, NF4, true>(c, M + (size_t)rn * B1 + segn + lane * 4, seg + lane * 4, inv_reg, vs, m, s);
+        else
+            sk_stream_unit<PRECISE, NF4, false>(c, M, seg + lane * 4, inv_reg, vs, m, s);
+        if (segn == 0) {                       // the row is complete
+            const double mm = wave_max_d(m);
+            const double tot = wave_sum_d((double)s * exp(m - mm));
+            if (lane == 0) u[r] = loga - (mm + log(tot));
+            m = SK_NEG; s = 0;
+        }
+        if (!has_next) break;
+        r = rn; seg = segn;
+    }
+}
+
+template <int NF4>
+__global__ __launch_bounds__(SK_STREAM_THREADS, SK_STREAM_OCC) void sk_row_stream(const float* __restrict__ M, int B0, int B1,
+                                                      double inv_reg, double loga,
+                                                      SkState* __restrict__ st,
+                                                      const double* __restrict__ v,
+                                                      double* __restrict__ u,
+                                                      int check, int slot, double stop_thr, int ii,
+                                                      double precise_below) {
+    extern __shared__ __attribute__((aligned(16))) double vs[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // consecutive rows go to different workgroups
+    const int r0 = wv * gridDim.x + blockIdx.x;
+    const int r_stride = gridDim.x * SK_STREAM_WAVES;
+    // the first unit is requested before anything is known about the state: a kernel starts cold,
+    // and the state block would otherwise be a dependent hop in front of the matrix
+    float4 c[SK_ROW_PRE];
+    {
+        const float* row = M + (size_t)(r0 < B0 ? r0 : 0) * B1 + lane * 4;
+#pragma unroll
+        for (int k = 0; k < NF4; ++k) c[k] = *reinterpret_cast<const float4*>(row + 256 * k);
+    }
+    if (st->done) return;
+    if (check) {
+        const double err = sqrt(st->err2[slot]);
+        if (err < stop_thr) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                st->last_err = err;
+                st->iters_done = ii;
+                st->vfinal = (ii - 1) & 1;
+                __threadfence();
+                st->done = 1;
+            }
+            return;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->last_err = err;
+            if (!st->precise && err < precise_below && stop_thr < precise_below) st->precise = 1;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->err2[slot ^ 1] = 0.0;
+    const int precise = st->precise;
+    for (int j = threadIdx.x * 2; j < B1; j += 2 * SK_STREAM_THREADS)
+        *reinterpret_cast<double2*>(vs + j) = *reinterpret_cast<const double2*>(v + j);
+    __syncthreads();
+    if (precise) sk_stream_rows<true, NF4>(M, B0, B1, inv_reg, loga, vs, u, c, r0, r_stride);
+    else         sk_stream_rows<false, NF4>(M, B0, B1, inv_reg, loga, vs, u, c, r0, r_stride);
+}
+
+template <int NF4>
+static void sk_launch_stream(int grid, size_t lds, hipStream_t s, const float* M, int B0, int B1, double inv_reg,
+                             double loga, SkState* st, const double* v, double* u, int check, int slot,
+                             double stop_thr, int ii, double precise_below) {
+    hipLaunchKernelGGL(sk_row_stream<NF4>, dim3(grid), dim3(SK_STREAM_THREADS), lds, s, M, B0, B1, inv_reg, loga,
+                       st, v, u, check, slot, stop_thr, ii, precise_below);
+}
+
 __global__ void sk_finish(SkState* st, const double* u, const double* v0, const double* v1,
                           int B0, int B1, double reg, float* f, float* g, int* iters_done,
                           float* last_err, int pending_check, int slot) {
@@ -527,6 +665,30 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, 
         if (raised < 0) v_in_lds = 0;
     }
     const size_t lds = v_in_lds ? (size_t)B1 * 8 : 0;
+    // streaming row pass: a persistent grid of SK_STREAM_WAVES-wave workgroups
+    int stream_grid = 0, stream_nf4 = 0;
+    if (row_fast && v_in_lds) {
+        static int per_cu = -1, cus = 0;
+        if (per_cu < 0) {
+            const char* e = getenv("CFM_SK_STREAM");       // workgroups per CU; 0 = one-shot row pass
+            per_cu = e ? atoi(e) : 1;
+            int dev = 0; hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cus = prop.multiProcessorCount;
+            if (cus <= 0) cus = 256;
+            const void* fns[4] = {(const void*)sk_row_stream<4>, (const void*)sk_row_stream<8>,
+                                  (const void*)sk_row_stream<12>, (const void*)sk_row_stream<16>};
+            for (int q = 0; q < 4; ++q)
+                if (hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                    per_cu = 0;
+            (void)hipGetLastError();
+        }
+        // units of 256 * nf4 columns: the largest of 4, 8, 12, 16 float4 per lane that divides the row
+        for (int q = 4; q <= SK_STREAM_UNIT; q += 4)
+            if ((B1 / 256) % q == 0) stream_nf4 = q;
+        const int want = (B0 + SK_STREAM_WAVES - 1) / SK_STREAM_WAVES;
+        stream_grid = (per_cu > 0 && stream_nf4 > 0) ? (want < cus * per_cu ? want : cus * per_cu) : 0;
+    }
 
     int n = B0 > B1 ? B0 : B1;
     hipLaunchKernelGGL(sk_init, dim3((n + 255) / 256), dim3(256), 0, s, w.st, w.u, w.v[0], w.v[1],
@@ -548,8 +710,15 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, 
         hipLaunchKernelGGL(sk_col_finalize, dim3((B1 + 63) / 64), dim3(256), 0, s, B1, nchunk, logb, b,
                            w.st, w.pm, w.ps, w.v[(ii + 1) & 1], w.v[ii & 1], check, slot);
         if (trailing) break;
-        if (row_fast && v_in_lds)
-            hipLaunchKernelGGL(sk_row_pass<true>, dim3(row_wgs), dim3(256), lds, s, M, B0, B1, inv_reg, loga,
+        if (row_fast && v_in_lds && stream_grid > 0)
+            switch (stream_nf4) {
+            case 4:  sk_launch_stream<4>(stream_grid, lds, s, M, B0, B1, inv_reg, loga, w.st, w.v[ii & 1], w.u, check, slot, stop_thr, ii, precise_below); break;
+            case 8:  sk_launch_stream<8>(stream_grid, lds, s, M, B0, B1, inv_reg, loga, w.st, w.v[ii & 1], w.u, check, slot, stop_thr, ii, precise_below); break;
+            case 12: sk_launch_stream<12>(stream_grid, lds, s, M, B0, B1, inv_reg, loga, w.st, w.v[ii & 1], w.u, check, slot, stop_thr, ii, precise_below); break;
+            default: sk_launch_stream<16>(stream_grid, lds, s, M, B0, B1, inv_reg, loga, w.st, w.v[ii & 1], w.u, check, slot, stop_thr, ii, precise_below); break;
+            }
+        else if (row_fast && v_in_lds)
+            hipLaunchKernelGGL(sk_row_pass<true>, dim3(row_wgs), dim3(SK_ROW_THREADS), lds, s, M, B0, B1, inv_reg, loga,
                                w.st, w.v[ii & 1], w.u, rows_per_wg, check, slot, stop_thr, ii,
                                vec, v_in_lds, precise_below);
         else

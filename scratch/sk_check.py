@@ -5,6 +5,7 @@ import torch, numpy as np
 from cfm_amd import _lib
 import cfm_amd.optimal_transport as ot
 import cfm_oracle as oracle
+if os.environ.get('CFM_LIB_OVERRIDE'): _lib.LIB_PATH=os.environ['CFM_LIB_OVERRIDE']
 lib=_lib.load(); dev=_lib.require_gpu()
 tag=os.environ.get('CFM_SK_FUSED','1')
 def pots(r,B0,B1):
