@@ -149,7 +149,7 @@ def main():
         u_host, t_host = drawn
         if timed:
             ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        M = ot.cost_matrix(x0, x1)
+        M = ot.cost_matrix(x0, x1, matrix_cores=False)     # as OTPlanSampler(method="exact") does
         if timed:
             ea.record()
         perm, info = ot.assign_exact(M, return_info=True)

@@ -18,7 +18,7 @@ _lock = threading.Lock()
 _lib = None
 
 # ops (include/cfm_gfx950.h)
-OP_SINKHORN, OP_ASSIGN, OP_SAMPLE_DENSE, OP_MLP, OP_ODE, OP_UNBALANCED = 1, 2, 3, 4, 5, 6
+OP_SINKHORN, OP_ASSIGN, OP_SAMPLE_DENSE, OP_MLP, OP_ODE, OP_UNBALANCED, OP_COST = 1, 2, 3, 4, 5, 6, 7
 VARIANT_ICFM, VARIANT_SB, VARIANT_TARGET, VARIANT_VP = 0, 1, 2, 3
 
 ERRORS = {
@@ -44,6 +44,7 @@ SIGNATURES = {
     "cfm_abi_version": (_i, []),
     "cfm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "cfm_sqeuclid_cost_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "cfm_sqeuclid_cost_ws_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "cfm_scale_inv_f32": (_i, [_vp, _sz, _vp, _vp]),
     "cfm_sqrt_inplace_f32": (_i, [_vp, _sz, _vp]),
     "cfm_sinkhorn_log_f32": (_i, [_vp, _i, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -2,10 +2,15 @@
 //
 // Replaces torch.cdist(x0, x1) ** 2 (torchcfm/optimal_transport.py:84).
 // Direct-difference form  M[i,j] = sum_k (x0[i,k] - x1[j,k])^2  in fp32: no
-// sqrt/square round trip and no ||x||^2+||y||^2-2xy cancellation.
+// sqrt/square round trip and no ||x||^2+||y||^2-2xy cancellation — and, for d >= 64 (with
+// scratch: cfm_sqeuclid_cost_ws_f32), the centred Gram form on the matrix cores with every
+// cancelling entry recomputed in the direct form.
 //
-// Two kernels:
-//   cost_small_d : d <= 16.  Output-write bound (4*B0*B1 bytes): each lane owns
+// Three kernels:
+//   cost_gemm    : d >= 64, B0, B1 >= 256.  v_mfma_f32_32x32x2_f32, 128x128 tile per workgroup;
+//                  measured max relative error 2-5e-7 against fp64 (direct form: 0.5-2e-6),
+//                  368 us at B = 4096, d = 784 (direct: 574 us).  See the section below.
+//   cost_small_d : d <= 8.  Output-write bound (4*B0*B1 bytes): each lane owns
 //                  four consecutive columns whose x1 rows live in registers,
 //                  loops over a strip of rows (x0 row is wave-uniform) and
 //                  stores one float4 per row -> 1 KiB contiguous per wave store.
@@ -16,6 +21,7 @@
 //                  8x8 super-tiles of workgroups per XCD so both operand panels
 //                  stay in that XCD's 4 MiB L2.
 #include "cfm_common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------- small d ----
 template <int D>
@@ -176,6 +182,222 @@ __global__ __launch_bounds__(256) void cost_tiled(const float* __restrict__ x0,
     }
 }
 
+// ------------------------------------------------------------------- MFMA ----
+// d >= 64: the Gram form on the matrix cores.  With every point centred on mu (the mean of 128
+// strided sample rows — any mu is valid, a central one keeps the norms at the scale of the
+// distances),  a_i = fl(x0_i - mu),  b_j = fl(x1_j - mu):
+//     M_ij = |a_i|^2 + |b_j|^2 - 2 <a_i, b_j>,        <a, b> on v_mfma_f32_32x32x2_f32
+// (exact fp32 products, fp32 accumulation).  The form cancels when a pair is much closer than the
+// cloud is wide, so every entry that comes out below 1/8 of |a_i|^2 + |b_j|^2 is recomputed in
+// the direct-difference form by its wave (64 lanes split the k loop): the relative error of what
+// is kept from the Gram form stays within 8x the direct form's, duplicates and x-vs-x diagonals
+// get the direct value.  2 flop per (i, j, k) at the 157 TFLOP/s matrix peak against 3 on the
+// packed vector pipes: 0.17 ms vs 0.33 ms floor at B = 4096, d = 784.
+typedef float cost_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void cost_center(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                   int B0, int B1, int d, float* __restrict__ mu) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int n0 = min(B0, 64), n1 = min(B1, 64);
+    float s = 0.f;
+    if (c < d) {
+        for (int q = g; q < n0; q += 4) s += x0[(size_t)((long long)q * B0 / n0) * d + c];
+        for (int q = g; q < n1; q += 4) s += x1[(size_t)((long long)q * B1 / n1) * d + c];
+    }
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && c < d) mu[c] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)(n0 + n1);
+}
+
+// nrm[i] = |fl(x0_i - mu)|^2 (i < B0), nrm[B0 + j] = |fl(x1_j - mu)|^2: one wave per row
+__global__ __launch_bounds__(256) void cost_norms(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                  int B0, int B1, int d, const float* __restrict__ mu,
+                                                  float* __restrict__ nrm) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B0 + B1) return;
+    const float* p = row < B0 ? x0 + (size_t)row * d : x1 + (size_t)(row - B0) * d;
+    float s = 0.f;
+    for (int k = lane; k < d; k += 64) {
+        const float t = p[k] - mu[k];
+        s = fmaf(t, t, s);
+    }
+    s = wave_sum_f(s);
+    if (lane == 0) nrm[row] = s;
+}
+
+// BM x 128 output tile per workgroup, 2 x 2 waves.
+template <int BM, bool VEC>
+__global__ __launch_bounds__(256) void cost_gemm(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                 int B0, int B1, int d, const float* __restrict__ mu,
+                                                 const float* __restrict__ nrm, float* __restrict__ M,
+                                                 int tiles_m, int tiles_n) {
+    constexpr int BN = 128, BK = 32, LD = BK + 1;
+    constexpr int MT = BM / 64;                    // 32-row MFMA tiles per wave along M
+    constexpr int QA = BM / 32, QB = BN / 32;      // float4 per thread and stage (A, B)
+    __shared__ float As[BM * LD];
+    __shared__ float Bs[BN * LD];
+
+    // XCD-aware super-tile order (as cost_tiled): each XCD walks 8x8 groups of tiles
+    unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    {
+        const int G = 8;
+        const int per_band = G * tiles_n;
+        const int band = lid / per_band, r = lid - band * per_band;
+        const int rows_in_band = min(G, tiles_m - band * G);
+        const int fgt = rows_in_band * G;
+        const int gcol = r / fgt;
+        const int rr = r - gcol * fgt;
+        const int cols_in_group = min(G, tiles_n - gcol * G);
+        tm = band * G + rr / cols_in_group;
+        tn = gcol * G + rr % cols_in_group;
+    }
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;          // 2 x 2 waves, (BM / 2) x 64 outputs each
+
+    cost_f32x16 acc[MT][2];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // a stage is [128 rows x 32 k] per operand.  VEC: thread owns float4 (row (tid >> 3) + 32 q,
+    // k = 4 (tid & 7)); otherwise single floats (row (tid >> 5) + 8 q, k = tid & 31): the k slot of
+    // a thread is the same for all of its elements, so mu is read once per stage.
+    float4 ra[QA], rb[QB];
+    auto fetch = [&](int k0) {
+        if (VEC) {
+            const int gk = k0 + 4 * (tid & 7);
+            const bool kin = gk < d;
+            const float4 m4 = kin ? *reinterpret_cast<const float4*>(mu + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < QA; ++q) {
+                const int ga = row0 + (tid >> 3) + 32 * q;
+                float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kin && ga < B0) {
+                    va = *reinterpret_cast<const float4*>(x0 + (size_t)ga * d + gk);
+                    va.x -= m4.x; va.y -= m4.y; va.z -= m4.z; va.w -= m4.w;
+                }
+                ra[q] = va;
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int gb = col0 + (tid >> 3) + 32 * q;
+                float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kin && gb < B1) {
+                    vb = *reinterpret_cast<const float4*>(x1 + (size_t)gb * d + gk);
+                    vb.x -= m4.x; vb.y -= m4.y; vb.z -= m4.z; vb.w -= m4.w;
+                }
+                rb[q] = vb;
+            }
+        } else {
+            const int gk = k0 + (tid & 31);
+            const bool kin = gk < d;
+            const float m1 = kin ? mu[gk] : 0.f;
+            float* fa = reinterpret_cast<float*>(ra);
+            float* fb = reinterpret_cast<float*>(rb);
+#pragma unroll
+            for (int q = 0; q < 4 * QA; ++q) {
+                const int ga = row0 + (tid >> 5) + 8 * q;
+                fa[q] = (kin && ga < B0) ? x0[(size_t)ga * d + gk] - m1 : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4 * QB; ++q) {
+                const int gb = col0 + (tid >> 5) + 8 * q;
+                fb[q] = (kin && gb < B1) ? x1[(size_t)gb * d + gk] - m1 : 0.f;
+            }
+        }
+    };
+    auto stash = [&]() {
+        if (VEC) {
+            const int kc = 4 * (tid & 7);
+#pragma unroll
+            for (int q = 0; q < QA; ++q) {
+                float* pa = &As[((tid >> 3) + 32 * q) * LD + kc];
+                pa[0] = ra[q].x; pa[1] = ra[q].y; pa[2] = ra[q].z; pa[3] = ra[q].w;
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                float* pb = &Bs[((tid >> 3) + 32 * q) * LD + kc];
+                pb[0] = rb[q].x; pb[1] = rb[q].y; pb[2] = rb[q].z; pb[3] = rb[q].w;
+            }
+        } else {
+            const float* fa = reinterpret_cast<const float*>(ra);
+            const float* fb = reinterpret_cast<const float*>(rb);
+#pragma unroll
+            for (int q = 0; q < 4 * QA; ++q) As[((tid >> 5) + 8 * q) * LD + (tid & 31)] = fa[q];
+#pragma unroll
+            for (int q = 0; q < 4 * QB; ++q) Bs[((tid >> 5) + 8 * q) * LD + (tid & 31)] = fb[q];
+        }
+    };
+
+    fetch(0);
+    const int fr = lane & 31, fk = lane >> 5;
+    for (int k0 = 0; k0 < d; k0 += BK) {
+        stash();
+        __syncthreads();
+        if (k0 + BK < d) fetch(k0 + BK);            // in flight while the MFMAs run
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[MT], b[2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = As[(wm * (BM / 2) + m * 32 + fr) * LD + kk + fk];
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) b[nn] = Bs[(wn * 64 + nn * 32 + fr) * LD + kk + fk];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[nn], acc[m][nn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue.  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+    if (tid < BM) As[tid] = (row0 + tid < B0) ? nrm[row0 + tid] : 0.f;
+    if (tid < BN) Bs[tid] = (col0 + tid < B1) ? nrm[B0 + col0 + tid] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+        const int cl = wn * 64 + nn * 32 + (lane & 31);
+        const int gc = col0 + cl;
+        const float ny = Bs[cl];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * (BM / 2) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int gr = row0 + rl;
+                const float sum = As[rl] + ny;
+                float v = fmaxf(fmaf(-2.f, acc[m][nn][r], sum), 0.f);
+                const bool ok = gr < B0 && gc < B1;
+                // cancellation: this wave recomputes the entry in the direct form
+                unsigned long long mask = __ballot(ok && v < 0.125f * sum);
+                while (mask) {
+                    const int l = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int gi = __shfl(gr, l, 64), gj = __shfl(gc, l, 64);
+                    const float* pa = x0 + (size_t)gi * d;
+                    const float* pb = x1 + (size_t)gj * d;
+                    float p = 0.f;
+                    for (int k = lane; k < d; k += 64) {
+                        const float t = pa[k] - pb[k];
+                        p = fmaf(t, t, p);
+                    }
+                    p = wave_sum_f(p);
+                    if (lane == l) v = p;
+                }
+                if (ok) M[(size_t)gr * B1 + gc] = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------- max / scale / sqrt --
 __global__ __launch_bounds__(256) void max_reduce_f32(const float* __restrict__ M, size_t n,
                                                       unsigned* __restrict__ out_bits) {
@@ -213,12 +435,57 @@ static void launch_small(const float* x0, const float* x1, int B0, int B1, float
     hipLaunchKernelGGL(cost_small_d<D>, grid, dim3(256), 0, st, x0, x1, B0, B1, M, rows_per_block);
 }
 
+// Gram form on the matrix cores for d >= 64 and at least a 2 x 2 grid of tiles (ws: mu [d padded],
+// norms [B0 + B1]); 0 = not taken.
+extern "C" size_t cfm_cost_ws_bytes_internal(int B0, int B1, int d) {
+    return sizeof(float) * ((size_t)((d + 63) & ~63) + (size_t)B0 + (size_t)B1) + 256;
+}
+static bool cost_use_mfma(int B0, int B1, int d) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("CFM_COST_MFMA"); off = (e && e[0] == '0') ? 1 : 0; }
+    return !off && d >= 64 && B0 >= 256 && B1 >= 256;
+}
+static int cost_mfma(const float* x0, const float* x1, int B0, int B1, int d, float* M, void* ws,
+                     hipStream_t st) {
+    float* mu = reinterpret_cast<float*>(ws);
+    float* nrm = mu + ((d + 63) & ~63);
+    hipLaunchKernelGGL(cost_center, dim3((d + 63) / 64), dim3(256), 0, st, x0, x1, B0, B1, d, mu);
+    hipLaunchKernelGGL(cost_norms, dim3((B0 + B1 + 3) / 4), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm);
+    const bool vec = (d % 4 == 0) && (((uintptr_t)x0 & 15) == 0) && (((uintptr_t)x1 & 15) == 0);
+    // (256 x 128 tiles — 8 MFMA tiles per wave, one resident round at B = 4096 — were measured at
+    //  549 us against 368 us for 128 x 128: the accumulators leave two waves per SIMD no room.)
+    const int tm = (B0 + 127) / 128, tn = (B1 + 127) / 128;
+    if (vec) hipLaunchKernelGGL((cost_gemm<128, true>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, M, tm, tn);
+    else     hipLaunchKernelGGL((cost_gemm<128, false>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, M, tm, tn);
+    return cfm_status();
+}
+
+static int cost_dispatch(const float* x0, const float* x1, int B0, int B1, int d, float* M,
+                         float* opt_max, void* ws, void* stream);
+
 extern "C" int cfm_sqeuclid_cost_f32(const float* x0, const float* x1, int B0, int B1, int d,
                                      float* M, float* opt_max, void* stream) {
+    return cost_dispatch(x0, x1, B0, B1, d, M, opt_max, nullptr, stream);
+}
+
+extern "C" int cfm_sqeuclid_cost_ws_f32(const float* x0, const float* x1, int B0, int B1, int d,
+                                        float* M, float* opt_max, void* ws, void* stream) {
+    if (!ws || ((uintptr_t)ws & 15) != 0) return ws ? CFM_EALIGN : CFM_EINVAL;
+    return cost_dispatch(x0, x1, B0, B1, d, M, opt_max, ws, stream);
+}
+
+static int cost_dispatch(const float* x0, const float* x1, int B0, int B1, int d, float* M,
+                         float* opt_max, void* ws, void* stream) {
     if (!x0 || !x1 || !M || B0 < 0 || B1 < 0 || d <= 0) return CFM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (B0 == 0 || B1 == 0) return 0;
     bool small = true;
+    if (ws && cost_use_mfma(B0, B1, d)) {
+        int rc = cost_mfma(x0, x1, B0, B1, d, M, ws, st);
+        if (rc) return rc;
+        small = true;      // done
+        goto finish;
+    }
     switch (d) {
         case 1: launch_small<1>(x0, x1, B0, B1, M, st); break;
         case 2: launch_small<2>(x0, x1, B0, B1, M, st); break;
@@ -243,6 +510,7 @@ extern "C" int cfm_sqeuclid_cost_f32(const float* x0, const float* x1, int B0, i
             else     hipLaunchKernelGGL((cost_tiled<4, false>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, M, tm, tn);
         }
     }
+finish:
     int rc = cfm_status();
     if (rc) return rc;
     if (opt_max) {

@@ -46,6 +46,7 @@ extern "C" {
 #define CFM_OP_MLP           4
 #define CFM_OP_ODE           5
 #define CFM_OP_UNBALANCED    6   /* also the partial (Dykstra) solver */
+#define CFM_OP_COST          7   /* cfm_sqeuclid_cost_ws_f32 (B0, B1, d)  */
 
 /* variants for cfm_sample_xt_ut_f32 (reference class in parentheses) */
 #define CFM_VARIANT_ICFM   0  /* ConditionalFlowMatcher / ExactOT...          */
@@ -65,6 +66,15 @@ size_t cfm_workspace_bytes(int op, int B0, int B1, int d);
  * x0 [B0,d], x1 [B1,d], M [B0,B1], fp32. */
 int cfm_sqeuclid_cost_f32(const float* x0, const float* x1, int B0, int B1, int d,
                           float* M, float* opt_max, void* stream);
+
+/* K1, matrix-core form — same contract and result class as cfm_sqeuclid_cost_f32, with scratch:
+ * for d >= 64 and B0, B1 >= 256 the Gram form |a|^2 + |b|^2 - 2<a,b> of the points centred on a
+ * sample mean runs on v_mfma_f32_32x32x2_f32, and every entry where that form cancels (result
+ * below 1/8 of |a|^2 + |b|^2: near-duplicates, an x-vs-x diagonal) is recomputed in the
+ * direct-difference form; other shapes take the direct kernels of cfm_sqeuclid_cost_f32.
+ * ws: cfm_workspace_bytes(CFM_OP_COST,B0,B1,d) bytes, 16-byte aligned. */
+int cfm_sqeuclid_cost_ws_f32(const float* x0, const float* x1, int B0, int B1, int d,
+                             float* M, float* opt_max, void* ws, void* stream);
 
 /* M[i] *= 1/(*maxval)   — `M / M.max()`     torchcfm/optimal_transport.py:86 */
 int cfm_scale_inv_f32(float* M, size_t n, const float* maxval, void* stream);

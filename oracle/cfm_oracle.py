@@ -100,8 +100,18 @@ def sqeuclid_cost_f64(x0, x1):
     b = np.asarray(x1, dtype=np.float64).reshape(len(x1), -1)
     if a.shape[1] <= 16:
         return ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
-    M = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * (a @ b.T)
-    return np.maximum(M, 0.0)
+    # float64 Gram form of the centred clouds (the translation changes no distance and keeps the
+    # norms at the scale of the cloud); the few entries where even that cancels more than six
+    # digits (duplicates, an x-vs-x diagonal) are redone as plain differences
+    mu = (a.sum(0) + b.sum(0)) / (len(a) + len(b))
+    a, b = a - mu, b - mu
+    na, nb = (a * a).sum(1), (b * b).sum(1)
+    M = np.maximum(na[:, None] + nb[None, :] - 2.0 * (a @ b.T), 0.0)
+    ii, jj = np.nonzero(M < 1e-6 * (na[:, None] + nb[None, :]))
+    for s0 in range(0, len(ii), 65536):
+        i, j = ii[s0:s0 + 65536], jj[s0:s0 + 65536]
+        M[i, j] = ((a[i] - b[j]) ** 2).sum(1)
+    return M
 
 
 def ref_cost_f32(x0, x1):

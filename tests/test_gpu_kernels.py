@@ -48,6 +48,65 @@ def test_cost_matches_f64_oracle(dev, B0, B1, d):
     assert (M >= 0).all()
 
 
+def _direct_cost(x0, x1, dev):
+    """The scratch-free entry point: always the direct-difference kernels."""
+    from cfm_amd import _lib
+    lib = _lib.load()
+    a, b = x0.to(dev), x1.to(dev)
+    M = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=dev)
+    _lib.check(lib.cfm_sqeuclid_cost_f32(_lib.ptr(a), _lib.ptr(b), a.shape[0], b.shape[0], a.shape[1], _lib.ptr(M),
+                                         None, _lib.stream_ptr()), "cfm_sqeuclid_cost_f32")
+    return M.cpu().numpy()
+
+
+def _cloud(kind, B0, B1, d):
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    if kind == "offset":            # a cloud far from the origin: the uncentred Gram form would lose 4 digits
+        return rn(B0, d) + 100.0, rn(B1, d) + 100.3
+    if kind == "near_duplicates":   # every diagonal pair 1e-3 apart in a cloud of width 1
+        x = rn(B0, d)
+        return x, x[torch.arange(B1) % B0] + 1e-3 * rn(B1, d)
+    if kind == "blobs":             # tight clusters: a whole block of pairs cancels
+        c = rn(8, d) * 5
+        return c[torch.arange(B0) % 8] + 0.01 * rn(B0, d), c[torch.arange(B1) % 8] + 0.01 * rn(B1, d)
+    if kind == "pixels":            # the C3 shape: Gaussian noise against [0, 1] pixel-like rows
+        return rn(B0, d), torch.rand(B1, d, generator=g).pow(4)
+    if kind == "tiny":
+        return rn(B0, d) * 1e-3, rn(B1, d) * 1e-3
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["offset", "near_duplicates", "blobs", "pixels", "tiny"])
+@pytest.mark.parametrize("B0,B1,d", [(256, 256, 64), (300, 260, 100), (257, 515, 65), (640, 512, 784)])
+def test_cost_matrix_core_form_vs_f64_oracle(dev, kind, B0, B1, d):
+    """d >= 64, B >= 256: the centred Gram form on the MFMA units, cancelling entries recomputed
+    directly.  Same bound as the direct kernels, entry by entry, on clouds built to break a Gram form."""
+    ot = _ot()
+    x0, x1 = _cloud(kind, B0, B1, d)
+    M = ot.cost_matrix(x0.to(dev), x1.to(dev)).cpu().numpy()
+    ref = oracle.sqeuclid_cost_f64(x0.numpy(), x1.numpy())
+    tol = 4e-7 * max(4.0, np.sqrt(d))
+    err = np.abs(M - ref) / np.maximum(ref, 1e-30)
+    assert err.max() < tol, (kind, err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert (M >= 0).all()
+    # and it agrees with the direct kernels to the sum of the two bounds
+    Md = _direct_cost(x0, x1, dev)
+    assert (np.abs(M - Md) <= 2 * tol * np.maximum(ref, 1e-30)).all()
+
+
+def test_cost_matrix_core_form_self_distance_is_zero(dev):
+    """x against itself: the diagonal cancels completely in a Gram form; it is recomputed -> exact 0."""
+    ot = _ot()
+    x = _rand(512, 128, 3) * 3 + 7
+    M = ot.cost_matrix(x.to(dev), x.clone().to(dev)).cpu().numpy()
+    assert (np.diag(M) == 0).all()
+    assert np.array_equal(M, M.T) or np.abs(M - M.T).max() <= 1e-6 * M.max()
+    ref = oracle.sqeuclid_cost_f64(x.numpy(), x.numpy())
+    off = ~np.eye(512, dtype=bool)
+    assert (np.abs(M - ref)[off] / ref[off]).max() < 4e-7 * np.sqrt(128)
+
+
 def test_cost_8gaussians_moons_and_normalize(dev):
     ot = _ot()
     x0, x1 = oracle.config_inputs("C1")
