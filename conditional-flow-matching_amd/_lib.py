@@ -70,6 +70,7 @@ EXTRA_SIGNATURES = {
     "cfm_assign_set_params": (None, [_d, _d, _d, _d, _i, _i, _i]),
     "cfm_assign_set_mode": (None, [_i]),
     "cfm_assign_set_handoff": (None, [_i]),
+    "cfm_assign_debug_times": (_i, [_vp, _vp]),
     "cfm_assign_set_wide_blocks": (None, [_i]),
     "cfm_assign_set_ms_quantile": (None, [_d]),
     "cfm_assign_set_stop_early": (None, [_d]),

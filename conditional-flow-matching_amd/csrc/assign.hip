@@ -93,6 +93,8 @@ extern "C" void cfm_assign_set_wide_blocks(int cap) { g_wide_blocks_cap = cap > 
 extern "C" void cfm_assign_set_handoff(int handoff) { if (handoff >= 0) g_params.handoff = handoff; }
 extern "C" void cfm_assign_set_stop_early(double f) { if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
 extern "C" void cfm_assign_set_ms_quantile(double q) { if (q > 0.0 && q <= 1.0) g_params.ms_q = q; }
+// (cfm_assign_debug_times, below the state definition: microseconds per state-machine mode of the
+//  last solve on a workspace)
 
 struct AsgState {
     int mode, n, phase, round;
@@ -116,7 +118,25 @@ struct AsgState {
     double ms_q;
     double stop_early;
     int wide_blocks, pad5;    // grid of asg_wide
+    // time accounting (100 MHz device clock): every controller launch books the time since the
+    // previous one on the mode that pair of launches ran in
+    long long t_prev;
+    long long t_acc[16];
+    int t_ctrl[16];       // ... and the controller's own share of it
 };
+static_assert(sizeof(AsgState) <= 512, "AsgState has 512 bytes at the head of the workspace");
+
+// Tuning aid, not part of the ABI: microseconds the last solve on `ws` spent in each mode (slots
+// 0-15, index = MODE_*: wide launch + controller launch + gaps) and, of that, inside the controller
+// kernel itself (slots 16-31).  Blocking.
+extern "C" int cfm_assign_debug_times(const void* ws, double* us32) {
+    if (!ws || !us32) return CFM_EINVAL;
+    AsgState h;
+    int rc = cfm_hip(hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost));
+    if (rc) return rc;
+    for (int q = 0; q < 16; ++q) { us32[q] = (double)h.t_acc[q] * 0.01; us32[16 + q] = (double)h.t_ctrl[q] * 0.01; }
+    return 0;
+}
 
 // SAP scan list entry arrays (two copies: current / next)
 struct SList {
@@ -163,8 +183,14 @@ __device__ __forceinline__ SList slist(const AsgWs& w, int c) {
     return L;
 }
 
-#define MS_YMAX 4       // a big relax round is split over this many workgroups per column group
-#define MS_SPLIT_MIN 256 // ... when it has more than this many entries
+#ifndef MS_YMAX
+#define MS_YMAX 4
+#endif
+#ifndef MS_SPLIT_MIN
+#define MS_SPLIT_MIN 256
+#endif
+// MS_YMAX: a big relax round is split over this many workgroups per column group
+// MS_SPLIT_MIN: ... when it has more than this many entries
 
 static inline size_t asg_ws_bytes(int n) {
     size_t N = (size_t)n;
@@ -601,6 +627,8 @@ __device__ __forceinline__ void wide_relax(const float* __restrict__ M, const As
             if (Y > 1) {
                 w.part_d[(size_t)y * n + k] = best; w.part_i[(size_t)y * n + k] = bi; w.part_r[(size_t)y * n + k] = br;
             } else if (best < w.dist[k]) {
+                // (requesting dist / owner / the owner's cost up front, next to the list entries,
+                //  instead of here was measured: no change — the hops are not what bounds a round)
                 w.dist[k] = best; w.pred[k] = bi;
                 const int ow = w.owner[k];
                 if (ow >= 0 && best < dfree) {
@@ -1009,8 +1037,7 @@ __device__ void ctrl_enter_cert(AsgState* st) {
     }
 }
 
-__global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
-    extern __shared__ __attribute__((aligned(16))) int dyn[];   // 2*n ints for the path walk
+__device__ __forceinline__ void asg_ctrl_body(const AsgWs& w, int* dyn) {
     __shared__ int sh[32];
     __shared__ double shd[32];
     __shared__ int shi[32];
@@ -1025,7 +1052,12 @@ __global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
     const bool use_lds = (n <= 6144);
     if (mode == MODE_DONE || st->error) return;
     __syncthreads();
-    if (threadIdx.x == 0) st->st_steps++;
+    if (threadIdx.x == 0) {
+        st->st_steps++;
+        const long long now = wall_clock64();
+        if (st->t_prev) st->t_acc[mode & 15] += now - st->t_prev;
+        st->t_prev = now;
+    }
     __syncthreads();
 
     if (mode == MODE_INIT) {
@@ -1191,6 +1223,15 @@ __global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
     }
 }
 
+__global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
+    extern __shared__ __attribute__((aligned(16))) int dyn[];   // 2*n ints for the path walk
+    const int mode0 = w.st->mode;
+    asg_ctrl_body(w, dyn);
+    __syncthreads();
+    if (threadIdx.x == 0 && mode0 != MODE_DONE)        // t_prev = this launch's start
+        w.st->t_ctrl[mode0 & 15] += (int)(wall_clock64() - w.st->t_prev);
+}
+
 // trivial sizes
 __global__ void asg_trivial(const float* M, int n, int* perm, int* certified, double* total_cost,
                             int* stats) {
@@ -1218,9 +1259,21 @@ __global__ void asg_export(AsgWs w, int n, int* perm, int* certified, double* to
 // cannot be captured (the legacy default stream) or CFM_ASG_GRAPH=0.
 struct AsgGraph {
     void* ws = nullptr; int n = 0, pairs = 0; size_t wide_dyn = 0;
-    hipGraphExec_t exec = nullptr; hipStream_t stream = nullptr; int disabled = 0;
+    hipGraphExec_t exec = nullptr;         // `pairs` kernel pairs: the bulk of a solve
+    hipGraphExec_t exec_small = nullptr;   // ASG_TAIL_PAIRS pairs: the polled tail
+    hipStream_t stream = nullptr; int disabled = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
 };
+#define ASG_TAIL_PAIRS 8
 static thread_local AsgGraph g_graph;
+
+// 1 (default): bulk chunks, then 8-pair chunks with one chunk of look-ahead, each followed by a
+// copy of the state and an event; 0: 64-pair chunks with a blocking copy.
+static int asg_tail_poll_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CFM_ASG_TAILPOLL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
 
 static int asg_graph_enabled() {
     static int v = -1;
@@ -1294,23 +1347,63 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     bool use_graph = asg_graph_enabled() && !G.disabled && n >= 256;
     if (use_graph && !(G.exec && G.ws == ws && G.n == n && G.pairs == gchunk && G.wide_dyn == wide_dyn && G.stream == s)) {
         if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
-        hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-            for (int c = 0; c < gchunk; ++c) {
+        if (G.exec_small) { (void)hipGraphExecDestroy(G.exec_small); G.exec_small = nullptr; }
+        auto capture = [&](int npairs, hipGraphExec_t* out) -> hipError_t {
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (e != hipSuccess) return e;
+            for (int c = 0; c < npairs; ++c) {
                 hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), wide_dyn, s, w, n);
                 hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, w);
             }
             e = hipStreamEndCapture(s, &graph);
-            if (e == hipSuccess && graph) e = hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0);
+            if (e == hipSuccess && graph) e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
             if (graph) (void)hipGraphDestroy(graph);
-        }
-        if (e != hipSuccess || !G.exec) {
+            return e;
+        };
+        hipError_t e = capture(gchunk, &G.exec);
+        if (e == hipSuccess && G.exec) e = capture(ASG_TAIL_PAIRS, &G.exec_small);
+        for (int q = 0; q < 2 && e == hipSuccess; ++q)
+            if (!G.ev[q]) e = hipEventCreateWithFlags(&G.ev[q], hipEventDisableTiming);
+        if (e != hipSuccess || !G.exec || !G.exec_small) {
             (void)hipGetLastError();
-            G.exec = nullptr; G.disabled = 1; use_graph = false;     // e.g. the legacy default stream
+            if (G.exec) { (void)hipGraphExecDestroy(G.exec); }
+            if (G.exec_small) { (void)hipGraphExecDestroy(G.exec_small); }
+            G.exec = nullptr; G.exec_small = nullptr; G.disabled = 1; use_graph = false;     // e.g. the legacy default stream
         } else {
             G.ws = ws; G.n = n; G.pairs = gchunk; G.wide_dyn = wide_dyn; G.stream = s;
         }
+    }
+
+    if (use_graph && n >= 1024 && asg_tail_poll_enabled()) {
+        // The bulk (a solve at n = 4096 takes 135 - 230 pairs) goes out unpolled; the tail in
+        // 8-pair chunks, each followed by a 64-byte copy of the state into its own pinned slot and
+        // an event, with the NEXT chunk already queued when the host waits for a slot: no idle
+        // gap, and a finished solve is followed by at most ~1.5 chunks of no-op pairs.
+        const int bulk = (n >= 4096) ? 2 : 1;
+        for (int r = 0; r < bulk; ++r) { rc = cfm_hip(hipGraphLaunch(G.exec, s)); if (rc) return rc; }
+        int pairs = bulk * gchunk, cur = 0;
+        auto chunk = [&](int slot) -> int {
+            int r2 = cfm_hip(hipGraphLaunch(G.exec_small, s)); if (r2) return r2;
+            r2 = cfm_hip(hipMemcpyAsync(g_pinned + 16 * slot, w.st, 64, hipMemcpyDeviceToHost, s)); if (r2) return r2;
+            return cfm_hip(hipEventRecord(G.ev[slot], s));
+        };
+        rc = chunk(0); if (rc) return rc;
+        pairs += ASG_TAIL_PAIRS;
+        for (;;) {
+            rc = chunk(cur ^ 1); if (rc) return rc;
+            pairs += ASG_TAIL_PAIRS;
+            rc = cfm_hip(hipEventSynchronize(G.ev[cur])); if (rc) return rc;
+            const int* hs = g_pinned + 16 * cur;
+            const int mode = hs[0], err = hs[9];
+            if (err) return CFM_ENOCONV;
+            if (mode == MODE_DONE) { if (cert_out) *cert_out = hs[15]; break; }
+            if (pairs >= g_params.max_pairs) return CFM_ETIMEOUT;
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(asg_export, dim3((n + 1023) / 1024 < 64 ? (n + 1023) / 1024 : 64), dim3(1024), 0, s, w, n,
+                           perm, certified, total_cost, stats);
+        return cfm_status();
     }
 
     int pairs = 0;

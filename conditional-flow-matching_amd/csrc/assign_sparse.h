@@ -22,6 +22,9 @@
 // the fp64 certificate pass over the whole matrix still closes the solve.
 #pragma once
 
+#ifndef ASG_BUILD_VEC
+#define ASG_BUILD_VEC 1
+#endif
 #define SP_K 64
 #define SP_NMAX 4096
 #define SP_NOCOL 0xffffu
@@ -104,34 +107,70 @@ __device__ __forceinline__ void wide_build(const float* __restrict__ M, const As
     const int nt = (n + 63) / 64;
     float* r = reinterpret_cast<float*>(lds) + (size_t)wv * nt * 64 + lane;   // r[t * 64]
     const int wave_gid = wv * gridDim.x + blockIdx.x, n_waves = gridDim.x * SP_BUILD_WAVES;
+#if ASG_BUILD_VEC
+    const bool fastb = ((n & 1023) == 0) && n > SP_K;     // n <= SP_NMAX = 4096: at most 16 float4 per lane
+#else
+    const bool fastb = false;
+#endif
     for (int i = wave_gid; i < n; i += n_waves) {
         const float* row = M + (size_t)i * n;
-        double m = INFINITY;
-        for (int t0 = 0; t0 < nt; t0 += 8) {
-            float c[8]; double pk[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = (t0 + q) * 64 + lane;
-                c[q] = (k < n) ? row[k] : INFINITY; pk[q] = (k < n) ? w.p[k] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) m = fmin(m, (double)c[q] + pk[q]);
-        }
-        m = wave_min_d(m);
         float lmin = INFINITY;
-        for (int t0 = 0; t0 < nt; t0 += 8) {
-            float c[8]; double pk[8];
+        double m = INFINITY;
+        if (fastb) {
+            // whole row in one burst of float4 requests (lane owns columns 256 j + 4 lane + e <-> strip
+            // slot t = 4 j + e); the prices are read twice (32 KiB, cache resident), the row once
+            const int nj = n >> 8;
+            float4 c4[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = (t0 + q) * 64 + lane;
-                c[q] = (k < n) ? row[k] : INFINITY; pk[q] = (k < n) ? w.p[k] : 0.0;
+            for (int j = 0; j < 16; ++j)
+                c4[j] = *reinterpret_cast<const float4*>(row + 256 * (j < nj ? j : 0) + 4 * lane);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < nj) {
+                    const double2 pa = *reinterpret_cast<const double2*>(w.p + 256 * j + 4 * lane);
+                    const double2 pb = *reinterpret_cast<const double2*>(w.p + 256 * j + 4 * lane + 2);
+                    m = fmin(m, fmin(fmin((double)c4[j].x + pa.x, (double)c4[j].y + pa.y),
+                                     fmin((double)c4[j].z + pb.x, (double)c4[j].w + pb.y)));
+                }
             }
+            m = wave_min_d(m);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = (t0 + q) * 64 + lane;
-                if (t0 + q < nt) {
-                    const float x = (k < n) ? (float)(((double)c[q] + pk[q]) - m) : INFINITY;
-                    r[(t0 + q) * 64] = x; lmin = fminf(lmin, x);
+            for (int j = 0; j < 16; ++j) {
+                if (j < nj) {
+                    const double2 pa = *reinterpret_cast<const double2*>(w.p + 256 * j + 4 * lane);
+                    const double2 pb = *reinterpret_cast<const double2*>(w.p + 256 * j + 4 * lane + 2);
+                    const float x0 = (float)(((double)c4[j].x + pa.x) - m), x1 = (float)(((double)c4[j].y + pa.y) - m);
+                    const float x2 = (float)(((double)c4[j].z + pb.x) - m), x3 = (float)(((double)c4[j].w + pb.y) - m);
+                    r[(4 * j + 0) * 64] = x0; r[(4 * j + 1) * 64] = x1; r[(4 * j + 2) * 64] = x2; r[(4 * j + 3) * 64] = x3;
+                    lmin = fminf(lmin, fminf(fminf(x0, x1), fminf(x2, x3)));
+                }
+            }
+        } else {
+            for (int t0 = 0; t0 < nt; t0 += 8) {
+                float c[8]; double pk[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = (t0 + q) * 64 + lane;
+                    c[q] = (k < n) ? row[k] : INFINITY; pk[q] = (k < n) ? w.p[k] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m = fmin(m, (double)c[q] + pk[q]);
+            }
+            m = wave_min_d(m);
+            for (int t0 = 0; t0 < nt; t0 += 8) {
+                float c[8]; double pk[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = (t0 + q) * 64 + lane;
+                    c[q] = (k < n) ? row[k] : INFINITY; pk[q] = (k < n) ? w.p[k] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = (t0 + q) * 64 + lane;
+                    if (t0 + q < nt) {
+                        const float x = (k < n) ? (float)(((double)c[q] + pk[q]) - m) : INFINITY;
+                        r[(t0 + q) * 64] = x; lmin = fminf(lmin, x);
+                    }
                 }
             }
         }
@@ -157,7 +196,7 @@ __device__ __forceinline__ void wide_build(const float* __restrict__ M, const As
         const bool all = (tau == INFINITY);
         int off = 0;
         for (int t = 0; t < nt; ++t) {
-            const int k = t * 64 + lane;
+            const int k = fastb ? ((t >> 2) * 256 + 4 * lane + (t & 3)) : (t * 64 + lane);
             const bool mem = (k < n) && (all || r[t * 64] < tau);
             const unsigned long long mask = __ballot(mem);
             if (mask) {
