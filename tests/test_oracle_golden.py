@@ -210,3 +210,26 @@ def test_rectangular_exact_oracle_is_a_transport_plan():
         A[6 + j, j::4] = 1
     res = linprog(M.ravel(), A_eq=A, b_eq=np.r_[np.full(6, 1 / 6), np.full(4, 1 / 4)], bounds=(0, None))
     assert abs(res.fun - cost) < 1e-10
+
+
+@pytest.mark.parametrize("kind", ["offset", "duplicates", "self", "small_d"])
+def test_cost_oracle_is_cancellation_safe(kind):
+    """The float64 cost oracle (centred Gram form + plain differences where that cancels) against
+    the plain-difference sum evaluated with math.fsum-grade care (float128 accumulation)."""
+    rng = np.random.default_rng(11)
+    d = 8 if kind == "small_d" else 96
+    a = rng.standard_normal((40, d)).astype(np.float32)
+    b = rng.standard_normal((37, d)).astype(np.float32)
+    if kind == "offset":
+        a, b = a + np.float32(1e4), b + np.float32(1e4)
+    elif kind == "duplicates":
+        b = (a[np.arange(37) % 40] + np.float32(1e-4) * rng.standard_normal((37, d))).astype(np.float32)
+    elif kind == "self":
+        b = a[:37].copy()
+    M = oracle.sqeuclid_cost_f64(a, b)
+    diff = a.astype(np.longdouble)[:, None, :] - b.astype(np.longdouble)[None, :, :]
+    ref = (diff * diff).sum(-1).astype(np.float64)
+    assert M.shape == ref.shape and (M >= 0).all()
+    assert np.all(np.abs(M - ref) <= 1e-9 * np.maximum(ref, 1e-300))
+    if kind == "self":
+        assert (np.diag(M[:37, :37]) == 0).all()
