@@ -12,8 +12,11 @@
 //   sk_col_finalize  (per-column merge of the strip partials, new v, and — for
 //                    free — the marginal error of the PREVIOUS iteration:
 //                    colsum_j = b_j * exp(v_old_j - v_new_j));
-//   sk_row_pass      one wave per row, v staged in LDS (fp64), wave shuffle
-//                    reduction of the per-lane (max,sum) pairs.
+//   sk_row_stream    persistent grid, one 8-wave workgroup per CU: v staged in LDS (fp64) once per
+//                    workgroup, every wave streams its rows in 1024-column units (registers
+//                    re-requested for the next unit as each trip consumes them), wave
+//                    reduction of the per-lane (max,sum) pairs per row;
+//   sk_row_pass      the one-shot / generic form (ragged widths, v too wide for LDS).
 // The exponent (u_i + v_j - M_ij/reg) cancels three O(100/reg) numbers to O(1):
 // it is formed in fp64 (the chip is HBM-bound here; fp64 VALU is free), only
 // exp() itself runs in fp32.  Log-scalings u, v live in fp64 in the workspace.
