@@ -37,12 +37,15 @@ def test_python_binding_covers_header(lib_built):
 def test_workspace_sizes(lib_built):
     lib = lib_built.load()
     assert lib.cfm_abi_version() == 1
-    for op in (1, 2, 3, 4, 5):
+    for op in (1, 2, 3, 4, 5, 6, 7):
         n = lib.cfm_workspace_bytes(op, 4096, 4096, 784)
         assert n > 0 and n % 256 == 0
     assert lib.cfm_workspace_bytes(99, 4, 4, 4) == 0
     # Sinkhorn scratch is O(B) potentials + strip partials, far below the B^2 matrix
     assert lib.cfm_workspace_bytes(1, 4096, 4096, 0) < 16 * 2**20
+    # cost scratch (matrix-core form): the centre (d floats) and one norm per point
+    assert 4 * (784 + 8192) <= lib.cfm_workspace_bytes(7, 4096, 4096, 784) < 64 * 2**10
+    assert lib.cfm_workspace_bytes(7, 4096, 4096, 0) == 0
     # assignment scratch: O(B) state + 64 candidate (column, cost) pairs per row
     assert lib.cfm_workspace_bytes(2, 4096, 4096, 0) < 4 * 2**20
 
