@@ -123,6 +123,8 @@ def main():
     rank, local, world = D.init_from_env()
     if world != args.gpus and rank == 0:
         print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py measures the HIP path: it needs an MI355X (no CPU fallback exists)")
     dev_index = local % torch.cuda.device_count()     # one rank per GPU on a real node (identity there)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
