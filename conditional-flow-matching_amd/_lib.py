@@ -74,6 +74,7 @@ EXTRA_SIGNATURES = {
     "cfm_assign_set_wide_blocks": (None, [_i]),
     "cfm_assign_set_ms_quantile": (None, [_d]),
     "cfm_assign_set_stop_early": (None, [_d]),
+    "cfm_assign_set_bulk": (None, [_i, _i]),
     "cfm_plan_zero_entries_f64": (_i, [_vp, _vp, _i, _vp]),
     "cfm_ode_set_fused": (None, [_i]),
 }
@@ -148,23 +149,32 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-_ws_cache = {}
+_ws_tls = threading.local()
+_WS_CACHE_MAX = 64
 
 
 def workspace(op, B0, B1, d=0, device=None, tag=0):
-    """Cached scratch buffer for (op, shape); returned as a uint8 tensor."""
+    """Cached scratch buffer for (op, shape, stream) of the CALLING thread; a uint8 tensor.
+
+    The cache is per host thread (coupling workers each own a stream) and is never cleared under
+    another thread's feet; when it is full the least recently used entry of this thread is dropped
+    (the buffer goes back to torch's allocator, which orders its reuse behind the stream it was
+    allocated on)."""
     lib = load()
     device = device or require_gpu()
+    cache = getattr(_ws_tls, "cache", None)
+    if cache is None:
+        cache = _ws_tls.cache = {}
     key = (op, B0, B1, d, str(device), tag, torch.cuda.current_stream().cuda_stream)
-    buf = _ws_cache.get(key)
+    buf = cache.pop(key, None)
     if buf is None:
         n = lib.cfm_workspace_bytes(op, B0, B1, d)
         if n == 0:
             raise CfmBackendError(f"cfm_workspace_bytes({op},{B0},{B1},{d}) = 0")
         buf = torch.empty(n, dtype=torch.uint8, device=device)
-        if len(_ws_cache) > 64:
-            _ws_cache.clear()
-        _ws_cache[key] = buf
+        while len(cache) >= _WS_CACHE_MAX:
+            cache.pop(next(iter(cache)))
+    cache[key] = buf          # (re-)inserted last: dicts keep insertion order = recency
     return buf
 
 

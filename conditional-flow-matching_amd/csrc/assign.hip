@@ -6,25 +6,41 @@
 // the problem is the linear assignment problem on the fp32 cost matrix.
 //
 // MI355X design.  The 64 MiB (B=4096) cost matrix is Infinity-Cache resident, a
-// full sweep costs ~15-25 us, kernel boundaries ~1.5 us: the algorithm is built
-// from wide, cheap sweeps and a tiny sequential control step, all device
-// resident.  The host only pumps a fixed (asg_wide, asg_ctrl) kernel pair — replayed
-// as a hipGraph, the kernels take nothing but the workspace — and polls 64 bytes.
-// Every kernel of the chain starts cold, so each is organised as two dependent global
-// hops (everything a hop needs is requested together, speculatively if need be).
+// full sweep costs ~15-25 us, a kernel boundary ~1.5 us: the algorithm is a chain of
+// ~200 short, dependent, chip-wide steps.  It runs as a device-resident state machine:
+// every step is ONE kernel launch that takes nothing but the workspace (so the chain is
+// replayed as hipGraphs), does the step's wide work on all CUs, and whose LAST-ARRIVING
+// workgroup (device-scope arrival ticket) performs the step's control decision and
+// publishes the next mode.  Everything a control decision needs from the other
+// workgroups of its launch travels through device-scope atomics (counters, ordered
+// min / max words), so no release / acquire fence is paid; everything else is read by
+// the NEXT launch, where the kernel boundary is the fence.  A kernel whose family does
+// not own the current mode exits at once, so the host may replay a guessed program:
+// correctness never depends on the guess.  Four kernels, one per register / LDS
+// profile (no scratch, no oversized LDS reservation):
+//
+//   asg_f1     init + auction      UMIN0, INITRED, AUCTION, ARR, CONVERT
+//   asg_f2     phase C, dense      UMIN, COLRED, ROOTMIN, SAP, MS_FINISH, CERT
+//   asg_build  candidate lists     BUILD            (n <= 4096)
+//   asg_solve  one-workgroup list solver   SOLVER   (n <= 4096)
 //
 //   init     Jonker-Volgenant row + column reduction: u_i = min_j c_ij,
 //            p_j = max_i (u_i - c_ij) (every column tight for some row) — the auction
 //            then starts at eps = 8e-3 of the cost range instead of 0.2.
-//   phase A  epsilon-scaling forward auction, Jacobi rounds (wave <-> row, a row bids
-//            iff it is unmatched; prices staged in LDS, the bidder's 16 float4 per
-//            lane in flight before the barrier, branch-free fp64 top-2, DPP wave
-//            reduction, one 64-bit atomicMax per bid).
-//            Each epsilon phase is cut when <= 2 % of the rows are unassigned —
-//            the phases only have to produce good prices.
+//   phase A  epsilon-scaling forward auction, Jacobi rounds, one launch per round and NO
+//            award step: the whole state of an object is one 64-bit key, the order-
+//            preserving image of its fp64 price with the bidder's row in the low bits
+//            (the row bits are part of the price: a relative perturbation below 2^-38).
+//            Prices only rise in a forward auction, so atomicMax(key) IS the award.  A row
+//            is matched iff the key of the object it bid for last still carries its id.
+//            wave <-> row, all keys staged into LDS as prices, the bidder's 16 float4 per
+//            lane in flight at once, branch-free fp64 top-2, DPP wave reduction.
+//            Each epsilon phase is cut when <= 2 % of the rows were unassigned at the
+//            start of a round — the phases only have to produce good prices.
 //   phase B  the same rounds with epsilon = 0 (Jonker-Volgenant "augmenting row
-//            reduction"): every kept pair is exactly tight, duals are exactly
-//            feasible (up to fp64 rounding).
+//            reduction").  A bid is rounded DOWN onto the key grid, so the bidder's new
+//            object is its strict minimum: every kept pair is exactly tight and the duals
+//            (u_i = min_k c_ik + p_k) are exactly feasible.
 //   phase C  shortest augmenting paths for the remaining free rows.  First the free
 //            columns are "column reduced" (their stale auction prices are lowered until
 //            each is tight for some row: a pure dual ascent step).  Then MULTI-SOURCE
@@ -40,20 +56,26 @@
 //            the whole matrix, total cost.
 //
 // Exactness comes from phases B-D (fp64 on exactly the fp32 costs the caller
-// passed); phase A is a heuristic warm start.  Any winner among simultaneous
-// bidders is a valid Gauss-Seidel order, so the fp32-rounded bid in the atomic
-// key only affects speed.
+// passed); phase A is a heuristic warm start.
 #include "cfm_common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
-enum { MODE_INIT = 0, MODE_AUCTION = 1, MODE_ARR = 2, MODE_SAP = 3, MODE_CERT = 4, MODE_DONE = 5,
-       MODE_BUILD = 6, MODE_SAP1 = 7, MODE_SAP1_DONE = 8,
-       MODE_UMIN = 9,      // u_i = min_k (c_ik + p_k) for every row (before the column reduction)
-       MODE_COLRED = 10,   // lower the price of every free column until it is tight
-       MODE_ROOTMIN = 11,  // u_r for the free rows of the next multi-source phase
-       MODE_UMIN0 = 12,    // initial dual: u_i = min_j c_ij
-       MODE_INITRED = 13 };// initial prices: p_j = max_i (u_i - c_ij)   (row + column reduction)
+enum { MODE_UMIN0 = 0,     // u_i = min_j c_ij, cost range, key / bid state reset          (f1)
+       MODE_INITRED = 1,   // initial prices: p_j = max_i (u_i - c_ij), straight into the keys (f1)
+       MODE_AUCTION = 2,   // epsilon > 0 rounds                                             (f1)
+       MODE_ARR = 3,       // epsilon = 0 rounds                                             (f1)
+       MODE_CONVERT = 4,   // keys -> prices, matches, free lists (workgroup 0)              (f1)
+       MODE_UMIN = 5,      // u_i = min_k (c_ik + p_k) for every row                         (f2)
+       MODE_COLRED = 6,    // lower the price of every free column until it is tight         (f2)
+       MODE_ROOTMIN = 7,   // u_r for the free rows + start of a multi-source phase          (f2)
+       MODE_SAP = 8,       // one relax round of the forest                                  (f2)
+       MODE_MS_FINISH = 9, // accept one path per tree, dual update, augment (workgroup 0)   (f2)
+       MODE_CERT = 10,     // certificate pass; its last workgroup exports the result        (f2)
+       MODE_BUILD = 11,    // candidate lists                                                (build)
+       MODE_SOLVER = 12,   // one-workgroup list solver                                      (solve)
+       MODE_DONE = 13 };
 
 struct AsgParams {
     double theta;          // epsilon reduction factor
@@ -62,19 +84,24 @@ struct AsgParams {
     double stop_frac;      // cut a phase when unassigned <= stop_frac * n
     int round_cap;         // max rounds per epsilon phase
     int arr_cap;           // max epsilon = 0 rounds
-    int chunk;             // kernel pairs per host poll
-    int max_pairs;         // safety cap on kernel pairs
+    int chunk;             // launches per polled chunk
+    int max_launches;      // safety cap on launches
     int sparse;            // 1: the last free rows go to the one-workgroup candidate-list solver (n <= 4096)
     int handoff;           // ... once at most this many free rows are left
-    double ms_q;           // radius of a multi-source phase: quantile of the free-column labels
-    double stop_early;     // stop_frac of every epsilon phase but the last (0 = same as stop_frac; a looser
-                           // cut saves auction rounds but measured slower overall: 5.9 vs 4.8 ms at 0.05)
+    double stop_early;     // stop_frac of every epsilon phase but the last (0 = same as stop_frac)
+    int wide_blocks_cap;   // upper bound on the grid of the wide kernels (0 = none)
+    int bulk_a, bulk_c;    // launches of asg_f1 / asg_f2 enqueued before the first poll (n >= 1024)
 };
 
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 64, 400000, 1, 6, 1.0, 0.0};
+// Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
+// called from another thread never tear a running solve.
+static std::mutex g_params_mu;
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 8, 800000, 1, 6, 0.0, 0, 104, 72};
+static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
                                       double stop_frac, int round_cap, int arr_cap, int chunk) {
+    std::lock_guard<std::mutex> lk(g_params_mu);
     if (theta > 1.0) g_params.theta = theta;
     if (eps0_frac > 0) g_params.eps0_frac = eps0_frac;
     if (eps_last_frac > 0) g_params.eps_last_frac = eps_last_frac;
@@ -83,58 +110,61 @@ extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps
     if (arr_cap >= 0) g_params.arr_cap = arr_cap;
     if (chunk > 0) g_params.chunk = chunk;
 }
+extern "C" void cfm_assign_set_mode(int sparse) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.sparse = sparse ? 1 : 0; }
+// Upper bound on the workgroups of the wide kernels (0 = none): with several couplings in flight on
+// different streams a smaller grid lets their kernels run side by side.
+extern "C" void cfm_assign_set_wide_blocks(int cap) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.wide_blocks_cap = cap > 0 ? cap : 0; }
+extern "C" void cfm_assign_set_handoff(int handoff) { std::lock_guard<std::mutex> lk(g_params_mu); if (handoff >= 0) g_params.handoff = handoff; }
+extern "C" void cfm_assign_set_stop_early(double f) { std::lock_guard<std::mutex> lk(g_params_mu); if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
+extern "C" void cfm_assign_set_ms_quantile(double) {}   // kept for old tuning scripts: the radius is the largest free-column label
+extern "C" void cfm_assign_set_bulk(int bulk_a, int bulk_c) {
+    std::lock_guard<std::mutex> lk(g_params_mu);
+    if (bulk_a >= 0) g_params.bulk_a = bulk_a;
+    if (bulk_c >= 0) g_params.bulk_c = bulk_c;
+}
 
-extern "C" void cfm_assign_set_mode(int sparse) { g_params.sparse = sparse ? 1 : 0; }
-// Upper bound on the workgroups of asg_wide (0 = none).  The kernel runs one 1024-thread workgroup
-// per CU (128 VGPRs), so a 256-workgroup launch needs the whole chip; with several couplings in
-// flight on different streams a smaller grid lets their kernels run side by side.
-static int g_wide_blocks_cap = 0;
-extern "C" void cfm_assign_set_wide_blocks(int cap) { g_wide_blocks_cap = cap > 0 ? cap : 0; }
-extern "C" void cfm_assign_set_handoff(int handoff) { if (handoff >= 0) g_params.handoff = handoff; }
-extern "C" void cfm_assign_set_stop_early(double f) { if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
-extern "C" void cfm_assign_set_ms_quantile(double q) { if (q > 0.0 && q <= 1.0) g_params.ms_q = q; }
-// (cfm_assign_debug_times, below the state definition: microseconds per state-machine mode of the
-//  last solve on a workspace)
-
+// 512 bytes at the head of the workspace.  Line 0 is read-mostly inside a launch (its first 64 bytes
+// are what the host polls), line 1 holds every word that is updated with device-scope atomics inside
+// a launch (read back by the last-arriving workgroup with atomic loads: never through the L1), the
+// rest is bookkeeping that one launch writes and the next one reads.
 struct AsgState {
-    int mode, n, phase, round;
-    // [offset 16] the cost matrix: kernels take it from here (same cache line as `mode`) so that their
-    // launch arguments depend on the workspace only and the kernel pairs can be replayed as a hipGraph
-    const float* Mptr;
-    int nU, stop, arr_round, error;
-    int nF, fidx, i0, nS;
-    int jfree, certified, cert_bad, nN;
-    // stats
-    int st_auction_rounds, st_arr_rounds, st_free_after_arr, st_sap_batches;
-    int st_sap_row_scans, st_total_row_scans, st_steps, cur;
+    int mode, n, error, certified;
+    const float* Mptr;     // kernels take the matrix from here: launch arguments depend on the workspace only
+    int* out_perm; int* out_cert; double* out_cost; int* out_stats;   // caller's buffers
+    int tag, rb;           // current bid tag (1..254), row bits of a key
+    int round, phase, stop, arr_round, round_cap, arr_cap, sparse, handoff;
     double eps, eps_last, theta, stop_frac;
-    double cmin, cmax, dfree, total_cost;
-    unsigned long long minslack_ord, pad2;
-    unsigned cmin_bits, cmax_bits;  // ordered-float atomics
-    int round_cap, arr_cap;
-    int nFC, sparse;
-    int st_dense_fallbacks, handoff;
-    int st_ms_phases, st_ms_augmented;
-    double ms_q;
-    double stop_early;
-    int wide_blocks, pad5;    // grid of asg_wide
-    // time accounting (100 MHz device clock): every controller launch books the time since the
-    // previous one on the mode that pair of launches ran in
-    long long t_prev;
-    long long t_acc[16];
-    int t_ctrl[16];       // ... and the controller's own share of it
+    // ---- line 1
+    alignas(128) int ticket;   // arrivals of the current launch
+    int cnt;                   // bidders of the current round
+    int nN;                    // entries appended to the next scan list
+    int cert_bad;
+    unsigned cmin_bits, cmax_bits;      // ordered-float min / max of the matrix
+    int next_mode, pad0;                // decision of a workgroup-0 step
+    unsigned long long fr_min, fr_max;  // ordered min / max of the free-column labels after a relax round
+    unsigned long long minslack_ord;
+    double total_cost;
+    // ---- line 2
+    alignas(128) int nF;
+    int nFC, nS, cur;
+    double dfree, cmin, cmax, stop_early;
+    int st_auction_rounds, st_arr_rounds, st_free_after_arr, st_sap_batches;
+    int st_sap_row_scans, st_total_row_scans, st_steps, st_dense_fallbacks;
+    int st_ms_phases, st_ms_augmented, wide_blocks, pad1;
+    long long t_prev;          // time accounting (100 MHz device clock): every control step books the
+    long long t_acc[16];       // time since the previous one on the mode that launch ran in
 };
 static_assert(sizeof(AsgState) <= 512, "AsgState has 512 bytes at the head of the workspace");
+static_assert(offsetof(AsgState, ticket) == 128 && offsetof(AsgState, nF) == 256, "AsgState layout");
 
 // Tuning aid, not part of the ABI: microseconds the last solve on `ws` spent in each mode (slots
-// 0-15, index = MODE_*: wide launch + controller launch + gaps) and, of that, inside the controller
-// kernel itself (slots 16-31).  Blocking.
+// 0-15, index = MODE_*; launch + gap to the next launch).  Slots 16-31 are zero.  Blocking.
 extern "C" int cfm_assign_debug_times(const void* ws, double* us32) {
     if (!ws || !us32) return CFM_EINVAL;
     AsgState h;
     int rc = cfm_hip(hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost));
     if (rc) return rc;
-    for (int q = 0; q < 16; ++q) { us32[q] = (double)h.t_acc[q] * 0.01; us32[16 + q] = (double)h.t_ctrl[q] * 0.01; }
+    for (int q = 0; q < 16; ++q) { us32[q] = (double)h.t_acc[q] * 0.01; us32[16 + q] = 0.0; }
     return 0;
 }
 
@@ -149,21 +179,20 @@ struct SList {
 
 struct AsgWs {
     AsgState* st;
-    double* p;        // prices (= -v)
-    double* bidval;   // per bidder
+    double* p;        // prices (= -v), phase C on
+    double* bidval;   // u_i (row minima)
     double* dist;     // SAP labels
-    unsigned long long* packed;  // per object: (fp32 bid bits << 32) | (row+1)
+    unsigned long long* key;   // per object: ordered fp64 price, bidder's row in the low bits (phases A / B);
+                               // per-tree scratch of a multi-source phase afterwards
     int* a;           // row -> col (or -1)
     int* owner;       // col -> row (or -1)
-    int* bidcol;
-    int* listA;       // unassigned rows (current)
-    int* listF;       // free rows snapshot for SAP
-    int* listFC;      // free columns during SAP
+    int* bidcol;      // row -> (tag << 24) | the object it bid for last
+    int* listA;       // row -> tree index during a multi-source phase
+    int* listF;       // free rows
+    int* listFC;      // free columns
     int* pred;
-    int* tcol;        // per tree: accepted free column of the phase (or -1)
+    int* tcol;        // per tree: accepted free column of the phase (or MS_NONE)
     int* grp_ticket;  // [n/64] arrival counters of a split relax round (one per column group)
-    int* out_perm;    // [n] result, exported to the caller's buffers once the solve is done
-    int* out_misc;    // [16]: certified, stats[8], pad, total_cost (double at [12])
     double* part_d;   // [MS_YMAX][n] partial minima of a split relax round
     int* part_i;      // [MS_YMAX][n] their rows
     int* part_r;      // [MS_YMAX][n] their trees
@@ -193,18 +222,18 @@ __device__ __forceinline__ SList slist(const AsgWs& w, int c) {
 // MS_SPLIT_MIN: ... when it has more than this many entries
 
 static inline size_t asg_ws_bytes(int n) {
-    size_t N = (size_t)n;
+    size_t N = ((size_t)n + 3) & ~(size_t)3;     // every array starts 16-byte aligned
     size_t lists = (n <= 4096) ? N * 64 * 8 + 8 * N : 0;
     return 512 + 8 * N * (4 + 4) + 4 * N * (10 + 6) + 64 + 16 + 16 * N * MS_YMAX + lists + 256;
 }
 
 static inline AsgWs asg_carve(void* ws, int n) {
-    AsgWs w; char* q = (char*)ws; size_t N = (size_t)n;
+    AsgWs w; char* q = (char*)ws; size_t N = ((size_t)n + 3) & ~(size_t)3;
     w.st = (AsgState*)q; q += 512;
     w.p = (double*)q; q += 8 * N;
     w.bidval = (double*)q; q += 8 * N;
     w.dist = (double*)q; q += 8 * N;
-    w.packed = (unsigned long long*)q; q += 8 * N;
+    w.key = (unsigned long long*)q; q += 8 * N;
     for (int c = 0; c < 2; ++c) { w.S[c].base = (double*)q; q += 8 * N; w.S[c].rj = (double*)q; q += 8 * N; }
     w.a = (int*)q; q += 4 * N;
     w.owner = (int*)q; q += 4 * N;
@@ -218,8 +247,7 @@ static inline AsgWs asg_carve(void* ws, int n) {
         w.S[c].col = (int*)q; q += 4 * N; w.S[c].row = (int*)q; q += 4 * N; w.S[c].root = (int*)q; q += 4 * N;
     }
     w.grp_ticket = (int*)q; q += 4 * N;
-    w.out_perm = (int*)q; q += 4 * N;
-    w.out_misc = (int*)q; q += 64;
+    q += 4 * N + 64;   // (formerly the staged result)
     q = (char*)(((uintptr_t)q + 15) & ~(uintptr_t)15);
     w.part_d = (double*)q; q += 8 * N * MS_YMAX;
     w.part_i = (int*)q; q += 4 * N * MS_YMAX;
@@ -231,6 +259,17 @@ static inline AsgWs asg_carve(void* ws, int n) {
 
 extern "C" size_t cfm_asg_ws_bytes_internal(int n) { return asg_ws_bytes(n); }
 
+// The cost matrix pointer comes out of the state block, so the compiler cannot prove it global and
+// would emit FLAT loads (which also count on the LDS counter and stall the LDS price reads of a bid):
+// the kernels cast it to the global address space once.
+typedef const __attribute__((address_space(1))) float* gfp;
+typedef float asg_v4f __attribute__((ext_vector_type(4)));
+#define ASG_GLOBAL(ptr) ((gfp)(ptr))
+__device__ __forceinline__ float4 asg_ld4(gfp p) {     // 16-byte global load
+    const asg_v4f v = *reinterpret_cast<const __attribute__((address_space(1))) asg_v4f*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // ordered bits for floats (total order)
 __device__ __forceinline__ unsigned f2ord(float x) {
     unsigned b = __float_as_uint(x);
@@ -241,38 +280,62 @@ __device__ __forceinline__ float ord2f(unsigned k) {
     return __uint_as_float(b);
 }
 
-// -------------------------------------------------------------- min / max ----
-__global__ __launch_bounds__(256) void asg_minmax(const float* __restrict__ M, size_t n2,
-                                                  AsgState* st) {
-    float lo = INFINITY, hi = -INFINITY;
-    const size_t n4 = n2 / 4;
-    const float4* M4 = reinterpret_cast<const float4*>(M);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const float4 v = M4[i];
-        lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
-        hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
-    }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
-        lo = fminf(lo, M[i]); hi = fmaxf(hi, M[i]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, o, 64));
-        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
-    }
-    __shared__ float slo[4], shi[4];
-    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+// ------------------------------------------------- device-scope words (line 1) -----
+#define ASG_AGENT __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ int asg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, ASG_AGENT); }
+__device__ __forceinline__ unsigned asg_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, ASG_AGENT); }
+__device__ __forceinline__ unsigned long long asg_ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, ASG_AGENT); }
+__device__ __forceinline__ void asg_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, ASG_AGENT); }
+__device__ __forceinline__ void asg_st(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, ASG_AGENT); }
+
+// Every workgroup of a launch calls this once, after its share of the step: returns true (in all
+// its threads) in the workgroup that arrives last.  Each wave first waits until its own stores and
+// atomics have been performed, so everything the others contributed through device-scope atomics
+// is complete when the last ticket is drawn.
+__device__ __forceinline__ bool asg_arrive_last(AsgState* st, int* sh_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
-        hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
-        atomicMin(&st->cmin_bits, f2ord(lo));
-        atomicMax(&st->cmax_bits, f2ord(hi));
+        const int t = __hip_atomic_fetch_add(&st->ticket, 1, __ATOMIC_RELAXED, ASG_AGENT);
+        const int last = (t == (int)gridDim.x - 1) ? 1 : 0;
+        if (last) asg_st(&st->ticket, 0);
+        *sh_flag = last;
     }
+    __syncthreads();
+    return *sh_flag != 0;
+}
+
+// thread 0 of the deciding workgroup: book the time since the previous control step on `mode`
+__device__ __forceinline__ void asg_book(AsgState* st, int mode) {
+    st->st_steps++;
+    const long long now = wall_clock64();
+    if (st->t_prev) st->t_acc[mode & 15] += now - st->t_prev;
+    st->t_prev = now;
+}
+
+__device__ __forceinline__ void asg_enter_cert(AsgState* st) {   // one thread
+    asg_st(&st->minslack_ord, ~0ull);
+    asg_st(reinterpret_cast<unsigned long long*>(&st->total_cost), 0ull);
+    asg_st(&st->cert_bad, 0);
+}
+
+// ------------------------------------------------------------------ keys -----
+// key = ((d2ord(price) & ~mask) - unit) | row: the largest grid value strictly below the price, so a
+// bid never exceeds what the bidder computed (its new object stays its strict minimum), and any
+// bid that registers (atomicMax) raises the price.  The price of an object IS ord2d(key).
+__device__ __forceinline__ unsigned long long asg_enc(double v, unsigned row, int rb) {
+    const unsigned long long mask = (1ull << rb) - 1ull;
+    return ((d2ord(v) & ~mask) - (1ull << rb)) | (unsigned long long)row;
+}
+// row bits of a decoded price
+__device__ __forceinline__ int asg_row_of(double p, int rb) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(p);
+    const unsigned long long lo = (b >> 63) ? ~b : b;
+    return (int)(lo & ((1ull << rb) - 1ull));
 }
 
 // --------------------------------------------------------- wide: auction -----
-#define WT 1024   // threads of the wide kernel (16 waves)
+#define WT 1024   // threads of the wide kernels (16 waves)
 #define WIDE_PLDS_MAX 8192   // prices are staged into LDS for the bid rounds up to this n
 // One wave per bidding row.  r_k = c_ik + p_k (fp64).  Top-2 over the row.
 struct Top2 { double b; double s; int j; };
@@ -317,13 +380,6 @@ __device__ __forceinline__ int asg_wave_min_i(int v) {
     v = min(v, asg_dpp_i<0x143, 0xc>(0x7fffffff, v));
     return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ Top2 top2_merge(const Top2& x, double b2, double s2, int j2) {
-    Top2 o;
-    const bool take2 = (b2 < x.b) || (b2 == x.b && j2 < x.j);
-    if (take2) { o.b = b2; o.j = j2; o.s = fmin(x.b, s2); }
-    else       { o.b = x.b; o.j = x.j; o.s = fmin(x.s, b2); }
-    return o;
-}
 
 // 64 columns of one row segment: top-2 of c + p with the prices in LDS
 __device__ __forceinline__ void bid_segment(Top2& best, const float4 (&c)[16], const double* ps, int jbase) {
@@ -340,85 +396,68 @@ __device__ __forceinline__ void bid_segment(Top2& best, const float4 (&c)[16], c
     }
 }
 
-// wave top-2 -> bid (lane 0)
+// price of object j: LDS copy of this round's keys, or the key itself (n > WIDE_PLDS_MAX)
+__device__ __forceinline__ double bid_price(const AsgWs& w, const double* p_lds, bool use_plds, int j) {
+    return use_plds ? p_lds[j] : ord2d(w.key[j]);
+}
+
+// A row is matched iff it bid in the current tag and the object it bid for still carries its id.
+__device__ __forceinline__ bool bid_matched(const AsgWs& w, const double* p_lds, bool use_plds, int bc, int tag,
+                                            int i, int rb) {
+    if (((unsigned)bc >> 24) != (unsigned)tag) return false;
+    return asg_row_of(bid_price(w, p_lds, use_plds, bc & 0xffffff), rb) == i;
+}
+
+// wave top-2 -> bid (lane 0): one atomicMax, no award step
 __device__ __forceinline__ void bid_commit(const AsgWs& w, Top2 best, int i, double eps, const double* p_lds,
-                                           bool use_plds) {
+                                           bool use_plds, int tag, int rb) {
     const double bmin = asg_wave_min_d(best.b);
     const int jwin = asg_wave_min_i(best.b == bmin ? best.j : 0x7fffffff);
     const double rest = (best.b == bmin && best.j == jwin) ? best.s : best.b;
     const double smin = asg_wave_min_d(rest);       // the best of everything but (bmin, jwin)
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && jwin != 0x7fffffff) {
         const double incr = (smin - bmin) + eps;          // >= eps >= 0
-        const double bv = (use_plds ? p_lds[jwin] : w.p[jwin]) + incr;
-        w.bidcol[i] = jwin;
-        w.bidval[i] = bv;
-        // prices may be negative (they start from the row + column reduction): ordered float bits
-        const unsigned long long key =
-            ((unsigned long long)f2ord((float)bv) << 32) | (unsigned)(i + 1);
-        atomicMax(&w.packed[jwin], key);
+        const double bv = bid_price(w, p_lds, use_plds, jwin) + incr;
+        if (bv < INFINITY && bv > -INFINITY) atomicMax(&w.key[jwin], asg_enc(bv, (unsigned)i, rb));
+        w.bidcol[i] = (tag << 24) | jwin;
     }
 }
 
-// One wave per bidding row.  `pre_a` is the (speculatively loaded) match of this wave's row,
-// pst* the thread's share of the prices on their way into LDS: the bidder's first row segment
-// is requested BEFORE the prices are written to LDS and the workgroup barrier, so the staging
-// hides behind the row's latency.
-__device__ __forceinline__ void wide_bid(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
-                         int wave_gid, int n_waves, int pre_a, bool stage_p, int n_host,
-                         double2 pst0, double2 pst1, double2 pst2, double2 pst3) {
-    extern __shared__ __attribute__((aligned(16))) char wide_lds_bid[];   // = the kernel's dynamic LDS
-    double* p_lds = reinterpret_cast<double*>(wide_lds_bid);
-    const int n = n_host;
-    const double eps = st->eps;        // same 128-byte line as st->mode: an L1 hit by now
+// One wave per row; a row bids iff it is unmatched.  pre_bc = bidcol of the wave's first row,
+// requested with the keys in the kernel prologue.  Returns the number of bids of this wave.
+__device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_lds,
+                                        int wave_gid, int n_waves, int pre_bc, bool stage_p, int n,
+                                        double eps, int tag, int rb) {
     const int lane = threadIdx.x & 63;
     const bool vec = ((n & 3) == 0);
     const bool fast = stage_p && (n & 4095) == 0;
-    // No bidder list: wave <-> row, a row bids iff it is unmatched (pre_a = a[wave_gid] came with
-    // the state block).  Rows beyond the first of a wave (n > number of waves) are checked as they come.
+    int nbids = 0;
     int i = wave_gid;
-    bool bids = (i < n) && (pre_a < 0);
-    float4 c[16];
-    if (fast && bids) {
-        const float* rs = M + (size_t)i * n + lane * 4;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) c[k] = *reinterpret_cast<const float4*>(rs + 256 * k);
-    }
-    if (stage_p) {
-        const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
-        if (j0 < n_host) *reinterpret_cast<double2*>(p_lds + j0) = pst0;
-        if (j1 < n_host) *reinterpret_cast<double2*>(p_lds + j1) = pst1;
-        if (j2 < n_host) *reinterpret_cast<double2*>(p_lds + j2) = pst2;
-        if (j3 < n_host) *reinterpret_cast<double2*>(p_lds + j3) = pst3;
-        __syncthreads();
-    }
     if (fast) {
-        while (i < n) {
-            if (bids) {
-                Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
-                bid_segment(best, c, p_lds + lane * 4, lane * 4);
-                for (int seg = 4096; seg < n; seg += 4096) {
-                    const float* rs = M + (size_t)i * n + seg + lane * 4;
+        for (; i < n; i += n_waves) {
+            const int bc = (i == wave_gid) ? pre_bc : w.bidcol[i];
+            if (bid_matched(w, p_lds, true, bc, tag, i, rb)) continue;
+            Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
+            for (int seg = 0; seg < n; seg += 4096) {
+                // the segment's 16 KB in flight at once: 16 float4 per lane
+                float4 c[16];
+                gfp rs = M + (size_t)i * n + seg + lane * 4;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) c[k] = *reinterpret_cast<const float4*>(rs + 256 * k);
-                    bid_segment(best, c, p_lds + seg + lane * 4, seg + lane * 4);
-                }
-                bid_commit(w, best, i, eps, p_lds, true);
+                for (int k = 0; k < 16; ++k) c[k] = asg_ld4(rs + 256 * k);
+                bid_segment(best, c, p_lds + seg + lane * 4, seg + lane * 4);
+                __builtin_amdgcn_sched_barrier(0);     // the next segment's loads stay behind this one's arithmetic
             }
-            i += n_waves;
-            bids = (i < n) && (w.a[i] < 0);
-            if (bids) {
-                const float* rs = M + (size_t)i * n + lane * 4;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) c[k] = *reinterpret_cast<const float4*>(rs + 256 * k);
-            }
+            bid_commit(w, best, i, eps, p_lds, true, tag, rb);
+            ++nbids;
         }
-        return;
+        return nbids;
     }
     for (; i < n; i += n_waves) {
-        if (!((i == wave_gid) ? (pre_a < 0) : (w.a[i] < 0))) continue;
-        const float* row = M + (size_t)i * n;
+        const int bc = (i == wave_gid) ? pre_bc : w.bidcol[i];
+        if (bid_matched(w, p_lds, stage_p, bc, tag, i, rb)) continue;
+        gfp row = M + (size_t)i * n;
         Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
-        if (vec) {
+        if (vec && stage_p) {
             for (int j0 = lane * 4; j0 < n; j0 += 1024) {
                 // 4 float4 in flight per lane per trip
                 float4 c4[4]; double2 pa[4], pb[4];
@@ -426,9 +465,9 @@ __device__ __forceinline__ void wide_bid(const float* __restrict__ M, const AsgW
                 for (int k = 0; k < 4; ++k) {
                     const int j = j0 + 256 * k;
                     if (j < n) {
-                        c4[k] = *reinterpret_cast<const float4*>(row + j);
-                        pa[k] = stage_p ? *reinterpret_cast<const double2*>(p_lds + j) : *reinterpret_cast<const double2*>(w.p + j);
-                        pb[k] = stage_p ? *reinterpret_cast<const double2*>(p_lds + j + 2) : *reinterpret_cast<const double2*>(w.p + j + 2);
+                        c4[k] = asg_ld4(row + j);
+                        pa[k] = *reinterpret_cast<const double2*>(p_lds + j);
+                        pb[k] = *reinterpret_cast<const double2*>(p_lds + j + 2);
                     }
                 }
 #pragma unroll
@@ -443,24 +482,116 @@ __device__ __forceinline__ void wide_bid(const float* __restrict__ M, const AsgW
                 }
             }
         } else {
-            for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + w.p[j], j);
+            for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + bid_price(w, p_lds, stage_p, j), j);
         }
-        bid_commit(w, best, i, eps, p_lds, stage_p);
+        bid_commit(w, best, i, eps, p_lds, stage_p, tag, rb);
+        ++nbids;
+    }
+    return nbids;
+}
+
+// MODE_UMIN0: row minima (bidval), the cost range (one pair of atomics per workgroup) and the reset
+// of the key / bid state.  sh: >= 64 floats of LDS.
+__device__ __forceinline__ void wide_umin0(gfp M, const AsgWs& w, AsgState* st,
+                                           int wave_gid, int n_waves, int n, float* sh) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = blockIdx.x * WT + threadIdx.x; j < n; j += gridDim.x * WT) { w.key[j] = 0ull; w.bidcol[j] = -1; }
+    float lo = INFINITY, hi = -INFINITY;
+    const bool vec = ((n & 3) == 0);
+    for (int i = wave_gid; i < n; i += n_waves) {
+        gfp row = M + (size_t)i * n;
+        float m = INFINITY;
+        if (vec) {
+            for (int j0 = lane * 4; j0 < n; j0 += 1024) {
+                float4 c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = j0 + 256 * k;
+                    c[k] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+                    if (j < n) c[k] = asg_ld4(row + j);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (j0 + 256 * k < n) {
+                        m = fminf(fminf(m, c[k].x), fminf(c[k].y, fminf(c[k].z, c[k].w)));
+                        hi = fmaxf(fmaxf(hi, c[k].x), fmaxf(c[k].y, fmaxf(c[k].z, c[k].w)));
+                    }
+                }
+            }
+        } else {
+            for (int j = lane; j < n; j += 64) { const float c = row[j]; m = fminf(m, c); hi = fmaxf(hi, c); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) w.bidval[i] = (double)m;
+        lo = fminf(lo, m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if (lane == 0) { sh[wv] = lo; sh[16 + wv] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < WT / 64; ++q) { lo = fminf(lo, sh[q]); hi = fmaxf(hi, sh[16 + q]); }
+        if (lo <= hi) { atomicMin(&st->cmin_bits, f2ord(lo)); atomicMax(&st->cmax_bits, f2ord(hi)); }
+    }
+}
+
+// MODE_INITRED: initial prices by row + column reduction (the classical Jonker-Volgenant start): with
+// u_i = min_j c_ij (bidval[], MODE_UMIN0) the price p_j = max_i (u_i - c_ij) <= 0 is the largest
+// one that keeps every row's minimum where it is, and it makes every column tight for some row.
+// The auction then starts two epsilon phases later (eps0 = 8e-3 instead of 0.2 of the cost range).
+// Lane <-> column, the grid splits the rows; the partial maxima go straight into the keys (the
+// encoding is monotone, so the max of the encoded values is the encoded max; row bits = none).
+__device__ __forceinline__ void wide_initred(gfp M, const AsgWs& w, double* sh_d, int n, int rb) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n_groups = (n + 63) / 64;
+    int Y = gridDim.x / n_groups; Y = Y < 1 ? 1 : Y;
+    constexpr int NW = WT / 64, Q = 8;
+    const unsigned none = (1u << rb) - 1u;
+    for (int unit = blockIdx.x; unit < n_groups * Y; unit += gridDim.x) {
+        const int g = unit % n_groups, y = unit / n_groups;
+        const int k = g * 64 + lane;
+        const bool ok = k < n;
+        const int r_beg = (int)((long long)n * y / Y), r_end = (int)((long long)n * (y + 1) / Y);
+        double m = -INFINITY;
+        for (int r0 = r_beg + wv * Q; r0 < r_end; r0 += NW * Q) {
+            float c[Q]; double u[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int r = r0 + q;
+                const bool v = ok && r < r_end;
+                c[q] = v ? M[(size_t)r * n + k] : 0.f;
+                u[q] = (r < r_end) ? w.bidval[r] : -INFINITY;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) m = fmax(m, u[q] - (double)c[q]);
+        }
+        sh_d[wv * 64 + lane] = m;
+        __syncthreads();
+        if (wv == 0 && ok) {
+#pragma unroll
+            for (int q = 1; q < NW; ++q) m = fmax(m, sh_d[q * 64 + lane]);
+            if (m > -INFINITY && m < INFINITY) atomicMax(&w.key[k], asg_enc(m, none, rb));
+        }
+        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------ wide: SAP ------
 // Row minima u_i = min_k (c_ik + p_k), one wave per row: for every row (before the column
-// reduction) or for the free rows of the next multi-source phase.  Result in bidval[row].
-__device__ __forceinline__ void wide_umin(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+// reduction) or for the free rows of the next multi-source phase.  Result in bidval[row]; for the
+// roots the wave also files the root's entry of the first scan list (the start of the phase).
+#define MS_NONE 0x7fffffff
+__device__ __forceinline__ void wide_umin(gfp M, const AsgWs& w, const AsgState* st,
                           int wave_gid, int n_waves, bool roots_only) {
     const int n = st->n;
     const int cnt = roots_only ? st->nF : n;
     const int lane = threadIdx.x & 63;
     const bool vec = ((n & 3) == 0);
+    const SList L = slist(w, roots_only ? st->cur : 0);
     for (int t = wave_gid; t < cnt; t += n_waves) {
         const int i = roots_only ? w.listF[t] : t;
-        const float* row = M + (size_t)i * n;
+        gfp row = M + (size_t)i * n;
         double m = INFINITY;
         if (vec) {
             for (int j0 = lane * 4; j0 < n; j0 += 1024) {
@@ -469,7 +600,7 @@ __device__ __forceinline__ void wide_umin(const float* __restrict__ M, const Asg
                 for (int k = 0; k < 4; ++k) {
                     const int j = j0 + 256 * k;
                     if (j < n) {
-                        c[k] = *reinterpret_cast<const float4*>(row + j);
+                        c[k] = asg_ld4(row + j);
                         pa[k] = *reinterpret_cast<const double2*>(w.p + j);
                         pb[k] = *reinterpret_cast<const double2*>(w.p + j + 2);
                     }
@@ -487,15 +618,28 @@ __device__ __forceinline__ void wide_umin(const float* __restrict__ M, const Asg
             for (int j = lane; j < n; j += 64) m = fmin(m, (double)row[j] + w.p[j]);
         }
         m = wave_min_d(m);
-        if (lane == 0) w.bidval[i] = m;
+        if (lane == 0) {
+            w.bidval[i] = m;
+            if (roots_only) {
+                L.col[t] = -1; L.row[t] = i; L.base[t] = 0.0; L.rj[t] = m; L.root[t] = t;
+                w.listA[i] = t;                 // row -> tree index
+                w.tcol[t] = MS_NONE; w.key[t] = ~0ull;
+            }
+        }
     }
+}
+
+// the rest of a multi-source phase start: labels unset (all threads of the grid)
+__device__ __forceinline__ void wide_ms_reset(const AsgWs& w, int n) {
+    for (int k = blockIdx.x * WT + threadIdx.x; k < n; k += gridDim.x * WT) { w.dist[k] = INFINITY; w.pred[k] = -1; }
+    for (int g = blockIdx.x * WT + threadIdx.x; g < (n + 63) / 64; g += gridDim.x * WT) w.grp_ticket[g] = 0;
 }
 
 // Column reduction of the free columns: p_k <- max_i (u_i - c_ik), the largest price at which
 // column k is still not cheaper than any row's current minimum.  No u_i changes, every matched
 // edge stays tight, the dual objective rises by the price drop.  One workgroup per column
 // (strided reads: 64 B sector per row, only nFC columns).
-__device__ __forceinline__ void wide_colred(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+__device__ __forceinline__ void wide_colred(gfp M, const AsgWs& w, const AsgState* st,
                             double* sh_d) {
     const int n = st->n, nFC = st->nFC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -525,52 +669,35 @@ __device__ __forceinline__ void wide_colred(const float* __restrict__ M, const A
     }
 }
 
-// Initial prices by row + column reduction (the classical Jonker-Volgenant start): with
-// u_i = min_j c_ij (bidval[], MODE_UMIN0) the price p_j = max_i (u_i - c_ij) <= 0 is the largest
-// one that keeps every row's minimum where it is, and it makes every column tight for some row.
-// The auction then starts two epsilon phases later (eps0 = 8e-3 instead of 0.2 of the cost range):
-// 78 rounds instead of 113 on the C3 data.  Lane <-> column, the grid splits the rows, partial
-// maxima through one ordered-double atomicMax per column and workgroup (packed[] is the scratch).
-__device__ __forceinline__ void wide_initred(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
-                                             double* sh_d, int n) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_groups = (n + 63) / 64;
-    int Y = gridDim.x / n_groups; Y = Y < 1 ? 1 : Y;
-    constexpr int NW = WT / 64, Q = 8;
-    for (int unit = blockIdx.x; unit < n_groups * Y; unit += gridDim.x) {
-        const int g = unit % n_groups, y = unit / n_groups;
-        const int k = g * 64 + lane;
-        const bool ok = k < n;
-        const int r_beg = (int)((long long)n * y / Y), r_end = (int)((long long)n * (y + 1) / Y);
-        double m = -INFINITY;
-        for (int r0 = r_beg + wv * Q; r0 < r_end; r0 += NW * Q) {
-            float c[Q]; double u[Q];
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int r = r0 + q;
-                const bool v = ok && r < r_end;
-                c[q] = v ? M[(size_t)r * n + k] : 0.f;
-                u[q] = (r < r_end) ? w.bidval[r] : -INFINITY;
-            }
-#pragma unroll
-            for (int q = 0; q < Q; ++q) m = fmax(m, u[q] - (double)c[q]);
-        }
-        sh_d[wv * 64 + lane] = m;
-        __syncthreads();
-        if (wv == 0 && ok) {
-#pragma unroll
-            for (int q = 1; q < NW; ++q) m = fmax(m, sh_d[q * 64 + lane]);
-            atomicMax(&w.packed[k], d2ord(m));
-        }
-        __syncthreads();
-    }
-}
-
 // How many workgroups share one column group in a relax round of nS entries.
 __device__ __forceinline__ int ms_split(int nS, int n_groups, int blocks) {
     if (nS <= MS_SPLIT_MIN) return 1;
     int y = blocks / n_groups;
     return y < 1 ? 1 : (y > MS_YMAX ? MS_YMAX : y);
+}
+
+// Close a column group's round (wave 0, lane <-> column k): take the merged minimum, append an
+// improved assigned column to the NEXT list, and contribute the labels of the group's free columns
+// to the round's radius words (ordered min / max, one pair of atomics per group).
+__device__ __forceinline__ void relax_close(gfp M, const AsgWs& w, AsgState* st,
+                                            const SList& Nx, int n, int k, bool ok, double pk, double dfree,
+                                            double best, int bi, int br) {
+    double dk = INFINITY; int ow = 0;
+    if (ok) { dk = w.dist[k]; ow = w.owner[k]; }
+    if (ok && best < dk) {
+        w.dist[k] = best; w.pred[k] = bi; dk = best;
+        if (ow >= 0 && best < dfree) {
+            const int idx = atomicAdd(&st->nN, 1);
+            Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = br;
+            Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
+        }
+    }
+    const bool fr = ok && ow < 0;
+    const double mx = wave_max_d(fr ? dk : -INFINITY), mn = wave_min_d(fr ? dk : INFINITY);
+    if ((threadIdx.x & 63) == 0 && mn < INFINITY) {       // mn < inf <=> the group has a free column with a finite label ...
+        atomicMin(&st->fr_min, d2ord(mn));
+    }
+    if ((threadIdx.x & 63) == 0 && mx > -INFINITY) atomicMax(&st->fr_max, d2ord(mx));   // ... inf labels count for the max
 }
 
 // Relax every listed row.  A workgroup owns columns [64g, 64g+64): lane <-> column
@@ -579,7 +706,7 @@ __device__ __forceinline__ int ms_split(int nS, int n_groups, int blocks) {
 // appends improved assigned columns to the NEXT list (one atomic per append).  A big round
 // is split over Y workgroups per column group (every Y-th slice of the list each); they write
 // per-column partial minima and the last of them to arrive merges them (see the end of the loop body).
-__device__ __forceinline__ void wide_relax(const float* __restrict__ M, const AsgWs& w, AsgState* st,
+__device__ __forceinline__ void wide_relax(gfp M, const AsgWs& w, AsgState* st,
                            double* sh_d, int* sh_i, int* sh_r) {
     const int n = st->n, nS = st->nS, cur = st->cur;
     const double dfree = st->dfree;
@@ -618,31 +745,24 @@ __device__ __forceinline__ void wide_relax(const float* __restrict__ M, const As
         }
         sh_d[wv * 64 + lane] = best; sh_i[wv * 64 + lane] = bi; sh_r[wv * 64 + lane] = br;
         __syncthreads();
-        if (wv == 0 && ok) {
+        if (wv == 0) {
+            if (ok) {
 #pragma unroll
-            for (int q = 1; q < NW; ++q) {
-                const double c2 = sh_d[q * 64 + lane]; const int i2 = sh_i[q * 64 + lane];
-                if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = sh_r[q * 64 + lane]; }
+                for (int q = 1; q < NW; ++q) {
+                    const double c2 = sh_d[q * 64 + lane]; const int i2 = sh_i[q * 64 + lane];
+                    if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = sh_r[q * 64 + lane]; }
+                }
             }
             if (Y > 1) {
-                w.part_d[(size_t)y * n + k] = best; w.part_i[(size_t)y * n + k] = bi; w.part_r[(size_t)y * n + k] = br;
-            } else if (best < w.dist[k]) {
-                // (requesting dist / owner / the owner's cost up front, next to the list entries,
-                //  instead of here was measured: no change — the hops are not what bounds a round)
-                w.dist[k] = best; w.pred[k] = bi;
-                const int ow = w.owner[k];
-                if (ow >= 0 && best < dfree) {
-                    const int idx = atomicAdd(&st->nN, 1);
-                    Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = br;
-                    Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
-                }
+                if (ok) { w.part_d[(size_t)y * n + k] = best; w.part_i[(size_t)y * n + k] = bi; w.part_r[(size_t)y * n + k] = br; }
+            } else {
+                relax_close(M, w, st, Nx, n, k, ok, pk, dfree, best, bi, br);
             }
         }
         __syncthreads();
         if (Y > 1) {
             // The Y workgroups of a column group hand their partial minima to the LAST one to arrive,
-            // which merges them and finalises the group's 64 columns exactly as an unsplit round does
-            // (one CU merging all 4096 columns in asg_ctrl was bound by that CU's bandwidth: ~20 us).
+            // which merges them and finalises the group's 64 columns exactly as an unsplit round does.
             // Hand-off: plain stores -> barrier -> lane 0: agent release, drained, device-scope ticket;
             // last arriver: agent acquire -> barrier -> plain loads.
             if (threadIdx.x == 0) {
@@ -658,21 +778,16 @@ __device__ __forceinline__ void wide_relax(const float* __restrict__ M, const As
             }
             __syncthreads();
             const int last = sh_i[0];
-            if (last && wv == 0 && ok) {
-                double mb = w.part_d[k]; int mi = w.part_i[k], mr = w.part_r[k];
-                for (int yy = 1; yy < Y; ++yy) {
-                    const double c2 = w.part_d[(size_t)yy * n + k]; const int i2 = w.part_i[(size_t)yy * n + k];
-                    if (c2 < mb || (c2 == mb && i2 < mi)) { mb = c2; mi = i2; mr = w.part_r[(size_t)yy * n + k]; }
-                }
-                if (mb < w.dist[k]) {
-                    w.dist[k] = mb; w.pred[k] = mi;
-                    const int ow = w.owner[k];
-                    if (ow >= 0 && mb < dfree) {
-                        const int idx = atomicAdd(&st->nN, 1);
-                        Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = mb; Nx.root[idx] = mr;
-                        Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
+            if (last && wv == 0) {
+                double mb = INFINITY; int mi = 0x7fffffff, mr = -1;
+                if (ok) {
+                    mb = w.part_d[k]; mi = w.part_i[k]; mr = w.part_r[k];
+                    for (int yy = 1; yy < Y; ++yy) {
+                        const double c2 = w.part_d[(size_t)yy * n + k]; const int i2 = w.part_i[(size_t)yy * n + k];
+                        if (c2 < mb || (c2 == mb && i2 < mi)) { mb = c2; mi = i2; mr = w.part_r[(size_t)yy * n + k]; }
                     }
                 }
+                relax_close(M, w, st, Nx, n, k, ok, pk, dfree, mb, mi, mr);
             }
             __syncthreads();
         }
@@ -681,7 +796,7 @@ __device__ __forceinline__ void wide_relax(const float* __restrict__ M, const As
 
 // ------------------------------------------------------------ wide: cert -----
 // pre_a: the match of row wave_gid, loaded with the state block in the kernel prologue.
-__device__ __forceinline__ void wide_cert(const float* __restrict__ M, const AsgWs& w, AsgState* st, int wave_gid,
+__device__ __forceinline__ void wide_cert(gfp M, const AsgWs& w, AsgState* st, int wave_gid,
                           int n_waves, int pre_a, double* sh_d) {
     const int n = st->n;
     const int lane = threadIdx.x & 63;
@@ -689,19 +804,18 @@ __device__ __forceinline__ void wide_cert(const float* __restrict__ M, const Asg
     for (int i = wave_gid; i < n; i += n_waves) {
         const int ai = (i == wave_gid) ? pre_a : w.a[i];
         if (ai < 0 || ai >= n || w.owner[ai] != i) { bad = 1; continue; }
-        const float* row = M + (size_t)i * n;
+        gfp row = M + (size_t)i * n;
         const double ui = (double)row[ai] + w.p[ai];
         double m = INFINITY;
         if ((n & 3) == 0) {
-            // 4 float4 of the row and their prices in flight per lane and trip (the scalar loop ran
-            // its 64 dependent trips at one L2 latency each: 114 us for the pass at n = 4096)
+            // 4 float4 of the row and their prices in flight per lane and trip
             for (int j0 = lane * 4; j0 < n; j0 += 1024) {
                 float4 c4[4]; double2 pa[4], pb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int j = j0 + 256 * k;
                     if (j < n) {
-                        c4[k] = *reinterpret_cast<const float4*>(row + j);
+                        c4[k] = asg_ld4(row + j);
                         pa[k] = *reinterpret_cast<const double2*>(w.p + j);
                         pb[k] = *reinterpret_cast<const double2*>(w.p + j + 2);
                     }
@@ -721,8 +835,7 @@ __device__ __forceinline__ void wide_cert(const float* __restrict__ M, const Asg
         if (lane == 0) csum += (double)row[ai];
     }
     wmin = wave_min_d(wmin);
-    // one set of atomics per workgroup: 4096 waves adding into the same fp64 word serialise at the
-    // L2 (the pass took 107 us at n = 4096 with the row loop already vectorised)
+    // one set of atomics per workgroup: 4096 waves adding into the same fp64 word serialise at the L2
     const int wv = threadIdx.x >> 6;
     if (lane == 0) { sh_d[wv] = wmin; sh_d[16 + wv] = csum; sh_d[32 + wv] = bad ? 1.0 : 0.0; }
     __syncthreads();
@@ -733,54 +846,13 @@ __device__ __forceinline__ void wide_cert(const float* __restrict__ M, const Asg
         if (c != 0.0) atomicAdd(&st->total_cost, c);
         if (b != 0.0) atomicOr(&st->cert_bad, 1);
     }
+    __syncthreads();
 }
 
 #include "assign_sparse.h"
 
-__global__ __launch_bounds__(WT) void asg_wide(AsgWs w, int n_host) {
-    extern __shared__ __attribute__((aligned(16))) char wide_lds[];   // modes are exclusive
-    double* sh_d = reinterpret_cast<double*>(wide_lds);
-    int* sh_i = reinterpret_cast<int*>(wide_lds + sizeof(double) * WT);
-    int* sh_r = sh_i + WT;
-    AsgState* st = w.st;
-    // consecutive work items go to different workgroups (different CUs)
-    const int wave_gid = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
-    const int n_waves = gridDim.x * (WT / 64);
-    // Every kernel of the state machine starts cold (the previous one ran elsewhere): each
-    // dependent global access is a hop of its own.  Whether this wave's row is unmatched (= bids)
-    // is loaded speculatively TOGETHER with the state block (n comes from the host), so a bid
-    // round is {state, match, prices} -> row instead of state -> list -> {row, prices}.
-    // The prices (all of them are needed by every bidder) are staged into LDS the same way, so
-    // a bidder's row can be requested in one go.
-    const bool stage_p = (n_host <= WIDE_PLDS_MAX) && ((n_host & 3) == 0);
-    double2 pst0, pst1, pst2, pst3;     // WIDE_PLDS_MAX / (2 * WT) = 4 double2 per thread
-    {
-        const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
-        const int nn = stage_p ? n_host : 0;
-        pst0 = *reinterpret_cast<const double2*>(w.p + (j0 < nn ? j0 : 0));
-        pst1 = *reinterpret_cast<const double2*>(w.p + (j1 < nn ? j1 : 0));
-        pst2 = *reinterpret_cast<const double2*>(w.p + (j2 < nn ? j2 : 0));
-        pst3 = *reinterpret_cast<const double2*>(w.p + (j3 < nn ? j3 : 0));
-    }
-    int pre_i = (wave_gid < n_host) ? w.a[wave_gid] : 0;
-    int mode = st->mode;
-    const float* __restrict__ M = st->Mptr;
-    asm volatile("" : "+v"(pre_i), "+v"(pst0.x), "+v"(pst1.x), "+v"(pst2.x), "+v"(pst3.x) : "s"(mode) : "memory");   // all of it in flight
-    if (mode == MODE_DONE || st->error) return;
-    if (mode == MODE_AUCTION || mode == MODE_ARR) {
-        wide_bid(M, w, st, wave_gid, n_waves, pre_i, stage_p, n_host, pst0, pst1, pst2, pst3);
-    } else if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i, sh_r);
-    else if (mode == MODE_UMIN || mode == MODE_UMIN0) wide_umin(M, w, st, wave_gid, n_waves, false);
-    else if (mode == MODE_INITRED) wide_initred(M, w, st, sh_d, n_host);
-    else if (mode == MODE_ROOTMIN) wide_umin(M, w, st, wave_gid, n_waves, true);
-    else if (mode == MODE_COLRED) wide_colred(M, w, st, sh_d);
-    else if (mode == MODE_CERT) wide_cert(M, w, st, wave_gid, n_waves, pre_i, sh_d);
-    else if (mode == MODE_BUILD) wide_build(M, w, st, wide_lds);
-    else if (mode == MODE_SAP1) { if (blockIdx.x == 0) sp_solver(M, w, st, wide_lds); }
-}
-
-// ------------------------------------------------------------------ ctrl -----
-#define CT 1024
+// ------------------------------------------------- one-workgroup helpers -----
+#define CT WT
 // exclusive scan of one int per thread over a 1024-thread workgroup
 __device__ int block_scan_excl(int v, int* total, int* sh /*>=17*/) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -825,137 +897,55 @@ __device__ void block_argmin(double v, int idx, double* out_v, int* out_i, doubl
     __syncthreads();
 }
 
-__device__ void ctrl_reset_assignment(const AsgWs& w, AsgState* st) {
-    const int n = st->n;
+// MODE_CONVERT (workgroup 0): the auction state (keys, last bids) becomes prices, matches and the
+// ordered lists of free rows / free columns.  Returns the number of free rows (all threads).
+__device__ int ctrl_convert(const AsgWs& w, AsgState* st, int* sh) {
+    const int n = st->n, tag = st->tag, rb = st->rb;
+    for (int k = threadIdx.x; k < n; k += CT) { w.owner[k] = -1; w.p[k] = ord2d(w.key[k]); }
+    __syncthreads();
     for (int i = threadIdx.x; i < n; i += CT) {
-        w.a[i] = -1; w.owner[i] = -1; w.packed[i] = 0ull;
-    }
-    if (threadIdx.x == 0) { st->nU = n; st->round = 0; }
-    __syncthreads();
-}
-
-// Block sum of one int per thread.
-__device__ int block_sum_i(int v, int* sh /*>=17*/) {
-    v = wave_sum_i(v);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    int tot = 0;
-#pragma unroll
-    for (int q = 0; q < CT / 64; ++q) tot += sh[q];
-    __syncthreads();
-    return tot;
-}
-
-// Apply the winning bids.  There is no bidder list (a row bids iff it is unmatched), so all that
-// is left to maintain is the number of unmatched rows: it drops by one for every object that was
-// free before.  Two global hops: {bids, owners} of the thread's objects, then the winners' exact bids.
-__device__ void ctrl_award(const AsgWs& w, AsgState* st, int* sh, int n, int nU_old) {
-    int newly = 0;
-    for (int j0 = threadIdx.x; j0 < n; j0 += 4 * CT) {
-        unsigned long long key[4]; int ow[4]; double bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = j0 + q * CT;
-            const bool ok = j < n;
-            key[q] = ok ? w.packed[j] : 0ull; ow[q] = ok ? w.owner[j] : -1;
+        const int bc = w.bidcol[i];
+        int ai = -1;
+        if (((unsigned)bc >> 24) == (unsigned)tag) {
+            const int j = bc & 0xffffff;
+            if (j < n && asg_row_of(ord2d(w.key[j]), rb) == i) ai = j;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = (key[q] != 0ull) ? w.bidval[(int)(key[q] & 0xffffffffull) - 1] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (key[q] != 0ull) {
-                const int j = j0 + q * CT;
-                const int i = (int)(key[q] & 0xffffffffull) - 1;
-                w.p[j] = bv[q]; w.owner[j] = i; w.a[i] = j; w.packed[j] = 0ull;
-                if (ow[q] >= 0) w.a[ow[q]] = -1; else ++newly;
-            }
-        }
+        w.a[i] = ai;
+        if (ai >= 0) w.owner[ai] = i;
     }
-    const int tot = block_sum_i(newly, sh);
-    if (threadIdx.x == 0) st->nU = nU_old - tot;
     __syncthreads();
-}
-
-// Pruning radius of a multi-source phase.  One tree: the best free-column label (no label
-// at or above it can matter).  Several trees: the q-quantile of the free-column labels (q = 1:
-// the largest).  Any radius is valid — labels at or below it are final once no listed entry is
-// below it, and only free columns at or below it are accepted — a smaller one trades fewer
-// augmentations per phase for far fewer relaxations of rows whose labels are still poor.  It
-// only ever decreases within a phase, so an entry skipped once is never needed later.
-__device__ void ctrl_radius(const AsgWs& w, AsgState* st, double* shd, int* shi, double* scratch) {
-    const int nFC = st->nFC;
-    const bool single = (st->nF == 1);
-    const double q = st->ms_q;
-    if (!single && nFC <= CT && q < 1.0) {
-        const int t = threadIdx.x;
-        const double v = (t < nFC) ? w.dist[w.listFC[t]] : INFINITY;
-        __syncthreads();
-        if (t < nFC) scratch[t] = v;
-        __syncthreads();
-        int kq = (int)ceil(q * nFC) - 1;
-        kq = kq < 0 ? 0 : (kq > nFC - 1 ? nFC - 1 : kq);
-        if (t < nFC) {
-            int rank = 0;
-            for (int s2 = 0; s2 < nFC; ++s2) {
-                const double vs = scratch[s2];
-                rank += (vs < v || (vs == v && s2 < t)) ? 1 : 0;
-            }
-            if (rank == kq) { st->dfree = v; st->jfree = -1; }
-        }
-        __syncthreads();
-        return;
+    int baseR = 0;
+    for (int i0 = 0; i0 < n; i0 += CT) {
+        const int i = i0 + threadIdx.x;
+        const int f = (i < n && w.a[i] < 0) ? 1 : 0;
+        int tot;
+        const int off = block_scan_excl(f, &tot, sh);
+        if (f) w.listF[baseR + off] = i;
+        baseR += tot;
     }
-    double lm = INFINITY; int li = 0x7fffffff;
-    for (int t = threadIdx.x; t < nFC; t += CT) {
-        const int k = w.listFC[t];
-        const double dk = single ? w.dist[k] : -w.dist[k];
-        if (dk < lm || (dk == lm && k < li)) { lm = dk; li = k; }
+    int base = 0;
+    for (int k0 = 0; k0 < n; k0 += CT) {
+        const int k = k0 + threadIdx.x;
+        const int f = (k < n && w.owner[k] < 0) ? 1 : 0;
+        int tot;
+        const int off = block_scan_excl(f, &tot, sh);
+        if (f) w.listFC[base + off] = k;
+        base += tot;
     }
-    double r; int jr;
-    block_argmin(lm, li, &r, &jr, shd, shi);
-    if (threadIdx.x == 0) { st->dfree = single ? r : -r; st->jfree = jr; }
     __syncthreads();
-}
-
-#define MS_NONE 0x7fffffff
-
-// Start a multi-source phase: labels unset, one root entry per free row (u_r in bidval[]).
-__device__ void ctrl_ms_begin(const AsgWs& w, AsgState* st) {
-    const int n = st->n, nF = st->nF, cur = st->cur;
-    const SList L = slist(w, cur);
-    __syncthreads();
-    for (int k = threadIdx.x; k < n; k += CT) { w.dist[k] = INFINITY; w.pred[k] = -1; }
-    for (int g = threadIdx.x; g < (n + 63) / 64; g += CT) w.grp_ticket[g] = 0;
-    for (int t = threadIdx.x; t < nF; t += CT) {
-        const int r = w.listF[t];
-        L.col[t] = -1; L.row[t] = r; L.base[t] = 0.0; L.rj[t] = w.bidval[r]; L.root[t] = t;
-        w.listA[r] = t;                 // row -> tree index (listA is free after the auction)
-        w.tcol[t] = MS_NONE; w.packed[t] = ~0ull;
-    }
     if (threadIdx.x == 0) {
-        st->nS = nF; st->nN = 0; st->dfree = INFINITY; st->jfree = -1; st->mode = MODE_SAP;
-        st->st_ms_phases++;
+        st->nFC = base; st->nF = baseR; st->st_free_after_arr = baseR;
+        st->cur = 0; asg_st(&st->nN, 0);
+        if (base != baseR) st->error = 4;
     }
     __syncthreads();
+    return baseR;
 }
 
-// After a relax round: new radius, swap lists; returns true if another round is needed.
-__device__ bool ctrl_sap_step(const AsgWs& w, AsgState* st, double* shd, int* shi, double* scratch) {
-    ctrl_radius(w, st, shd, shi, scratch);
-    const double dfree = st->dfree;
-    const int nN = st->nN, cur = st->cur;
-    const SList Nx = slist(w, cur ^ 1);
-    int any = 0;
-    for (int t = threadIdx.x; t < nN; t += CT) any |= (Nx.base[t] < dfree) ? 1 : 0;
-    any = __syncthreads_or(any);
-    if (threadIdx.x == 0) { st->cur = cur ^ 1; st->nS = any ? nN : 0; st->nN = 0; }
-    __syncthreads();
-    return any != 0;
-}
-
-// The forest has converged below the radius.  Every free column with a finite label belongs to
-// exactly one tree (walk the predecessors to its free row); each tree accepts its nearest free
-// column (ties: lowest column).  With D = the largest accepted label, the dual update
+// MODE_MS_FINISH (workgroup 0).  The forest has converged below the radius.  Every free column with a
+// finite label belongs to exactly one tree (walk the predecessors to its free row); each tree
+// accepts its nearest free column (ties: lowest column).  With D = the largest accepted label, the
+// dual update
 //     p_k += D - d_k  for every column with d_k < D   (u follows through the tight matched edges)
 // keeps the duals feasible and makes every accepted path tight; the paths are vertex disjoint
 // (different trees), so all of them are augmented.  Returns the number of augmented paths.
@@ -985,7 +975,7 @@ __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds
                 if (aj < 0) { ti = w.listA[i]; break; }
                 j = aj;
             }
-            if (ti >= 0) atomicMin(&w.packed[ti], d2ord(d));
+            if (ti >= 0) atomicMin(&w.key[ti], d2ord(d));
         }
         w.bidcol[t] = ti;
     }
@@ -996,14 +986,14 @@ __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds
         const int ti = w.bidcol[t];
         if (ti >= 0) {
             const int k = w.listFC[t];
-            if (d2ord(w.dist[k]) == w.packed[ti]) atomicMin(&w.tcol[ti], k);
+            if (d2ord(w.dist[k]) == w.key[ti]) atomicMin(&w.tcol[ti], k);
         }
     }
     __syncthreads();
     // radius D = largest accepted label
     double lm = INFINITY; int cnt = 0;
     for (int t = threadIdx.x; t < nF; t += CT) {
-        if (w.tcol[t] != MS_NONE) { lm = fmin(lm, -ord2d(w.packed[t])); ++cnt; }
+        if (w.tcol[t] != MS_NONE) { lm = fmin(lm, -ord2d(w.key[t])); ++cnt; }
     }
     double negD; int dummy;
     block_argmin(lm, threadIdx.x, &negD, &dummy, shd, shi);
@@ -1054,7 +1044,7 @@ __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds
         baseC += tot;
     }
     if (threadIdx.x == 0) {
-        st->nF = baseF; st->nFC = baseC; st->fidx = 0;
+        st->nF = baseF; st->nFC = baseC;
         st->st_ms_augmented += total;
         st->st_total_row_scans += total;
         if (baseF != baseC || baseF != nF - total) st->error = 4;
@@ -1063,184 +1053,166 @@ __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds
     return total;
 }
 
-__device__ void ctrl_enter_cert(AsgState* st) {
-    if (threadIdx.x == 0) {
-        st->mode = MODE_CERT; st->minslack_ord = ~0ull; st->total_cost = 0.0; st->cert_bad = 0;
+// ------------------------------------------------------------------- f1 ------
+// control step of an f1 launch: thread 0 of the last-arriving workgroup
+__device__ __forceinline__ void f1_ctrl(AsgState* st, int mode, int n) {
+    asg_book(st, mode);
+    if (mode == MODE_UMIN0) {
+        st->cmin = (double)ord2f(asg_ld(&st->cmin_bits));
+        st->cmax = (double)ord2f(asg_ld(&st->cmax_bits));
+        double cr = st->cmax - st->cmin;
+        if (!(cr > 0.0) || !(cr < INFINITY)) cr = 1.0;
+        st->eps = cr * st->eps;          // eps / eps_last hold the fractions on entry
+        st->eps_last = cr * st->eps_last;
+        // every phase but the last is cut earlier: it only has to shape the prices
+        const bool first_is_last = (st->eps / st->theta) < st->eps_last;
+        st->stop = (int)((first_is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
+        st->st_total_row_scans += n;
+        st->mode = MODE_INITRED;
+    } else if (mode == MODE_INITRED) {
+        st->st_total_row_scans += n;
+        st->round = 0; st->phase = 0; st->tag = 1;
+        st->mode = MODE_AUCTION;
+    } else if (mode == MODE_AUCTION || mode == MODE_ARR) {
+        // cnt = rows that were unmatched at the START of this round (they all bid in it)
+        const int cnt = asg_ld(&st->cnt);
+        asg_st(&st->cnt, 0);
+        st->st_total_row_scans += cnt;
+        const int tag_next = (st->tag % 254) + 1;
+        if (mode == MODE_AUCTION) {
+            st->st_auction_rounds++;
+            const int round = st->round + 1;
+            if (cnt <= st->stop || round >= st->round_cap) {
+                const double e2 = st->eps / st->theta;
+                if (e2 < st->eps_last) { st->mode = MODE_ARR; st->eps = 0.0; st->arr_round = 0; }
+                else {
+                    st->eps = e2; st->phase++;
+                    const bool is_last = (e2 / st->theta) < st->eps_last;
+                    st->stop = (int)((is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
+                }
+                st->tag = tag_next; st->round = 0;    // every row is unassigned again, the prices stay
+            } else st->round = round;
+        } else {
+            st->st_arr_rounds++;
+            const int ar = st->arr_round + 1;
+            st->arr_round = ar;
+            if (cnt == 0 || ar >= st->arr_cap) st->mode = MODE_CONVERT;
+        }
+    } else if (mode == MODE_CONVERT) {
+        st->mode = asg_ld(&st->next_mode);
     }
 }
 
-__device__ __forceinline__ void asg_ctrl_body(const AsgWs& w, int* dyn) {
+__global__ __launch_bounds__(WT) void asg_f1(AsgWs w, int n_host) {
+    extern __shared__ __attribute__((aligned(16))) char f1_lds[];   // prices | scratch of the other modes
+    double* p_lds = reinterpret_cast<double*>(f1_lds);
+    AsgState* st = w.st;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // consecutive work items go to different workgroups (different CUs)
+    const int wave_gid = wv * gridDim.x + blockIdx.x;
+    const int n_waves = gridDim.x * (WT / 64);
+    // Every launch starts cold: what a bid round needs first — the state block, all keys (they go to
+    // LDS as prices) and the last bid of the wave's row — is requested together.
+    const bool stage_p = (n_host <= WIDE_PLDS_MAX) && ((n_host & 3) == 0);
+    ulonglong2 kst0, kst1, kst2, kst3;     // WIDE_PLDS_MAX / (2 * WT) = 4 key pairs per thread
+    {
+        const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
+        const int nn = stage_p ? n_host : 0;
+        kst0 = *reinterpret_cast<const ulonglong2*>(w.key + (j0 < nn ? j0 : 0));
+        kst1 = *reinterpret_cast<const ulonglong2*>(w.key + (j1 < nn ? j1 : 0));
+        kst2 = *reinterpret_cast<const ulonglong2*>(w.key + (j2 < nn ? j2 : 0));
+        kst3 = *reinterpret_cast<const ulonglong2*>(w.key + (j3 < nn ? j3 : 0));
+    }
+    int pre_bc = (wave_gid < n_host) ? w.bidcol[wave_gid] : -1;
+    const int mode = st->mode;
+    gfp M = ASG_GLOBAL(st->Mptr);
+    asm volatile("" : "+v"(pre_bc), "+v"(kst0.x), "+v"(kst1.x), "+v"(kst2.x), "+v"(kst3.x) : "s"(mode) : "memory");   // all of it in flight
+    if (mode > MODE_CONVERT || st->error) return;
+    const int n = n_host;
+    // flags live behind the largest user of the dynamic region
+    int* sh_flag = reinterpret_cast<int*>(f1_lds + (stage_p ? (size_t)n * sizeof(double) : 0) + 8 * WT);
+    if (mode == MODE_AUCTION || mode == MODE_ARR) {
+        const double eps = st->eps; const int tag = st->tag, rb = st->rb;
+        if (threadIdx.x == 0) sh_flag[1] = 0;
+        if (stage_p) {
+            const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
+            if (j0 < n) *reinterpret_cast<double2*>(p_lds + j0) = make_double2(ord2d(kst0.x), ord2d(kst0.y));
+            if (j1 < n) *reinterpret_cast<double2*>(p_lds + j1) = make_double2(ord2d(kst1.x), ord2d(kst1.y));
+            if (j2 < n) *reinterpret_cast<double2*>(p_lds + j2) = make_double2(ord2d(kst2.x), ord2d(kst2.y));
+            if (j3 < n) *reinterpret_cast<double2*>(p_lds + j3) = make_double2(ord2d(kst3.x), ord2d(kst3.y));
+        }
+        __syncthreads();
+        const int nb = wide_bid(M, w, p_lds, wave_gid, n_waves, pre_bc, stage_p, n, eps, tag, rb);
+        if (lane == 0 && nb) atomicAdd(&sh_flag[1], nb);
+        __syncthreads();
+        if (threadIdx.x == 0 && sh_flag[1]) atomicAdd(&st->cnt, sh_flag[1]);
+    } else if (mode == MODE_UMIN0) {
+        wide_umin0(M, w, st, wave_gid, n_waves, n, reinterpret_cast<float*>(f1_lds));
+    } else if (mode == MODE_INITRED) {
+        wide_initred(M, w, reinterpret_cast<double*>(f1_lds), n, st->rb);
+    } else if (blockIdx.x == 0) {        // MODE_CONVERT
+        const int nF = ctrl_convert(w, st, reinterpret_cast<int*>(f1_lds));
+        if (threadIdx.x == 0) {
+            if (nF == 0) asg_enter_cert(st);
+            asg_st(&st->next_mode, nF == 0 ? MODE_CERT : MODE_UMIN);
+        }
+    }
+    if (asg_arrive_last(st, sh_flag) && threadIdx.x == 0) f1_ctrl(st, mode, n);
+}
+
+// ------------------------------------------------------------------- f2 ------
+__global__ __launch_bounds__(WT) void asg_f2(AsgWs w, int n_host) {
+    extern __shared__ __attribute__((aligned(16))) char f2_lds[];   // modes are exclusive
+    double* sh_d = reinterpret_cast<double*>(f2_lds);
+    int* sh_i = reinterpret_cast<int*>(f2_lds + sizeof(double) * WT);
+    int* sh_r = sh_i + WT;
     __shared__ int sh[32];
     __shared__ double shd[32];
     __shared__ int shi[32];
     AsgState* st = w.st;
-    const int n = st->n;
-    int mode = st->mode;
-    const float* __restrict__ M = st->Mptr;
-    int* perm = w.out_perm;
-    int* certified = w.out_misc;
-    int* stats = w.out_misc + 1;
-    double* total_cost = reinterpret_cast<double*>(w.out_misc + 12);
-    const bool use_lds = (n <= 6144);
-    if (mode == MODE_DONE || st->error) return;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        st->st_steps++;
-        const long long now = wall_clock64();
-        if (st->t_prev) st->t_acc[mode & 15] += now - st->t_prev;
-        st->t_prev = now;
-    }
-    __syncthreads();
-
-    if (mode == MODE_INIT) {
+    const int wave_gid = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    const int n_waves = gridDim.x * (WT / 64);
+    int pre_a = (wave_gid < n_host) ? w.a[wave_gid] : 0;
+    const int mode = st->mode;
+    gfp M = ASG_GLOBAL(st->Mptr);
+    asm volatile("" : "+v"(pre_a) : "s"(mode) : "memory");
+    if (mode < MODE_UMIN || mode > MODE_CERT || st->error) return;
+    const int n = n_host;
+    if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i, sh_r);
+    else if (mode == MODE_UMIN) wide_umin(M, w, st, wave_gid, n_waves, false);
+    else if (mode == MODE_COLRED) wide_colred(M, w, st, sh_d);
+    else if (mode == MODE_ROOTMIN) { wide_umin(M, w, st, wave_gid, n_waves, true); wide_ms_reset(w, n); }
+    else if (mode == MODE_CERT) wide_cert(M, w, st, wave_gid, n_waves, pre_a, sh_d);
+    else if (blockIdx.x == 0) {          // MODE_MS_FINISH
+        const bool use_lds = (n <= 6144);
+        ctrl_ms_finish(w, st, reinterpret_cast<int*>(f2_lds), reinterpret_cast<int*>(f2_lds) + n, use_lds, shd, shi, sh);
         if (threadIdx.x == 0) {
-            st->cmin = (double)ord2f(st->cmin_bits);
-            st->cmax = (double)ord2f(st->cmax_bits);
-            double cr = st->cmax - st->cmin;
-            if (!(cr > 0.0)) cr = 1.0;
-            st->eps = cr * st->eps;          // eps/eps_last hold the fractions on entry
-            st->eps_last = cr * st->eps_last;
-            // every phase but the last is cut earlier: it only has to shape the prices
-            const bool first_is_last = (st->eps / st->theta) < st->eps_last;
-            st->stop = (int)((first_is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
-            st->mode = MODE_UMIN0; st->phase = 0;
+            const int nF = st->nF;
+            int nm = MODE_ROOTMIN;
+            if (st->error) nm = MODE_DONE;
+            else if (nF == 0) { asg_enter_cert(st); nm = MODE_CERT; }
+            else if (st->sparse && nF <= st->handoff) nm = MODE_BUILD;
+            asg_st(&st->next_mode, nm);
         }
-        for (int k = threadIdx.x; k < n; k += CT) { w.p[k] = 0.0; w.packed[k] = 0ull; }
-        return;
     }
-    if (mode == MODE_UMIN0) {          // bidval[i] = min_j c_ij
-        if (threadIdx.x == 0) { st->mode = MODE_INITRED; st->st_total_row_scans += n; }
-        return;
-    }
-    if (mode == MODE_INITRED) {        // packed[k] = ordered max_i (u_i - c_ik)
-        for (int k = threadIdx.x; k < n; k += CT) w.p[k] = ord2d(w.packed[k]);
-        __syncthreads();
-        if (threadIdx.x == 0) { st->mode = MODE_AUCTION; st->st_total_row_scans += n; }
-        ctrl_reset_assignment(w, st);
-        return;
-    }
-
-    if (mode == MODE_AUCTION || mode == MODE_ARR) {
-        // snapshot everything the decision needs BEFORE thread 0 mutates the state
-        const int bidders = st->nU, round = st->round, round_cap = st->round_cap, stop = st->stop;
-        const int arr_round = st->arr_round, arr_cap = st->arr_cap;
-        const double eps_cur = st->eps, eps_last = st->eps_last, theta = st->theta;
-        __syncthreads();
-        ctrl_award(w, st, sh, n, bidders);
-        const int nU = st->nU;
-        __syncthreads();
-        if (threadIdx.x == 0) st->st_total_row_scans += bidders;
-        if (mode == MODE_AUCTION) {
-            const bool next_phase = (nU <= stop) || (round + 1 >= round_cap);
-            if (threadIdx.x == 0) { st->round = round + 1; st->st_auction_rounds++; }
-            __syncthreads();
-            if (next_phase) {
-                const double e2 = eps_cur / theta;
-                if (e2 < eps_last) {
-                    if (threadIdx.x == 0) { st->mode = MODE_ARR; st->eps = 0.0; st->arr_round = 0; }
-                } else {
-                    if (threadIdx.x == 0) {
-                        st->eps = e2; st->phase++;
-                        const bool is_last = (e2 / theta) < eps_last;
-                        st->stop = (int)((is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
-                    }
-                }
-                __syncthreads();
-                ctrl_reset_assignment(w, st);
-            }
-            return;
-        }
-        // MODE_ARR
-        if (threadIdx.x == 0) { st->arr_round = arr_round + 1; st->st_arr_rounds++; }
-        __syncthreads();
-        if (nU == 0) {
-            if (threadIdx.x == 0) st->st_free_after_arr = 0;
-            ctrl_enter_cert(st);
-            return;
-        }
-        if (arr_round + 1 < arr_cap) return;
-        // -> phase C: snapshot the free rows and the free columns, then column reduction
-        {
-            int baseR = 0;
-            for (int i0 = 0; i0 < n; i0 += CT) {
-                const int i = i0 + threadIdx.x;
-                const int f = (i < n && w.a[i] < 0) ? 1 : 0;
-                int tot;
-                const int off = block_scan_excl(f, &tot, sh);
-                if (f) w.listF[baseR + off] = i;
-                baseR += tot;
-            }
-            if (baseR != nU && threadIdx.x == 0) st->error = 4;
-        }
-        {
-            int base = 0;
-            for (int k0 = 0; k0 < n; k0 += CT) {
-                const int k = k0 + threadIdx.x;
-                const int f = (k < n && w.owner[k] < 0) ? 1 : 0;
-                int tot;
-                const int off = block_scan_excl(f, &tot, sh);
-                if (f) w.listFC[base + off] = k;
-                base += tot;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                st->nFC = base; st->nF = nU; st->fidx = 0; st->st_free_after_arr = nU;
-                st->mode = MODE_UMIN; st->cur = 0; st->nN = 0;
-                if (base != nU) st->error = 4;
-            }
-        }
-        return;
-    }
-
-    if (mode == MODE_UMIN) {           // bidval[i] = u_i for every row
-        if (threadIdx.x == 0) { st->mode = MODE_COLRED; st->st_total_row_scans += n; }
-        return;
-    }
-    if (mode == MODE_BUILD) {          // the wide pass has written the candidate lists
-        if (threadIdx.x == 0) st->mode = MODE_SAP1;
-        return;
-    }
-    if (mode == MODE_SAP1_DONE) {      // the one-workgroup solver has matched every row
-        ctrl_enter_cert(st);
-        return;
-    }
-    if (mode == MODE_COLRED || mode == MODE_ROOTMIN) {
-        // free-column prices are reduced / the roots' u_r are known: hand the last few rows to
-        // the candidate-list solver, otherwise grow a forest from all free rows
-        const int nF = st->nF, sparse = st->sparse, handoff = st->handoff;
-        __syncthreads();
-        if (sparse && nF <= handoff) { if (threadIdx.x == 0) st->mode = MODE_BUILD; return; }
-        ctrl_ms_begin(w, st);
-        return;
-    }
-    if (mode == MODE_SAP) {
-        const int scanned = st->nS;
-        __syncthreads();
-        if (threadIdx.x == 0) { st->st_sap_batches++; st->st_sap_row_scans += scanned; st->st_total_row_scans += scanned; }
-        if (ctrl_sap_step(w, st, shd, shi, reinterpret_cast<double*>(dyn))) return;
-        // converged below the radius: accept one path per tree
-        ctrl_ms_finish(w, st, dyn, dyn + n, use_lds, shd, shi, sh);
-        if (st->error) return;
-        const int nF = st->nF;
-        __syncthreads();
-        if (nF == 0) { ctrl_enter_cert(st); return; }
-        if (threadIdx.x == 0) st->mode = (st->sparse && nF <= st->handoff) ? MODE_BUILD : MODE_ROOTMIN;
-        return;
-    }
-
+    if (!asg_arrive_last(st, &sh[31])) return;
+    // ---- control step (last-arriving workgroup)
     if (mode == MODE_CERT) {
-        // the wide pass has filled minslack / total_cost
-        const double minslack = ord2d(st->minslack_ord);
-        if (threadIdx.x == 0) st->st_total_row_scans += n;
+        // the pass has filled minslack / total_cost: export the result to the caller's buffers
+        const double minslack = ord2d(asg_ld(&st->minslack_ord));
         const double scale = fmax(fabs(st->cmax), fabs(st->cmin));
         const double tol = 1e-10 * fmax(scale, 1e-30);
-        for (int i = threadIdx.x; i < n; i += CT) perm[i] = w.a[i];
-        __syncthreads();
+        int* perm = st->out_perm;
+        for (int i = threadIdx.x; i < n; i += WT) perm[i] = w.a[i];
         if (threadIdx.x == 0) {
-            const int ok = (!st->cert_bad) && (minslack >= -tol);
+            asg_book(st, mode);
+            st->st_total_row_scans += n;
+            const int ok = (!asg_ld(&st->cert_bad)) && (minslack >= -tol);
             st->certified = ok;
-            if (certified) *certified = ok;
-            if (total_cost) *total_cost = st->total_cost;
+            const double total = __longlong_as_double((long long)asg_ld(reinterpret_cast<unsigned long long*>(&st->total_cost)));
+            if (st->out_cert) *st->out_cert = ok;
+            if (st->out_cost) *st->out_cost = total;
+            int* stats = st->out_stats;
             if (stats) {
                 stats[0] = st->st_auction_rounds; stats[1] = st->st_arr_rounds;
                 stats[2] = st->st_free_after_arr; stats[3] = st->st_sap_batches;
@@ -1248,23 +1220,71 @@ __device__ __forceinline__ void asg_ctrl_body(const AsgWs& w, int* dyn) {
                 stats[6] = st->st_steps;
                 stats[7] = (st->phase & 0xff) | ((st->st_ms_phases & 0xff) << 8) | (st->st_dense_fallbacks << 16);
             }
-            __threadfence();
             st->mode = MODE_DONE;
         }
         return;
     }
+    if (threadIdx.x != 0) return;
+    asg_book(st, mode);
+    if (mode == MODE_UMIN) {
+        st->st_total_row_scans += n;
+        st->mode = MODE_COLRED;
+    } else if (mode == MODE_COLRED) {
+        st->mode = (st->sparse && st->nF <= st->handoff) ? MODE_BUILD : MODE_ROOTMIN;
+    } else if (mode == MODE_ROOTMIN) {
+        st->nS = st->nF; asg_st(&st->nN, 0); st->dfree = INFINITY;
+        asg_st(&st->fr_min, ~0ull); asg_st(&st->fr_max, 0ull);
+        st->st_ms_phases++;
+        st->st_total_row_scans += st->nF;
+        st->mode = MODE_SAP;
+    } else if (mode == MODE_SAP) {
+        // New radius: one tree — the best free-column label (no label at or above it can matter);
+        // several trees — the largest free-column label (infinite until every free column is
+        // reached).  It only ever decreases within a phase, so an entry skipped once is never
+        // needed later.  Entries were appended against the OLD radius: if none is left below the
+        // new one the next round relaxes nothing, appends nothing, and the phase closes.
+        const int nN = asg_ld(&st->nN);
+        const unsigned long long f = (st->nF == 1) ? asg_ld(&st->fr_min) : asg_ld(&st->fr_max);
+        st->st_sap_batches++; st->st_sap_row_scans += st->nS; st->st_total_row_scans += st->nS;
+        st->dfree = (f == ~0ull || f == 0ull) ? INFINITY : ord2d(f);
+        asg_st(&st->fr_min, ~0ull); asg_st(&st->fr_max, 0ull);
+        st->cur ^= 1; st->nS = nN; asg_st(&st->nN, 0);
+        if (nN == 0) st->mode = MODE_MS_FINISH;
+    } else if (mode == MODE_MS_FINISH) {
+        st->mode = asg_ld(&st->next_mode);
+    }
 }
 
-__global__ __launch_bounds__(CT) void asg_ctrl(AsgWs w) {
-    extern __shared__ __attribute__((aligned(16))) int dyn[];   // 2*n ints for the path walk
-    const int mode0 = w.st->mode;
-    asg_ctrl_body(w, dyn);
-    __syncthreads();
-    if (threadIdx.x == 0 && mode0 != MODE_DONE)        // t_prev = this launch's start
-        w.st->t_ctrl[mode0 & 15] += (int)(wall_clock64() - w.st->t_prev);
+// ---------------------------------------------------------------- build ------
+__global__ __launch_bounds__(SP_BUILD_WAVES * 64) void asg_build(AsgWs w, int n_host) {
+    extern __shared__ __attribute__((aligned(16))) char build_lds[];
+    __shared__ int sh_flag[4];
+    AsgState* st = w.st;
+    const int mode = st->mode;
+    gfp M = ASG_GLOBAL(st->Mptr);
+    if (mode != MODE_BUILD || st->error) return;
+    wide_build(M, w, st, build_lds);
+    if (asg_arrive_last(st, sh_flag) && threadIdx.x == 0) { asg_book(st, mode); st->mode = MODE_SOLVER; }
 }
 
-// trivial sizes
+// --------------------------------------------------------------- solver ------
+__global__ __launch_bounds__(SP_T) void asg_solve(AsgWs w, int n_host) {
+    extern __shared__ __attribute__((aligned(16))) char solve_lds[];
+    AsgState* st = w.st;
+    const int mode = st->mode;
+    gfp M = ASG_GLOBAL(st->Mptr);
+    if (mode != MODE_SOLVER || st->error) return;
+    sp_solver(M, w, st, solve_lds);      // one workgroup: publishes MODE_CERT (or an error) itself
+}
+
+// --------------------------------------------------------- init / trivial ----
+__global__ void asg_init(AsgWs w, AsgState h) {
+    // the state block arrives as a kernel argument: no host staging buffer, stream ordered
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&h);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(w.st);
+    for (int q = threadIdx.x; q < (int)(sizeof(AsgState) / 8); q += blockDim.x) dst[q] = src[q];
+}
+
 __global__ void asg_trivial(const float* M, int n, int* perm, int* certified, double* total_cost,
                             int* stats) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1274,51 +1294,70 @@ __global__ void asg_trivial(const float* M, int n, int* perm, int* certified, do
     }
 }
 
-// copy the workspace-resident results to the caller's buffers
-__global__ void asg_export(AsgWs w, int n, int* perm, int* certified, double* total_cost, int* stats) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) perm[i] = w.out_perm[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (certified) *certified = w.out_misc[0];
-        if (total_cost) *total_cost = *reinterpret_cast<const double*>(w.out_misc + 12);
-        if (stats) for (int k = 0; k < 8; ++k) stats[k] = w.out_misc[1 + k];
-    }
-}
-
-// The (asg_wide, asg_ctrl) pairs take only workspace-derived arguments, so a chunk of them is
-// captured once per host thread / workspace into a hipGraph and replayed: a solve is ~400 kernel
-// launches, and with several couplings in flight on different streams the host launch rate
-// (~2.7 us per launch across threads) was the limit.  Falls back to plain launches when the stream
-// cannot be captured (the legacy default stream) or CFM_ASG_GRAPH=0.
+// ------------------------------------------------------------------ host -----
+// The kernels take only workspace-derived arguments, so the launch programs are captured once per
+// host thread / workspace into hipGraphs and replayed (a solve is ~200 launches; with several
+// couplings in flight on different streams the host launch rate would be the limit).  Falls back
+// to plain launches when the stream cannot be captured (the legacy default stream) or CFM_ASG_GRAPH=0.
+enum { PRG_A8 = 0, PRG_C8 = 1, PRG_END = 2, PRG_BULK_A = 3, PRG_BULK_C = 4, PRG_COUNT = 5 };
 struct AsgGraph {
-    void* ws = nullptr; int n = 0, pairs = 0; size_t wide_dyn = 0;
-    hipGraphExec_t exec = nullptr;         // `pairs` kernel pairs: the bulk of a solve
-    hipGraphExec_t exec_small = nullptr;   // ASG_TAIL_PAIRS pairs: the polled tail
+    void* ws = nullptr; int n = 0, chunk = 0, bulk_a = 0, bulk_c = 0, blocks = 0, sparse = 0;
+    hipGraphExec_t exec[PRG_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream = nullptr; int disabled = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
-#define ASG_TAIL_PAIRS 8
 static thread_local AsgGraph g_graph;
 
-// 1 (default): bulk chunks, then 8-pair chunks with one chunk of look-ahead, each followed by a
-// copy of the state and an event; 0: 64-pair chunks with a blocking copy.
-static int asg_tail_poll_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CFM_ASG_TAILPOLL"); v = (e && e[0] == '0') ? 0 : 1; }
+static int asg_graph_enabled() {
+    static const int v = [] { const char* e = getenv("CFM_ASG_GRAPH"); return (e && e[0] == '0') ? 0 : 1; }();
     return v;
 }
 
-static int asg_graph_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CFM_ASG_GRAPH"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v;
+// dynamic LDS above the 64 KiB default needs the attribute: once per device
+static int asg_raise_lds() {
+    static std::once_flag once[16];
+    static int ok[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    std::call_once(once[dev], [dev] {
+        hipError_t e1 = hipFuncSetAttribute((const void*)asg_f1, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipError_t e2 = hipFuncSetAttribute((const void*)asg_build, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        hipError_t e3 = hipFuncSetAttribute((const void*)asg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        ok[dev] = (e1 == hipSuccess ? 1 : 0) | (e2 == hipSuccess && e3 == hipSuccess ? 2 : 0);
+        (void)hipGetLastError();
+    });
+    return ok[dev];
 }
 
 // poll buffer (pinned host memory): one per host thread, concurrent solves on different streams
 // must not share it
 static thread_local int* g_pinned = nullptr;
 
+struct AsgLaunch {
+    AsgWs w; int n, blocks; size_t lds_f1, lds_f2, lds_build, lds_solve; int sparse; hipStream_t s;
+    void f1() const { hipLaunchKernelGGL(asg_f1, dim3(blocks), dim3(WT), lds_f1, s, w, n); }
+    void f2() const { hipLaunchKernelGGL(asg_f2, dim3(blocks), dim3(WT), lds_f2, s, w, n); }
+    void end() const {
+        if (sparse) {
+            hipLaunchKernelGGL(asg_build, dim3(blocks), dim3(SP_BUILD_WAVES * 64), lds_build, s, w, n);
+            hipLaunchKernelGGL(asg_solve, dim3(1), dim3(SP_T), lds_solve, s, w, n);
+        }
+        f2(); f2();
+    }
+    void program(int prg, int chunk, int bulk_a, int bulk_c) const {
+        if (prg == PRG_A8) for (int c = 0; c < chunk; ++c) f1();
+        else if (prg == PRG_C8) for (int c = 0; c < chunk; ++c) f2();
+        else if (prg == PRG_END) end();
+        else if (prg == PRG_BULK_A) for (int c = 0; c < bulk_a; ++c) f1();
+        else if (prg == PRG_BULK_C) for (int c = 0; c < bulk_c; ++c) f2();
+    }
+    int count(int prg, int chunk, int bulk_a, int bulk_c) const {
+        return prg == PRG_A8 || prg == PRG_C8 ? chunk : prg == PRG_END ? (sparse ? 4 : 2) : prg == PRG_BULK_A ? bulk_a : bulk_c;
+    }
+};
+
 static int asg_run(const float* M, int B, int* perm, int* certified, double* total_cost, int* stats,
-                   void* ws, void* stream, int use_sparse, int* cert_out) {
+                   void* ws, void* stream, const AsgParams& P, int use_sparse, int* cert_out) {
     if (!M || !perm || B < 0 || (B > 1 && !ws)) return CFM_EINVAL;
     if (B > (1 << 20)) return CFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -1329,154 +1368,124 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     }
     if (((uintptr_t)ws & 15) != 0 || ((uintptr_t)M & 15) != 0) return CFM_EALIGN;
     const int n = B;
-    AsgWs w = asg_carve(ws, n);
+    AsgLaunch L;
+    L.w = asg_carve(ws, n); L.n = n; L.s = s;
     if (!g_pinned) {
         int rc = cfm_hip(hipHostMalloc((void**)&g_pinned, 256, hipHostMallocDefault));
         if (rc) return rc;
     }
     int wide_blocks = (n + 15) / 16;        // one wave per row when everything bids
     if (wide_blocks > 512) wide_blocks = 512;
-    if (g_wide_blocks_cap > 0 && wide_blocks > g_wide_blocks_cap) wide_blocks = g_wide_blocks_cap;
+    if (P.wide_blocks_cap > 0 && wide_blocks > P.wide_blocks_cap) wide_blocks = P.wide_blocks_cap;
     if (wide_blocks < (n + 63) / 64) wide_blocks = (n + 63) / 64;
     if (wide_blocks < 1) wide_blocks = 1;
+    L.blocks = wide_blocks;
+    const int raised = asg_raise_lds();
+    const bool stage_p = (n <= WIDE_PLDS_MAX) && ((n & 3) == 0);
+    L.lds_f1 = (stage_p ? (size_t)n * sizeof(double) : 0) + 8 * WT + 64;      // prices | 8 KiB scratch | flags
+    if (L.lds_f1 > 64 * 1024 && !(raised & 1)) return CFM_EINVAL;
+    L.lds_f2 = sizeof(double) * WT + 2 * sizeof(int) * WT;
+    if (n <= 6144 && (size_t)2 * n * sizeof(int) > L.lds_f2) L.lds_f2 = (size_t)2 * n * sizeof(int);   // path walks of MS_FINISH
+    L.sparse = (use_sparse && n <= SP_NMAX && (raised & 2)) ? 1 : 0;
+    L.lds_build = sp_build_lds_bytes(n); L.lds_solve = sp_solver_lds_bytes(n);
+
     AsgState h;
     memset(&h, 0, sizeof(h));
     h.wide_blocks = wide_blocks;
-    h.mode = MODE_INIT; h.n = n; h.Mptr = M;
-    h.eps = g_params.eps0_frac; h.eps_last = g_params.eps_last_frac; h.theta = g_params.theta;
-    h.stop_frac = g_params.stop_frac; h.round_cap = g_params.round_cap; h.arr_cap = g_params.arr_cap;
+    h.mode = MODE_UMIN0; h.n = n; h.Mptr = M;
+    h.out_perm = perm; h.out_cert = certified; h.out_cost = total_cost; h.out_stats = stats;
+    h.eps = P.eps0_frac; h.eps_last = P.eps_last_frac; h.theta = P.theta;
+    h.stop_frac = P.stop_frac; h.round_cap = P.round_cap; h.arr_cap = P.arr_cap;
     h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
-    h.sparse = (use_sparse && n <= SP_NMAX) ? 1 : 0;
-    h.handoff = g_params.handoff; h.ms_q = g_params.ms_q; h.stop_early = g_params.stop_early;
-    size_t wide_dyn = sizeof(double) * WT + 2 * sizeof(int) * WT;
-    if (n <= WIDE_PLDS_MAX && (size_t)n * sizeof(double) > wide_dyn) wide_dyn = (size_t)n * sizeof(double);
-    if (h.sparse) {
-        const size_t need = sp_lds_bytes(n);
-        if (need > wide_dyn) wide_dyn = need;
-        static int raised = 0;   // dynamic LDS above the 64 KiB default needs the attribute
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)asg_wide,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised = (e == hipSuccess) ? 1 : -1;
-            (void)hipGetLastError();
-        }
-        if (raised < 0 && wide_dyn > 64 * 1024) { h.sparse = 0; wide_dyn = 64 * 1024; }
-    }
-    int rc = cfm_hip(hipMemcpyAsync(w.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
-    if (rc) return rc;
-    const size_t n2 = (size_t)n * n;
-    const int mm_blocks = (int)((n2 / 4 + 255) / 256 < 1024 ? (n2 / 4 + 255) / 256 + 1 : 1024);
-    hipLaunchKernelGGL(asg_minmax, dim3(mm_blocks), dim3(256), 0, s, M, n2, w.st);
-    // path walks in LDS (2 n ints, n <= 6144); never less than the 1024 doubles of ctrl_radius
-    const size_t dyn = (n <= 6144) ? (size_t)2 * n * sizeof(int) : (size_t)CT * sizeof(double);
-    hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, w);
-    rc = cfm_status();
+    h.fr_min = ~0ull; h.fr_max = 0ull;
+    h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early;
+    h.tag = 1;
+    { int rb = 1; while ((1 << rb) <= n) ++rb; h.rb = rb; }     // row ids 0 .. n-1 and the all-ones "none"
+    hipLaunchKernelGGL(asg_init, dim3(1), dim3(64), 0, s, L.w, h);
+    int rc = cfm_status();
     if (rc) return rc;
 
-    // one hipGraph of `chunk` pairs per (thread, workspace, n), replayed
-    const int gchunk = g_params.chunk;
+    const int chunk = P.chunk > 0 ? P.chunk : 8;
+    const bool blind = n >= 1024;
+    const int bulk_a = blind ? P.bulk_a : 0, bulk_c = blind ? P.bulk_c : 0;
     AsgGraph& G = g_graph;
     bool use_graph = asg_graph_enabled() && !G.disabled && n >= 256;
-    if (use_graph && !(G.exec && G.ws == ws && G.n == n && G.pairs == gchunk && G.wide_dyn == wide_dyn && G.stream == s)) {
-        if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
-        if (G.exec_small) { (void)hipGraphExecDestroy(G.exec_small); G.exec_small = nullptr; }
-        auto capture = [&](int npairs, hipGraphExec_t* out) -> hipError_t {
+    if (use_graph && !(G.exec[0] && G.ws == ws && G.n == n && G.chunk == chunk && G.bulk_a == bulk_a &&
+                       G.bulk_c == bulk_c && G.blocks == wide_blocks && G.sparse == L.sparse && G.stream == s)) {
+        for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
+        hipError_t e = hipSuccess;
+        for (int prg = 0; prg < PRG_COUNT && e == hipSuccess; ++prg) {
+            if (L.count(prg, chunk, bulk_a, bulk_c) == 0) continue;
             hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-            if (e != hipSuccess) return e;
-            for (int c = 0; c < npairs; ++c) {
-                hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), wide_dyn, s, w, n);
-                hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, w);
-            }
+            e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (e != hipSuccess) break;
+            L.program(prg, chunk, bulk_a, bulk_c);
             e = hipStreamEndCapture(s, &graph);
-            if (e == hipSuccess && graph) e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+            if (e == hipSuccess && graph) e = hipGraphInstantiate(&G.exec[prg], graph, nullptr, nullptr, 0);
             if (graph) (void)hipGraphDestroy(graph);
-            return e;
-        };
-        hipError_t e = capture(gchunk, &G.exec);
-        if (e == hipSuccess && G.exec) e = capture(ASG_TAIL_PAIRS, &G.exec_small);
+        }
         for (int q = 0; q < 2 && e == hipSuccess; ++q)
             if (!G.ev[q]) e = hipEventCreateWithFlags(&G.ev[q], hipEventDisableTiming);
-        if (e != hipSuccess || !G.exec || !G.exec_small) {
+        if (e != hipSuccess) {
             (void)hipGetLastError();
-            if (G.exec) { (void)hipGraphExecDestroy(G.exec); }
-            if (G.exec_small) { (void)hipGraphExecDestroy(G.exec_small); }
-            G.exec = nullptr; G.exec_small = nullptr; G.disabled = 1; use_graph = false;     // e.g. the legacy default stream
+            for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
+            G.disabled = 1; use_graph = false;     // e.g. the legacy default stream
         } else {
-            G.ws = ws; G.n = n; G.pairs = gchunk; G.wide_dyn = wide_dyn; G.stream = s;
+            G.ws = ws; G.n = n; G.chunk = chunk; G.bulk_a = bulk_a; G.bulk_c = bulk_c; G.blocks = wide_blocks;
+            G.sparse = L.sparse; G.stream = s;
         }
     }
+    if (!use_graph) for (int q = 0; q < 2; ++q)
+        if (!G.ev[q]) { rc = cfm_hip(hipEventCreateWithFlags(&G.ev[q], hipEventDisableTiming)); if (rc) return rc; }
 
-    if (use_graph && n >= 1024 && asg_tail_poll_enabled()) {
-        // The bulk (a solve at n = 4096 takes 135 - 230 pairs) goes out unpolled; the tail in
-        // 8-pair chunks, each followed by a 64-byte copy of the state into its own pinned slot and
-        // an event, with the NEXT chunk already queued when the host waits for a slot: no idle
-        // gap, and a finished solve is followed by at most ~1.5 chunks of no-op pairs.
-        const int bulk = (n >= 4096) ? 2 : 1;
-        for (int r = 0; r < bulk; ++r) { rc = cfm_hip(hipGraphLaunch(G.exec, s)); if (rc) return rc; }
-        int pairs = bulk * gchunk, cur = 0;
-        auto chunk = [&](int slot) -> int {
-            int r2 = cfm_hip(hipGraphLaunch(G.exec_small, s)); if (r2) return r2;
-            r2 = cfm_hip(hipMemcpyAsync(g_pinned + 16 * slot, w.st, 64, hipMemcpyDeviceToHost, s)); if (r2) return r2;
-            return cfm_hip(hipEventRecord(G.ev[slot], s));
-        };
-        rc = chunk(0); if (rc) return rc;
-        pairs += ASG_TAIL_PAIRS;
-        for (;;) {
-            rc = chunk(cur ^ 1); if (rc) return rc;
-            pairs += ASG_TAIL_PAIRS;
-            rc = cfm_hip(hipEventSynchronize(G.ev[cur])); if (rc) return rc;
-            const int* hs = g_pinned + 16 * cur;
-            const int mode = hs[0], err = hs[9];
-            if (err) return CFM_ENOCONV;
-            if (mode == MODE_DONE) { if (cert_out) *cert_out = hs[15]; break; }
-            if (pairs >= g_params.max_pairs) return CFM_ETIMEOUT;
-            cur ^= 1;
-        }
-        hipLaunchKernelGGL(asg_export, dim3((n + 1023) / 1024 < 64 ? (n + 1023) / 1024 : 64), dim3(1024), 0, s, w, n,
-                           perm, certified, total_cost, stats);
+    long launched = 0;
+    auto run = [&](int prg) -> int {
+        const int cnt = L.count(prg, chunk, bulk_a, bulk_c);
+        if (cnt == 0) return 0;
+        launched += cnt;
+        if (use_graph) return cfm_hip(hipGraphLaunch(G.exec[prg], s));
+        L.program(prg, chunk, bulk_a, bulk_c);
         return cfm_status();
-    }
-
-    int pairs = 0;
+    };
+    // The bulk goes out unpolled (a solve at n = 4096 takes ~100 f1 and ~75 f2 launches); the rest in
+    // chunks chosen from the last polled mode, each followed by a 64-byte copy of the state into its
+    // own pinned slot and an event, with the NEXT chunk already queued when the host waits for a
+    // slot: no idle gap.  A wrong guess costs a few no-op launches, never correctness.
+    rc = run(PRG_BULK_A); if (rc) return rc;
+    rc = run(PRG_BULK_C); if (rc) return rc;
+    int guess = blind ? PRG_C8 : PRG_A8, cur = 0;
+    auto issue = [&](int slot) -> int {
+        int r2 = run(guess); if (r2) return r2;
+        r2 = cfm_hip(hipMemcpyAsync(g_pinned + 16 * slot, L.w.st, 64, hipMemcpyDeviceToHost, s)); if (r2) return r2;
+        return cfm_hip(hipEventRecord(G.ev[slot], s));
+    };
+    rc = issue(0); if (rc) return rc;
     for (;;) {
-        // a typical solve needs 150 - 300 pairs: enqueue most of them before the first poll
-        const int reps = (pairs == 0 && n >= 1024) ? 3 : 1;
-        for (int r = 0; r < reps; ++r) {
-            if (use_graph) {
-                rc = cfm_hip(hipGraphLaunch(G.exec, s));
-                if (rc) return rc;
-            } else {
-                for (int c = 0; c < gchunk; ++c) {
-                    hipLaunchKernelGGL(asg_wide, dim3(wide_blocks), dim3(WT), wide_dyn, s, w, n);
-                    hipLaunchKernelGGL(asg_ctrl, dim3(1), dim3(CT), dyn, s, w);
-                }
-            }
-        }
-        pairs += reps * gchunk;
-        rc = cfm_status();
-        if (rc) return rc;
-        rc = cfm_hip(hipMemcpyAsync(g_pinned, w.st, 64, hipMemcpyDeviceToHost, s));
-        if (rc) return rc;
-        rc = cfm_hip(hipStreamSynchronize(s));
-        if (rc) return rc;
-        const int mode = g_pinned[0], err = g_pinned[9];
+        rc = issue(cur ^ 1); if (rc) return rc;
+        rc = cfm_hip(hipEventSynchronize(G.ev[cur])); if (rc) return rc;
+        const int* hs = g_pinned + 16 * cur;
+        const int mode = hs[0], err = hs[2];
         if (err) return CFM_ENOCONV;
-        if (mode == MODE_DONE) { if (cert_out) *cert_out = g_pinned[15]; break; }
-        if (pairs >= g_params.max_pairs) return CFM_ETIMEOUT;
+        if (mode == MODE_DONE) { if (cert_out) *cert_out = hs[3]; break; }
+        if (launched >= P.max_launches) return CFM_ETIMEOUT;
+        guess = (mode <= MODE_CONVERT) ? PRG_A8 : (mode == MODE_BUILD || mode == MODE_SOLVER) ? PRG_END : PRG_C8;
+        cur ^= 1;
     }
-    hipLaunchKernelGGL(asg_export, dim3((n + 1023) / 1024 < 64 ? (n + 1023) / 1024 : 64), dim3(1024), 0, s, w, n,
-                       perm, certified, total_cost, stats);
-    return cfm_status();
+    // the look-ahead chunk is still in flight: it is a string of no-ops on a finished state, but the
+    // workspace (and the pinned slot it copies into) must not be reused under it
+    rc = cfm_hip(hipEventSynchronize(G.ev[cur ^ 1]));
+    return rc;
 }
 
 extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,
                                     double* total_cost, int* stats, void* ws, void* stream) {
+    const AsgParams P = asg_params_snapshot();
     int cert = 1;
-    int rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, g_params.sparse, &cert);
+    int rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, P, P.sparse, &cert);
     // The candidate-list path is exact by construction; should its certificate ever fail
     // (or its solver report an inconsistency) the dense state machine decides.
-    if (g_params.sparse && B > 1 && B <= SP_NMAX && (rc == CFM_ENOCONV || (rc == 0 && !cert)))
-        rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, 0, &cert);
+    if (P.sparse && B > 1 && B <= SP_NMAX && (rc == CFM_ENOCONV || (rc == 0 && !cert)))
+        rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, P, 0, &cert);
+    if (rc == 0 && B > 1 && !cert) rc = CFM_ENOCONV;     // never hand back an uncertified permutation silently
     return rc;
 }

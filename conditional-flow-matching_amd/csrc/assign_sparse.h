@@ -9,7 +9,7 @@
 //                columns with the smallest c_ik + p_k, their fp32 costs, and a bound T_i with
 //                c_ik + p_k >= T_i for every column that was NOT kept.  Prices only rise
 //                afterwards, so the bound stays valid for the rest of the solve.
-//   sp_solver    (ONE workgroup, 16 waves, state in LDS: prices, labels, predecessors,
+//   sp_solver    (ONE workgroup = the asg_solve kernel, 16 waves, state in LDS: prices, labels, predecessors,
 //                owners, the scan list)  runs all searches with workgroup barriers instead
 //                of kernel boundaries.  A row is relaxed over its 64 candidates only; when a
 //                search has converged every tree row is checked a posteriori:
@@ -37,13 +37,12 @@
 #define SP_BUILD_WAVES 8   // waves per workgroup that build lists
 #define SP_CAP 64          // list entries per batch (16 waves x 4 entries kept in registers)
 
-// dynamic LDS of asg_wide when the candidate-list path is on: the solver's state (34 B per
-// column) or the list builder's strips (one fp32 row per building wave), whichever is larger
-static inline size_t sp_lds_bytes(int n) {
-    const size_t solver = (size_t)n * 34 + 4096;
-    const size_t build = (size_t)SP_BUILD_WAVES * (size_t)((n + 63) / 64) * 64 * sizeof(float) + 64;
-    return solver > build ? solver : build;
+// dynamic LDS of the two candidate-list kernels: the list builder's strips (one fp32 row per building
+// wave) and the solver's state (34 B per column)
+static inline size_t sp_build_lds_bytes(int n) {
+    return (size_t)SP_BUILD_WAVES * (size_t)((n + 63) / 64) * 64 * sizeof(float) + 64;
 }
+static inline size_t sp_solver_lds_bytes(int n) { return (size_t)n * 34 + 4096; }
 
 struct SpL {
     double* p;               // prices
@@ -99,7 +98,7 @@ __device__ __forceinline__ int sp_count(const float* __restrict__ r, int nt, flo
 // lives in the wave's LDS strip (lane-major: conflict free).  A threshold tau with
 // count(r < tau) in [32, 64] is found by bisection; members are r < tau, and every
 // non-member satisfies (c + p) >= rowmin + tau * (1 - 2^-22) =: T.
-__device__ __forceinline__ void wide_build(const float* __restrict__ M, const AsgWs& w, const AsgState* st,
+__device__ __forceinline__ void wide_build(gfp M, const AsgWs& w, const AsgState* st,
                            char* lds) {
     const int n = st->n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -113,7 +112,7 @@ __device__ __forceinline__ void wide_build(const float* __restrict__ M, const As
     const bool fastb = false;
 #endif
     for (int i = wave_gid; i < n; i += n_waves) {
-        const float* row = M + (size_t)i * n;
+        gfp row = M + (size_t)i * n;
         float lmin = INFINITY;
         double m = INFINITY;
         if (fastb) {
@@ -123,7 +122,7 @@ __device__ __forceinline__ void wide_build(const float* __restrict__ M, const As
             float4 c4[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                c4[j] = *reinterpret_cast<const float4*>(row + 256 * (j < nj ? j : 0) + 4 * lane);
+                c4[j] = asg_ld4(row + 256 * (j < nj ? j : 0) + 4 * lane);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 if (j < nj) {
@@ -319,7 +318,7 @@ __device__ __forceinline__ double sp_cand(double pk, float c, double rj, double 
 
 // generic entry (dense entries allowed); recomputed in phase W
 template <bool PHASE_W>
-__device__ __forceinline__ void sp_entry(const float* __restrict__ M, const AsgWs& w, const SpL& L, int n,
+__device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, int n,
                                          unsigned e, double base, int i0, double u0, int lane, int plcur,
                                          double dfree, double far_thr) {
     const bool dense = (e & SP_DENSE) != 0, root = (e & SP_ROOT) != 0;
@@ -343,7 +342,7 @@ __device__ __forceinline__ void sp_entry(const float* __restrict__ M, const AsgW
             else if (cand < dfree) sp_lower(L, (int)col, cand, L.dist[col]);
         }
     } else {
-        const float* row = M + (size_t)i * n;
+        gfp row = M + (size_t)i * n;
         if (!root) rj = (double)row[j] + L.p[j];
         for (int k0 = 0; k0 < n; k0 += 64 * 8) {
             float c[8];
@@ -385,7 +384,7 @@ __device__ __forceinline__ double sp_rfl_d(double v) {
 // that is uniform over the wave (entry, row, base label, the lane holding the matched edge)
 // is moved to scalar registers so the control flow is scalar.  Candidates stay in registers
 // between the two phases.  The last wave also refreshes dfree (published through LDS).
-__device__ __forceinline__ void sp_fast_batch(const float* __restrict__ M, const AsgWs& w, const SpL& L,
+__device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& L,
                                               int n, int nS, int nFC, double dfree, int i0, double u0,
                                               int lane, int wv, int plcur, double far_thr, long long* fb) {
 #ifdef SP_PROFILE
@@ -660,7 +659,7 @@ __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double
 #define SP_TICK(slot) do { } while (0)
 #endif
 
-__device__ __forceinline__ void sp_solver(const float* __restrict__ M, const AsgWs& w, AsgState* st, char* lds) {
+__device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, char* lds) {
 #ifdef SP_PROFILE
     long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long fbv[6] = {0, 0, 0, 0, 0, 0};
@@ -917,6 +916,8 @@ __device__ __forceinline__ void sp_solver(const float* __restrict__ M, const Asg
         st->st_total_row_scans += scans;
         st->st_dense_fallbacks += dense_scans;
         if (err) st->error = err;
-        st->mode = MODE_SAP1_DONE;
+        asg_book(st, MODE_SOLVER);
+        asg_enter_cert(st);
+        st->mode = MODE_CERT;
     }
 }

@@ -86,8 +86,10 @@ def assign_exact(M, return_info=False):
     ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
     check(lib.cfm_assign_exact_f32(ptr(M), B, ptr(perm), ptr(cert), ptr(tot), ptr(stats), ptr(ws),
                                    stream_ptr()), "cfm_assign_exact_f32")
+    # The call returns only once the result is resident, and it returns CFM_ENOCONV rather than an
+    # uncertified permutation, so nothing has to be read back unless the caller wants the statistics.
     info = None
-    if B > 0:
+    if return_info and B > 0:
         c, s, t = cert.cpu(), stats.cpu(), tot.cpu()
         if int(c[0]) != 1:
             raise CfmBackendError("exact assignment finished without an optimality certificate")
@@ -138,7 +140,10 @@ def sinkhorn_log(M, reg, max_iter=_SINKHORN_MAX_ITER, stop_thr=_SINKHORN_STOP_TH
     r.g = torch.empty(B1, dtype=torch.float32, device=dev)
     r.iters = torch.zeros(1, dtype=torch.int32, device=dev)
     r.err = torch.zeros(1, dtype=torch.float32, device=dev)
-    r.ws = _lib.workspace(_lib.OP_SINKHORN, B0, B1, 0, dev)
+    # The fp64 potentials stay in this buffer and the result object refers to them later (plan,
+    # sampling, cost): it owns the buffer — a cached, shared workspace would be overwritten by the
+    # next same-shape solve on this stream while earlier results are still alive.
+    r.ws = torch.empty(lib.cfm_workspace_bytes(_lib.OP_SINKHORN, B0, B1, 0), dtype=torch.uint8, device=dev)
     r.reg, r.M = float(reg), M
     check(lib.cfm_sinkhorn_log_f32(ptr(M), B0, B1, float(reg), int(max_iter), float(stop_thr),
                                    int(check_every), ptr(r.f), ptr(r.g), ptr(r.iters), ptr(r.err),
@@ -286,8 +291,8 @@ class OTPlanSampler:
                 plan, _ = exact_plan_rect(M)
                 self._last = torch.zeros(4, dtype=torch.int32)
                 return "plan", plan, M
-            perm, info = assign_exact(M, return_info=True)
-            self._last = info
+            perm = assign_exact(M)        # raises unless the fp64 certificate holds; nothing is read back
+            self._last = {"certified": True}
             return "perm", perm, M
         r = sinkhorn_log(M, self.reg)
         self._last = r
