@@ -16,13 +16,13 @@
 // min / max words), so no release / acquire fence is paid; everything else is read by
 // the NEXT launch, where the kernel boundary is the fence.  A kernel whose family does
 // not own the current mode exits at once, so the host may replay a guessed program:
-// correctness never depends on the guess.  Four kernels, one per register / LDS
+// correctness never depends on the guess.  Three kernels, one per register / LDS
 // profile (no scratch, no oversized LDS reservation):
 //
-//   asg_f1     init + auction      UMIN0, INITRED, AUCTION, ARR, CONVERT
-//   asg_f2     phase C, dense      UMIN, COLRED, ROOTMIN, SAP, MS_FINISH, CERT
-//   asg_build  candidate lists     BUILD            (n <= 4096)
-//   asg_solve  one-workgroup list solver   SOLVER   (n <= 4096)
+//   asg_step   every chip-wide step   UMIN0, INITRED, AUCTION, ARR, CONVERT, UMIN, COLRED, ROOTMIN,
+//                                     SAP, MS_FINISH, CERT       (119 VGPRs, <= 48 KiB LDS at n = 4096)
+//   asg_build  candidate lists        BUILD            (n <= 4096; 8 waves, 128 KiB of row strips)
+//   asg_solve  one-workgroup list solver   SOLVER      (n <= 4096; 143 KiB of solver state)
 //
 //   init     Jonker-Volgenant row + column reduction: u_i = min_j c_ij,
 //            p_j = max_i (u_i - c_ij) (every column tight for some row) — the auction
@@ -90,13 +90,13 @@ struct AsgParams {
     int handoff;           // ... once at most this many free rows are left
     double stop_early;     // stop_frac of every epsilon phase but the last (0 = same as stop_frac)
     int wide_blocks_cap;   // upper bound on the grid of the wide kernels (0 = none)
-    int bulk_a, bulk_c;    // launches of asg_f1 / asg_f2 enqueued before the first poll (n >= 1024)
+    int bulk;              // asg_step launches enqueued before the first poll (n >= 1024)
 };
 
 // Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
 // called from another thread never tear a running solve.
 static std::mutex g_params_mu;
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 8, 800000, 1, 6, 0.0, 0, 104, 72};
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 10, 800000, 1, 6, 0.0, 0, 160};
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
@@ -117,10 +117,9 @@ extern "C" void cfm_assign_set_wide_blocks(int cap) { std::lock_guard<std::mutex
 extern "C" void cfm_assign_set_handoff(int handoff) { std::lock_guard<std::mutex> lk(g_params_mu); if (handoff >= 0) g_params.handoff = handoff; }
 extern "C" void cfm_assign_set_stop_early(double f) { std::lock_guard<std::mutex> lk(g_params_mu); if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
 extern "C" void cfm_assign_set_ms_quantile(double) {}   // kept for old tuning scripts: the radius is the largest free-column label
-extern "C" void cfm_assign_set_bulk(int bulk_a, int bulk_c) {
+extern "C" void cfm_assign_set_bulk(int bulk, int) {
     std::lock_guard<std::mutex> lk(g_params_mu);
-    if (bulk_a >= 0) g_params.bulk_a = bulk_a;
-    if (bulk_c >= 0) g_params.bulk_c = bulk_c;
+    if (bulk >= 0) g_params.bulk = bulk;
 }
 
 // 512 bytes at the head of the workspace.  Line 0 is read-mostly inside a launch (its first 64 bytes
@@ -132,11 +131,10 @@ struct AsgState {
     const float* Mptr;     // kernels take the matrix from here: launch arguments depend on the workspace only
     int* out_perm; int* out_cert; double* out_cost; int* out_stats;   // caller's buffers
     int tag, rb;           // current bid tag (1..254), row bits of a key
-    int round, phase, stop, arr_round, round_cap, arr_cap, sparse, handoff;
+    int round, phase, stop, arr_round, round_cap, arr_cap, sparse, handoff;   // (meta bits of a key = rb + ASG_RND_BITS)
     double eps, eps_last, theta, stop_frac;
     // ---- line 1
-    alignas(128) int ticket;   // arrivals of the current launch
-    int cnt;                   // bidders of the current round
+    alignas(128) unsigned long long arrive;   // arrivals of the current launch << 32 | their payload sum (bidders of the round)
     int nN;                    // entries appended to the next scan list
     int cert_bad;
     unsigned cmin_bits, cmax_bits;      // ordered-float min / max of the matrix
@@ -155,7 +153,7 @@ struct AsgState {
     long long t_acc[16];       // time since the previous one on the mode that launch ran in
 };
 static_assert(sizeof(AsgState) <= 512, "AsgState has 512 bytes at the head of the workspace");
-static_assert(offsetof(AsgState, ticket) == 128 && offsetof(AsgState, nF) == 256, "AsgState layout");
+static_assert(offsetof(AsgState, arrive) == 128 && offsetof(AsgState, nF) == 256, "AsgState layout");
 
 // Tuning aid, not part of the ABI: microseconds the last solve on `ws` spent in each mode (slots
 // 0-15, index = MODE_*; launch + gap to the next launch).  Slots 16-31 are zero.  Blocking.
@@ -291,18 +289,21 @@ __device__ __forceinline__ void asg_st(unsigned long long* p, unsigned long long
 // Every workgroup of a launch calls this once, after its share of the step: returns true (in all
 // its threads) in the workgroup that arrives last.  Each wave first waits until its own stores and
 // atomics have been performed, so everything the others contributed through device-scope atomics
-// is complete when the last ticket is drawn.
-__device__ __forceinline__ bool asg_arrive_last(AsgState* st, int* sh_flag) {
+// is complete when the last ticket is drawn.  The arrival word also carries a payload (the
+// workgroup's bidders in a bid round): ONE device-scope round trip per workgroup, and the last
+// arriver gets the sum with its ticket (sh_flag[1]).
+__device__ __forceinline__ bool asg_arrive_last(AsgState* st, int* sh_flag, unsigned payload) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(&st->ticket, 1, __ATOMIC_RELAXED, ASG_AGENT);
-        const int last = (t == (int)gridDim.x - 1) ? 1 : 0;
-        if (last) asg_st(&st->ticket, 0);
-        *sh_flag = last;
+        const unsigned long long t = __hip_atomic_fetch_add(&st->arrive, (1ull << 32) | (unsigned long long)payload,
+                                                            __ATOMIC_RELAXED, ASG_AGENT);
+        const int last = ((unsigned)(t >> 32) == gridDim.x - 1u) ? 1 : 0;
+        if (last) asg_st(&st->arrive, 0ull);
+        sh_flag[0] = last; sh_flag[1] = (int)((unsigned)t + payload);
     }
     __syncthreads();
-    return *sh_flag != 0;
+    return sh_flag[0] != 0;
 }
 
 // thread 0 of the deciding workgroup: book the time since the previous control step on `mode`
@@ -320,18 +321,22 @@ __device__ __forceinline__ void asg_enter_cert(AsgState* st) {   // one thread
 }
 
 // ------------------------------------------------------------------ keys -----
-// key = ((d2ord(price) & ~mask) - unit) | row: the largest grid value strictly below the price, so a
-// bid never exceeds what the bidder computed (its new object stays its strict minimum), and any
-// bid that registers (atomicMax) raises the price.  The price of an object IS ord2d(key).
-__device__ __forceinline__ unsigned long long asg_enc(double v, unsigned row, int rb) {
-    const unsigned long long mask = (1ull << rb) - 1ull;
-    return ((d2ord(v) & ~mask) - (1ull << rb)) | (unsigned long long)row;
+// key = (d2ord(price) & ~meta_mask) | round << rb | row.  The PRICE of an object is the key with the
+// meta bits cleared: a grid of 2^-(52 - mb) relative resolution (1.2e-10 at n = 4096).  A bid is
+// rounded DOWN onto the grid, so it never exceeds what the bidder computed (its new object stays
+// its minimum: exact complementary slackness with the grid prices).  Among bids at one price the
+// later round wins, then the higher row: a zero-increment bid of an epsilon = 0 round (a row that
+// is indifferent between its best two objects) still takes the object, as in the classical
+// augmenting row reduction, and simultaneous bids have one winner.
+#define ASG_RND_BITS 6
+__device__ __forceinline__ unsigned long long asg_enc(double v, unsigned meta, int mb) {
+    return (d2ord(v) & ~((1ull << mb) - 1ull)) | (unsigned long long)meta;
 }
-// row bits of a decoded price
-__device__ __forceinline__ int asg_row_of(double p, int rb) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(p);
-    const unsigned long long lo = (b >> 63) ? ~b : b;
-    return (int)(lo & ((1ull << rb) - 1ull));
+__device__ __forceinline__ double asg_price(unsigned long long key, int mb) {
+    return ord2d(key & ~((1ull << mb) - 1ull));
+}
+__device__ __forceinline__ int asg_key_row(unsigned long long key, int rb) {
+    return (int)(key & ((1ull << rb) - 1ull));
 }
 
 // --------------------------------------------------------- wide: auction -----
@@ -396,47 +401,49 @@ __device__ __forceinline__ void bid_segment(Top2& best, const float4 (&c)[16], c
     }
 }
 
-// price of object j: LDS copy of this round's keys, or the key itself (n > WIDE_PLDS_MAX)
-__device__ __forceinline__ double bid_price(const AsgWs& w, const double* p_lds, bool use_plds, int j) {
-    return use_plds ? p_lds[j] : ord2d(w.key[j]);
-}
-
 // A row is matched iff it bid in the current tag and the object it bid for still carries its id.
-__device__ __forceinline__ bool bid_matched(const AsgWs& w, const double* p_lds, bool use_plds, int bc, int tag,
+__device__ __forceinline__ bool bid_matched(const AsgWs& w, const int* r_lds, bool use_lds, int bc, int tag,
                                             int i, int rb) {
     if (((unsigned)bc >> 24) != (unsigned)tag) return false;
-    return asg_row_of(bid_price(w, p_lds, use_plds, bc & 0xffffff), rb) == i;
+    const int j = bc & 0xffffff;
+    return (use_lds ? r_lds[j] : asg_key_row(w.key[j], rb)) == i;
 }
 
-// wave top-2 -> bid (lane 0): one atomicMax, no award step
-__device__ __forceinline__ void bid_commit(const AsgWs& w, Top2 best, int i, double eps, const double* p_lds,
-                                           bool use_plds, int tag, int rb) {
+// wave top-2 -> bid (lane 0): one atomicMax, no award step.  The bid p_j + (second - best) + eps is
+// formed from the price the top-2 was computed with (the LDS snapshot of the round); without a
+// snapshot (n > WIDE_PLDS_MAX) the price may have moved since, and the bid is formed from the
+// cost instead: second - c_ij + eps.
+__device__ __forceinline__ void bid_commit(gfp M, const AsgWs& w, Top2 best, int i, int n, double eps,
+                                           const double* p_lds, bool use_lds, int tag, int rb, int rnd) {
     const double bmin = asg_wave_min_d(best.b);
     const int jwin = asg_wave_min_i(best.b == bmin ? best.j : 0x7fffffff);
     const double rest = (best.b == bmin && best.j == jwin) ? best.s : best.b;
     const double smin = asg_wave_min_d(rest);       // the best of everything but (bmin, jwin)
     if ((threadIdx.x & 63) == 0 && jwin != 0x7fffffff) {
-        const double incr = (smin - bmin) + eps;          // >= eps >= 0
-        const double bv = bid_price(w, p_lds, use_plds, jwin) + incr;
-        if (bv < INFINITY && bv > -INFINITY) atomicMax(&w.key[jwin], asg_enc(bv, (unsigned)i, rb));
+        double bv;
+        if (use_lds) bv = p_lds[jwin] + ((smin - bmin) + eps);          // increment >= eps >= 0
+        else bv = (smin - (double)M[(size_t)i * n + jwin]) + eps;
+        if (bv < INFINITY && bv > -INFINITY)
+            atomicMax(&w.key[jwin], asg_enc(bv, ((unsigned)rnd << rb) | (unsigned)i, rb + ASG_RND_BITS));
         w.bidcol[i] = (tag << 24) | jwin;
     }
 }
 
 // One wave per row; a row bids iff it is unmatched.  pre_bc = bidcol of the wave's first row,
 // requested with the keys in the kernel prologue.  Returns the number of bids of this wave.
-__device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_lds,
+__device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_lds, const int* r_lds,
                                         int wave_gid, int n_waves, int pre_bc, bool stage_p, int n,
-                                        double eps, int tag, int rb) {
+                                        double eps, int tag, int rb, int rnd) {
     const int lane = threadIdx.x & 63;
     const bool vec = ((n & 3) == 0);
     const bool fast = stage_p && (n & 4095) == 0;
+    const int mb = rb + ASG_RND_BITS;
     int nbids = 0;
     int i = wave_gid;
     if (fast) {
         for (; i < n; i += n_waves) {
             const int bc = (i == wave_gid) ? pre_bc : w.bidcol[i];
-            if (bid_matched(w, p_lds, true, bc, tag, i, rb)) continue;
+            if (bid_matched(w, r_lds, true, bc, tag, i, rb)) continue;
             Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
             for (int seg = 0; seg < n; seg += 4096) {
                 // the segment's 16 KB in flight at once: 16 float4 per lane
@@ -447,14 +454,14 @@ __device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_l
                 bid_segment(best, c, p_lds + seg + lane * 4, seg + lane * 4);
                 __builtin_amdgcn_sched_barrier(0);     // the next segment's loads stay behind this one's arithmetic
             }
-            bid_commit(w, best, i, eps, p_lds, true, tag, rb);
+            bid_commit(M, w, best, i, n, eps, p_lds, true, tag, rb, rnd);
             ++nbids;
         }
         return nbids;
     }
     for (; i < n; i += n_waves) {
         const int bc = (i == wave_gid) ? pre_bc : w.bidcol[i];
-        if (bid_matched(w, p_lds, stage_p, bc, tag, i, rb)) continue;
+        if (bid_matched(w, r_lds, stage_p, bc, tag, i, rb)) continue;
         gfp row = M + (size_t)i * n;
         Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
         if (vec && stage_p) {
@@ -481,10 +488,12 @@ __device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_l
                     }
                 }
             }
+        } else if (stage_p) {
+            for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + p_lds[j], j);
         } else {
-            for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + bid_price(w, p_lds, stage_p, j), j);
+            for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + asg_price(w.key[j], mb), j);
         }
-        bid_commit(w, best, i, eps, p_lds, stage_p, tag, rb);
+        bid_commit(M, w, best, i, n, eps, p_lds, stage_p, tag, rb, rnd);
         ++nbids;
     }
     return nbids;
@@ -571,7 +580,7 @@ __device__ __forceinline__ void wide_initred(gfp M, const AsgWs& w, double* sh_d
         if (wv == 0 && ok) {
 #pragma unroll
             for (int q = 1; q < NW; ++q) m = fmax(m, sh_d[q * 64 + lane]);
-            if (m > -INFINITY && m < INFINITY) atomicMax(&w.key[k], asg_enc(m, none, rb));
+            if (m > -INFINITY && m < INFINITY) atomicMax(&w.key[k], asg_enc(m, none, rb + ASG_RND_BITS));
         }
         __syncthreads();
     }
@@ -583,8 +592,7 @@ __device__ __forceinline__ void wide_initred(gfp M, const AsgWs& w, double* sh_d
 // roots the wave also files the root's entry of the first scan list (the start of the phase).
 #define MS_NONE 0x7fffffff
 __device__ __forceinline__ void wide_umin(gfp M, const AsgWs& w, const AsgState* st,
-                          int wave_gid, int n_waves, bool roots_only) {
-    const int n = st->n;
+                          int wave_gid, int n_waves, bool roots_only, const int n) {
     const int cnt = roots_only ? st->nF : n;
     const int lane = threadIdx.x & 63;
     const bool vec = ((n & 3) == 0);
@@ -632,7 +640,6 @@ __device__ __forceinline__ void wide_umin(gfp M, const AsgWs& w, const AsgState*
 // the rest of a multi-source phase start: labels unset (all threads of the grid)
 __device__ __forceinline__ void wide_ms_reset(const AsgWs& w, int n) {
     for (int k = blockIdx.x * WT + threadIdx.x; k < n; k += gridDim.x * WT) { w.dist[k] = INFINITY; w.pred[k] = -1; }
-    for (int g = blockIdx.x * WT + threadIdx.x; g < (n + 63) / 64; g += gridDim.x * WT) w.grp_ticket[g] = 0;
 }
 
 // Column reduction of the free columns: p_k <- max_i (u_i - c_ik), the largest price at which
@@ -640,8 +647,8 @@ __device__ __forceinline__ void wide_ms_reset(const AsgWs& w, int n) {
 // edge stays tight, the dual objective rises by the price drop.  One workgroup per column
 // (strided reads: 64 B sector per row, only nFC columns).
 __device__ __forceinline__ void wide_colred(gfp M, const AsgWs& w, const AsgState* st,
-                            double* sh_d) {
-    const int n = st->n, nFC = st->nFC;
+                            double* sh_d, const int n) {
+    const int nFC = st->nFC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int t = blockIdx.x; t < nFC; t += gridDim.x) {
         const int k = w.listFC[t];
@@ -669,26 +676,19 @@ __device__ __forceinline__ void wide_colred(gfp M, const AsgWs& w, const AsgStat
     }
 }
 
-// How many workgroups share one column group in a relax round of nS entries.
-__device__ __forceinline__ int ms_split(int nS, int n_groups, int blocks) {
-    if (nS <= MS_SPLIT_MIN) return 1;
-    int y = blocks / n_groups;
-    return y < 1 ? 1 : (y > MS_YMAX ? MS_YMAX : y);
-}
-
 // Close a column group's round (wave 0, lane <-> column k): take the merged minimum, append an
 // improved assigned column to the NEXT list, and contribute the labels of the group's free columns
 // to the round's radius words (ordered min / max, one pair of atomics per group).
 __device__ __forceinline__ void relax_close(gfp M, const AsgWs& w, AsgState* st,
-                                            const SList& Nx, int n, int k, bool ok, double pk, double dfree,
-                                            double best, int bi, int br) {
+                                            const SList& L, const SList& Nx, int n, int k, bool ok, double pk,
+                                            double dfree, double best, int bi, int bt) {
     double dk = INFINITY; int ow = 0;
     if (ok) { dk = w.dist[k]; ow = w.owner[k]; }
     if (ok && best < dk) {
         w.dist[k] = best; w.pred[k] = bi; dk = best;
         if (ow >= 0 && best < dfree) {
             const int idx = atomicAdd(&st->nN, 1);
-            Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = br;
+            Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = L.root[bt];   // the winner's tree
             Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
         }
     }
@@ -700,105 +700,87 @@ __device__ __forceinline__ void relax_close(gfp M, const AsgWs& w, AsgState* st,
     if ((threadIdx.x & 63) == 0 && mx > -INFINITY) atomicMax(&st->fr_max, d2ord(mx));   // ... inf labels count for the max
 }
 
-// Relax every listed row.  A workgroup owns columns [64g, 64g+64): lane <-> column
-// (single writer: dist/pred/tree stay consistent without atomics), its 16 waves split the
-// list, 8 independent row loads in flight per lane, LDS merge.  The writer lane
-// appends improved assigned columns to the NEXT list (one atomic per append).  A big round
-// is split over Y workgroups per column group (every Y-th slice of the list each); they write
-// per-column partial minima and the last of them to arrive merges them (see the end of the loop body).
+// Relax every listed row.  A workgroup owns 16 columns; a wave covers 4 list entries x 16 columns per
+// load (64 B of each row), 6 such loads in flight per lane, so one trip of the workgroup's 16 waves
+// relaxes 384 entries and a round is one or two trips deep whatever its size.  The four entry
+// sub-groups of a wave are merged with two lane exchanges, the waves through LDS, and lane <-> column
+// of wave 0 is the single writer of the column (dist / pred / tree stay consistent without atomics
+// or fences); it appends an improved assigned column to the NEXT list (one atomic per append).
+// Ties go to the lowest row id, so the result does not depend on how the list is split.
 __device__ __forceinline__ void wide_relax(gfp M, const AsgWs& w, AsgState* st,
-                           double* sh_d, int* sh_i, int* sh_r) {
-    const int n = st->n, nS = st->nS, cur = st->cur;
+                           double* sh_d, int* sh_i, int* sh_r, const int n) {
+    const int nS = st->nS, cur = st->cur;
     const double dfree = st->dfree;
     const SList L = slist(w, cur), Nx = slist(w, cur ^ 1);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_groups = (n + 63) / 64;
-    constexpr int Q = 8, NW = WT / 64;
-    const int Y = ms_split(nS, n_groups, gridDim.x);
-    for (int unit = blockIdx.x; unit < n_groups * Y; unit += gridDim.x) {
-        const int g = unit % n_groups, y = unit / n_groups;
-        const int k = g * 64 + lane;
+    const int sub = lane >> 4, cl = lane & 15;
+    const int n_groups = (n + 15) / 16;
+    constexpr int Q = 6, NW = WT / 64;     // (8 in flight would need 4 VGPRs more than the 128 of a 16-wave workgroup)
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int k = g * 16 + cl;
         const bool ok = k < n;
         const double pk = ok ? w.p[k] : 0.0;
-        double best = INFINITY; int bi = 0x7fffffff, br = -1;
-        for (int t0 = (y * NW + wv) * Q; t0 < nS; t0 += NW * Q * Y) {
-            int ri[Q], cj[Q], rt[Q]; double bs[Q], rj[Q]; float c[Q];
+        double best = INFINITY; int bi = 0x7fffffff, br = 0;     // br: list index of the best entry (its tree is looked up at the end)
+        for (int t0 = wv * (4 * Q); t0 < nS; t0 += NW * 4 * Q) {
+            int ri[Q]; double bs[Q], rj[Q]; float c[Q];
+            // one base address per array and immediate offsets: entries past nS are read (the lists are
+            // followed by other workspace arrays) and masked
+            const int* prow = L.row + t0 + sub;
+            const double* pbase = L.base + t0 + sub; const double* prj = L.rj + t0 + sub;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { ri[q] = prow[q * 4]; bs[q] = pbase[q * 4]; rj[q] = prj[q * 4]; }
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const int t = t0 + q;
-                const bool v = t < nS;
-                ri[q] = v ? L.row[t] : 0; cj[q] = v ? L.col[t] : -1; rt[q] = v ? L.root[t] : -1;
-                bs[q] = v ? L.base[t] : INFINITY; rj[q] = v ? L.rj[t] : 0.0;
+                const bool v = (t0 + q * 4 + sub) < nS;
+                bs[q] = v ? bs[q] : INFINITY;
+                ri[q] = v ? ri[q] : 0;
             }
 #pragma unroll
             for (int q = 0; q < Q; ++q)
                 c[q] = (ok && bs[q] < dfree) ? M[(size_t)ri[q] * n + k] : 0.f;
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                if (ok && bs[q] < dfree && k != cj[q]) {
+                // (the entry's own column needs no exclusion: its candidate is exactly its label, never below it)
+                if (ok && bs[q] < dfree) {
                     double rc = ((double)c[q] + pk) - rj[q];
                     rc = fmax(rc, 0.0);                   // dual feasible up to rounding
                     const double cand = bs[q] + rc;
-                    if (cand < best || (cand == best && ri[q] < bi)) { best = cand; bi = ri[q]; br = rt[q]; }
+                    if (cand < best || (cand == best && ri[q] < bi)) { best = cand; bi = ri[q]; br = t0 + q * 4 + sub; }
                 }
             }
         }
-        sh_d[wv * 64 + lane] = best; sh_i[wv * 64 + lane] = bi; sh_r[wv * 64 + lane] = br;
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const double c2 = __shfl_xor(best, o, 64); const int i2 = __shfl_xor(bi, o, 64), r2 = __shfl_xor(br, o, 64);
+            if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = r2; }
+        }
+        if (sub == 0) { sh_d[wv * 16 + cl] = best; sh_i[wv * 16 + cl] = bi; sh_r[wv * 16 + cl] = br; }
         __syncthreads();
         if (wv == 0) {
-            if (ok) {
+            const bool okc = ok && sub == 0;
+            // lane (sub, cl) merges the results of waves 4 sub .. 4 sub + 3, then two lane exchanges
+            best = INFINITY; bi = 0x7fffffff; br = 0;
 #pragma unroll
-                for (int q = 1; q < NW; ++q) {
-                    const double c2 = sh_d[q * 64 + lane]; const int i2 = sh_i[q * 64 + lane];
-                    if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = sh_r[q * 64 + lane]; }
-                }
+            for (int q = 0; q < NW / 4; ++q) {
+                const int s2 = (sub * (NW / 4) + q) * 16 + cl;
+                const double c2 = sh_d[s2]; const int i2 = sh_i[s2];
+                if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = sh_r[s2]; }
             }
-            if (Y > 1) {
-                if (ok) { w.part_d[(size_t)y * n + k] = best; w.part_i[(size_t)y * n + k] = bi; w.part_r[(size_t)y * n + k] = br; }
-            } else {
-                relax_close(M, w, st, Nx, n, k, ok, pk, dfree, best, bi, br);
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const double c2 = __shfl_xor(best, o, 64); const int i2 = __shfl_xor(bi, o, 64), r2 = __shfl_xor(br, o, 64);
+                if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = r2; }
             }
+            relax_close(M, w, st, L, Nx, n, k, okc, pk, dfree, best, bi, br);
         }
         __syncthreads();
-        if (Y > 1) {
-            // The Y workgroups of a column group hand their partial minima to the LAST one to arrive,
-            // which merges them and finalises the group's 64 columns exactly as an unsplit round does.
-            // Hand-off: plain stores -> barrier -> lane 0: agent release, drained, device-scope ticket;
-            // last arriver: agent acquire -> barrier -> plain loads.
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int t = atomicAdd(&w.grp_ticket[g], 1);
-                const int last = (t == Y - 1) ? 1 : 0;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    w.grp_ticket[g] = 0;          // next use is in a later kernel
-                }
-                sh_i[0] = last;
-            }
-            __syncthreads();
-            const int last = sh_i[0];
-            if (last && wv == 0) {
-                double mb = INFINITY; int mi = 0x7fffffff, mr = -1;
-                if (ok) {
-                    mb = w.part_d[k]; mi = w.part_i[k]; mr = w.part_r[k];
-                    for (int yy = 1; yy < Y; ++yy) {
-                        const double c2 = w.part_d[(size_t)yy * n + k]; const int i2 = w.part_i[(size_t)yy * n + k];
-                        if (c2 < mb || (c2 == mb && i2 < mi)) { mb = c2; mi = i2; mr = w.part_r[(size_t)yy * n + k]; }
-                    }
-                }
-                relax_close(M, w, st, Nx, n, k, ok, pk, dfree, mb, mi, mr);
-            }
-            __syncthreads();
-        }
     }
 }
 
 // ------------------------------------------------------------ wide: cert -----
 // pre_a: the match of row wave_gid, loaded with the state block in the kernel prologue.
 __device__ __forceinline__ void wide_cert(gfp M, const AsgWs& w, AsgState* st, int wave_gid,
-                          int n_waves, int pre_a, double* sh_d) {
-    const int n = st->n;
+                          int n_waves, int pre_a, double* sh_d, const int n) {
     const int lane = threadIdx.x & 63;
     double wmin = INFINITY, csum = 0.0; int bad = 0;
     for (int i = wave_gid; i < n; i += n_waves) {
@@ -901,14 +883,14 @@ __device__ void block_argmin(double v, int idx, double* out_v, int* out_i, doubl
 // ordered lists of free rows / free columns.  Returns the number of free rows (all threads).
 __device__ int ctrl_convert(const AsgWs& w, AsgState* st, int* sh) {
     const int n = st->n, tag = st->tag, rb = st->rb;
-    for (int k = threadIdx.x; k < n; k += CT) { w.owner[k] = -1; w.p[k] = ord2d(w.key[k]); }
+    for (int k = threadIdx.x; k < n; k += CT) { w.owner[k] = -1; w.p[k] = asg_price(w.key[k], rb + ASG_RND_BITS); }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += CT) {
         const int bc = w.bidcol[i];
         int ai = -1;
         if (((unsigned)bc >> 24) == (unsigned)tag) {
             const int j = bc & 0xffffff;
-            if (j < n && asg_row_of(ord2d(w.key[j]), rb) == i) ai = j;
+            if (j < n && asg_key_row(w.key[j], rb) == i) ai = j;
         }
         w.a[i] = ai;
         if (ai >= 0) w.owner[ai] = i;
@@ -1053,30 +1035,41 @@ __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds
     return total;
 }
 
-// ------------------------------------------------------------------- f1 ------
-// control step of an f1 launch: thread 0 of the last-arriving workgroup
-__device__ __forceinline__ void f1_ctrl(AsgState* st, int mode, int n) {
+// ----------------------------------------------------------------- step ------
+// control step of a launch: thread 0 of the last-arriving workgroup (MODE_CERT: the whole workgroup)
+__device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode, int n, int payload) {
+    if (mode == MODE_CERT) {
+        // the pass has filled minslack / total_cost: export the result to the caller's buffers
+        int* perm = st->out_perm;
+        for (int i = threadIdx.x; i < n; i += WT) perm[i] = w.a[i];
+        if (threadIdx.x == 0) {
+            asg_book(st, mode);
+            const double minslack = ord2d(asg_ld(&st->minslack_ord));
+            const double scale = fmax(fabs(st->cmax), fabs(st->cmin));
+            const double tol = 1e-10 * fmax(scale, 1e-30);
+            st->st_total_row_scans += n;
+            const int ok = (!asg_ld(&st->cert_bad)) && (minslack >= -tol);
+            st->certified = ok;
+            const double total = __longlong_as_double((long long)asg_ld(reinterpret_cast<unsigned long long*>(&st->total_cost)));
+            if (st->out_cert) *st->out_cert = ok;
+            if (st->out_cost) *st->out_cost = total;
+            int* stats = st->out_stats;
+            if (stats) {
+                stats[0] = st->st_auction_rounds; stats[1] = st->st_arr_rounds;
+                stats[2] = st->st_free_after_arr; stats[3] = st->st_sap_batches;
+                stats[4] = st->st_sap_row_scans; stats[5] = st->st_total_row_scans;
+                stats[6] = st->st_steps;
+                stats[7] = (st->phase & 0xff) | ((st->st_ms_phases & 0xff) << 8) | (st->st_dense_fallbacks << 16);
+            }
+            st->mode = MODE_DONE;
+        }
+        return;
+    }
+    if (threadIdx.x != 0) return;
     asg_book(st, mode);
-    if (mode == MODE_UMIN0) {
-        st->cmin = (double)ord2f(asg_ld(&st->cmin_bits));
-        st->cmax = (double)ord2f(asg_ld(&st->cmax_bits));
-        double cr = st->cmax - st->cmin;
-        if (!(cr > 0.0) || !(cr < INFINITY)) cr = 1.0;
-        st->eps = cr * st->eps;          // eps / eps_last hold the fractions on entry
-        st->eps_last = cr * st->eps_last;
-        // every phase but the last is cut earlier: it only has to shape the prices
-        const bool first_is_last = (st->eps / st->theta) < st->eps_last;
-        st->stop = (int)((first_is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
-        st->st_total_row_scans += n;
-        st->mode = MODE_INITRED;
-    } else if (mode == MODE_INITRED) {
-        st->st_total_row_scans += n;
-        st->round = 0; st->phase = 0; st->tag = 1;
-        st->mode = MODE_AUCTION;
-    } else if (mode == MODE_AUCTION || mode == MODE_ARR) {
-        // cnt = rows that were unmatched at the START of this round (they all bid in it)
-        const int cnt = asg_ld(&st->cnt);
-        asg_st(&st->cnt, 0);
+    if (mode == MODE_AUCTION || mode == MODE_ARR) {
+        // payload = rows that were unmatched at the START of this round (they all bid in it)
+        const int cnt = payload;
         st->st_total_row_scans += cnt;
         const int tag_next = (st->tag % 254) + 1;
         if (mode == MODE_AUCTION) {
@@ -1098,145 +1091,6 @@ __device__ __forceinline__ void f1_ctrl(AsgState* st, int mode, int n) {
             st->arr_round = ar;
             if (cnt == 0 || ar >= st->arr_cap) st->mode = MODE_CONVERT;
         }
-    } else if (mode == MODE_CONVERT) {
-        st->mode = asg_ld(&st->next_mode);
-    }
-}
-
-__global__ __launch_bounds__(WT) void asg_f1(AsgWs w, int n_host) {
-    extern __shared__ __attribute__((aligned(16))) char f1_lds[];   // prices | scratch of the other modes
-    double* p_lds = reinterpret_cast<double*>(f1_lds);
-    AsgState* st = w.st;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // consecutive work items go to different workgroups (different CUs)
-    const int wave_gid = wv * gridDim.x + blockIdx.x;
-    const int n_waves = gridDim.x * (WT / 64);
-    // Every launch starts cold: what a bid round needs first — the state block, all keys (they go to
-    // LDS as prices) and the last bid of the wave's row — is requested together.
-    const bool stage_p = (n_host <= WIDE_PLDS_MAX) && ((n_host & 3) == 0);
-    ulonglong2 kst0, kst1, kst2, kst3;     // WIDE_PLDS_MAX / (2 * WT) = 4 key pairs per thread
-    {
-        const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
-        const int nn = stage_p ? n_host : 0;
-        kst0 = *reinterpret_cast<const ulonglong2*>(w.key + (j0 < nn ? j0 : 0));
-        kst1 = *reinterpret_cast<const ulonglong2*>(w.key + (j1 < nn ? j1 : 0));
-        kst2 = *reinterpret_cast<const ulonglong2*>(w.key + (j2 < nn ? j2 : 0));
-        kst3 = *reinterpret_cast<const ulonglong2*>(w.key + (j3 < nn ? j3 : 0));
-    }
-    int pre_bc = (wave_gid < n_host) ? w.bidcol[wave_gid] : -1;
-    const int mode = st->mode;
-    gfp M = ASG_GLOBAL(st->Mptr);
-    asm volatile("" : "+v"(pre_bc), "+v"(kst0.x), "+v"(kst1.x), "+v"(kst2.x), "+v"(kst3.x) : "s"(mode) : "memory");   // all of it in flight
-    if (mode > MODE_CONVERT || st->error) return;
-    const int n = n_host;
-    // flags live behind the largest user of the dynamic region
-    int* sh_flag = reinterpret_cast<int*>(f1_lds + (stage_p ? (size_t)n * sizeof(double) : 0) + 8 * WT);
-    if (mode == MODE_AUCTION || mode == MODE_ARR) {
-        const double eps = st->eps; const int tag = st->tag, rb = st->rb;
-        if (threadIdx.x == 0) sh_flag[1] = 0;
-        if (stage_p) {
-            const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
-            if (j0 < n) *reinterpret_cast<double2*>(p_lds + j0) = make_double2(ord2d(kst0.x), ord2d(kst0.y));
-            if (j1 < n) *reinterpret_cast<double2*>(p_lds + j1) = make_double2(ord2d(kst1.x), ord2d(kst1.y));
-            if (j2 < n) *reinterpret_cast<double2*>(p_lds + j2) = make_double2(ord2d(kst2.x), ord2d(kst2.y));
-            if (j3 < n) *reinterpret_cast<double2*>(p_lds + j3) = make_double2(ord2d(kst3.x), ord2d(kst3.y));
-        }
-        __syncthreads();
-        const int nb = wide_bid(M, w, p_lds, wave_gid, n_waves, pre_bc, stage_p, n, eps, tag, rb);
-        if (lane == 0 && nb) atomicAdd(&sh_flag[1], nb);
-        __syncthreads();
-        if (threadIdx.x == 0 && sh_flag[1]) atomicAdd(&st->cnt, sh_flag[1]);
-    } else if (mode == MODE_UMIN0) {
-        wide_umin0(M, w, st, wave_gid, n_waves, n, reinterpret_cast<float*>(f1_lds));
-    } else if (mode == MODE_INITRED) {
-        wide_initred(M, w, reinterpret_cast<double*>(f1_lds), n, st->rb);
-    } else if (blockIdx.x == 0) {        // MODE_CONVERT
-        const int nF = ctrl_convert(w, st, reinterpret_cast<int*>(f1_lds));
-        if (threadIdx.x == 0) {
-            if (nF == 0) asg_enter_cert(st);
-            asg_st(&st->next_mode, nF == 0 ? MODE_CERT : MODE_UMIN);
-        }
-    }
-    if (asg_arrive_last(st, sh_flag) && threadIdx.x == 0) f1_ctrl(st, mode, n);
-}
-
-// ------------------------------------------------------------------- f2 ------
-__global__ __launch_bounds__(WT) void asg_f2(AsgWs w, int n_host) {
-    extern __shared__ __attribute__((aligned(16))) char f2_lds[];   // modes are exclusive
-    double* sh_d = reinterpret_cast<double*>(f2_lds);
-    int* sh_i = reinterpret_cast<int*>(f2_lds + sizeof(double) * WT);
-    int* sh_r = sh_i + WT;
-    __shared__ int sh[32];
-    __shared__ double shd[32];
-    __shared__ int shi[32];
-    AsgState* st = w.st;
-    const int wave_gid = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
-    const int n_waves = gridDim.x * (WT / 64);
-    int pre_a = (wave_gid < n_host) ? w.a[wave_gid] : 0;
-    const int mode = st->mode;
-    gfp M = ASG_GLOBAL(st->Mptr);
-    asm volatile("" : "+v"(pre_a) : "s"(mode) : "memory");
-    if (mode < MODE_UMIN || mode > MODE_CERT || st->error) return;
-    const int n = n_host;
-    if (mode == MODE_SAP) wide_relax(M, w, st, sh_d, sh_i, sh_r);
-    else if (mode == MODE_UMIN) wide_umin(M, w, st, wave_gid, n_waves, false);
-    else if (mode == MODE_COLRED) wide_colred(M, w, st, sh_d);
-    else if (mode == MODE_ROOTMIN) { wide_umin(M, w, st, wave_gid, n_waves, true); wide_ms_reset(w, n); }
-    else if (mode == MODE_CERT) wide_cert(M, w, st, wave_gid, n_waves, pre_a, sh_d);
-    else if (blockIdx.x == 0) {          // MODE_MS_FINISH
-        const bool use_lds = (n <= 6144);
-        ctrl_ms_finish(w, st, reinterpret_cast<int*>(f2_lds), reinterpret_cast<int*>(f2_lds) + n, use_lds, shd, shi, sh);
-        if (threadIdx.x == 0) {
-            const int nF = st->nF;
-            int nm = MODE_ROOTMIN;
-            if (st->error) nm = MODE_DONE;
-            else if (nF == 0) { asg_enter_cert(st); nm = MODE_CERT; }
-            else if (st->sparse && nF <= st->handoff) nm = MODE_BUILD;
-            asg_st(&st->next_mode, nm);
-        }
-    }
-    if (!asg_arrive_last(st, &sh[31])) return;
-    // ---- control step (last-arriving workgroup)
-    if (mode == MODE_CERT) {
-        // the pass has filled minslack / total_cost: export the result to the caller's buffers
-        const double minslack = ord2d(asg_ld(&st->minslack_ord));
-        const double scale = fmax(fabs(st->cmax), fabs(st->cmin));
-        const double tol = 1e-10 * fmax(scale, 1e-30);
-        int* perm = st->out_perm;
-        for (int i = threadIdx.x; i < n; i += WT) perm[i] = w.a[i];
-        if (threadIdx.x == 0) {
-            asg_book(st, mode);
-            st->st_total_row_scans += n;
-            const int ok = (!asg_ld(&st->cert_bad)) && (minslack >= -tol);
-            st->certified = ok;
-            const double total = __longlong_as_double((long long)asg_ld(reinterpret_cast<unsigned long long*>(&st->total_cost)));
-            if (st->out_cert) *st->out_cert = ok;
-            if (st->out_cost) *st->out_cost = total;
-            int* stats = st->out_stats;
-            if (stats) {
-                stats[0] = st->st_auction_rounds; stats[1] = st->st_arr_rounds;
-                stats[2] = st->st_free_after_arr; stats[3] = st->st_sap_batches;
-                stats[4] = st->st_sap_row_scans; stats[5] = st->st_total_row_scans;
-                stats[6] = st->st_steps;
-                stats[7] = (st->phase & 0xff) | ((st->st_ms_phases & 0xff) << 8) | (st->st_dense_fallbacks << 16);
-            }
-            st->mode = MODE_DONE;
-        }
-        return;
-    }
-    if (threadIdx.x != 0) return;
-    asg_book(st, mode);
-    if (mode == MODE_UMIN) {
-        st->st_total_row_scans += n;
-        st->mode = MODE_COLRED;
-    } else if (mode == MODE_COLRED) {
-        st->mode = (st->sparse && st->nF <= st->handoff) ? MODE_BUILD : MODE_ROOTMIN;
-    } else if (mode == MODE_ROOTMIN) {
-        st->nS = st->nF; asg_st(&st->nN, 0); st->dfree = INFINITY;
-        asg_st(&st->fr_min, ~0ull); asg_st(&st->fr_max, 0ull);
-        st->st_ms_phases++;
-        st->st_total_row_scans += st->nF;
-        st->mode = MODE_SAP;
     } else if (mode == MODE_SAP) {
         // New radius: one tree — the best free-column label (no label at or above it can matter);
         // several trees — the largest free-column label (infinite until every free column is
@@ -1250,9 +1104,131 @@ __global__ __launch_bounds__(WT) void asg_f2(AsgWs w, int n_host) {
         asg_st(&st->fr_min, ~0ull); asg_st(&st->fr_max, 0ull);
         st->cur ^= 1; st->nS = nN; asg_st(&st->nN, 0);
         if (nN == 0) st->mode = MODE_MS_FINISH;
-    } else if (mode == MODE_MS_FINISH) {
+    } else if (mode == MODE_UMIN0) {
+        st->cmin = (double)ord2f(asg_ld(&st->cmin_bits));
+        st->cmax = (double)ord2f(asg_ld(&st->cmax_bits));
+        double cr = st->cmax - st->cmin;
+        if (!(cr > 0.0) || !(cr < INFINITY)) cr = 1.0;
+        st->eps = cr * st->eps;          // eps / eps_last hold the fractions on entry
+        st->eps_last = cr * st->eps_last;
+        // every phase but the last is cut earlier: it only has to shape the prices
+        const bool first_is_last = (st->eps / st->theta) < st->eps_last;
+        st->stop = (int)((first_is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
+        st->st_total_row_scans += n;
+        st->mode = MODE_INITRED;
+    } else if (mode == MODE_INITRED) {
+        st->st_total_row_scans += n;
+        st->round = 0; st->phase = 0; st->tag = 1;
+        st->mode = MODE_AUCTION;
+    } else if (mode == MODE_CONVERT || mode == MODE_MS_FINISH) {
         st->mode = asg_ld(&st->next_mode);
+    } else if (mode == MODE_UMIN) {
+        st->st_total_row_scans += n;
+        st->mode = MODE_COLRED;
+    } else if (mode == MODE_COLRED) {
+        st->mode = (st->sparse && st->nF <= st->handoff) ? MODE_BUILD : MODE_ROOTMIN;
+    } else if (mode == MODE_ROOTMIN) {
+        st->nS = st->nF; asg_st(&st->nN, 0); st->dfree = INFINITY;
+        asg_st(&st->fr_min, ~0ull); asg_st(&st->fr_max, 0ull);
+        st->st_ms_phases++;
+        st->st_total_row_scans += st->nF;
+        st->mode = MODE_SAP;
     }
+}
+
+// ONE wide kernel for every chip-wide step (modes UMIN0 .. CERT): the host replays it without knowing
+// which step comes next.  LDS (modes are exclusive): bid rounds — prices [n] fp64 + owner rows [n]
+// int; relax — 16 KiB of merge buffers; MS_FINISH — 2 n ints for the path walks; the rest < 8 KiB.
+__global__ __launch_bounds__(WT) void asg_step(AsgWs w, int n_host) {
+    extern __shared__ __attribute__((aligned(16))) char step_lds[];
+    __shared__ int sh[32];
+    __shared__ double shd[32];
+    __shared__ int shi[32];
+    AsgState* st = w.st;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // consecutive work items go to different workgroups (different CUs)
+    const int wave_gid = wv * gridDim.x + blockIdx.x;
+    const int n_waves = gridDim.x * (WT / 64);
+    // Every launch starts cold: what a bid round needs first — the state block, all keys (they go to
+    // LDS as prices + owner rows) and the last bid of the wave's row — is requested together.
+    const bool stage_p = (n_host <= WIDE_PLDS_MAX);
+    ulonglong2 kst0, kst1, kst2, kst3;     // WIDE_PLDS_MAX / (2 * WT) = 4 key pairs per thread
+    {
+        const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
+        const int nn = stage_p ? n_host : 0;
+        kst0 = *reinterpret_cast<const ulonglong2*>(w.key + (j0 < nn ? j0 : 0));
+        kst1 = *reinterpret_cast<const ulonglong2*>(w.key + (j1 < nn ? j1 : 0));
+        kst2 = *reinterpret_cast<const ulonglong2*>(w.key + (j2 < nn ? j2 : 0));
+        kst3 = *reinterpret_cast<const ulonglong2*>(w.key + (j3 < nn ? j3 : 0));
+    }
+    int pre_bc = (wave_gid < n_host) ? w.bidcol[wave_gid] : -1;
+    const int mode = st->mode;
+    gfp M = ASG_GLOBAL(st->Mptr);
+    asm volatile("" : "+v"(pre_bc), "+v"(kst0.x), "+v"(kst1.x), "+v"(kst2.x), "+v"(kst3.x) : "s"(mode) : "memory");   // all of it in flight
+    if (mode > MODE_CERT || st->error) return;
+    const int n = n_host;
+    unsigned payload = 0;
+    if (mode == MODE_AUCTION || mode == MODE_ARR) {
+        double* p_lds = reinterpret_cast<double*>(step_lds);
+        int* r_lds = reinterpret_cast<int*>(step_lds + (size_t)((n + 1) & ~1) * sizeof(double));
+        const double eps = st->eps; const int tag = st->tag, rb = st->rb;
+        const int rnd = (mode == MODE_ARR) ? min(st->arr_round + 1, (1 << ASG_RND_BITS) - 1) : 0;
+        if (threadIdx.x == 0) sh[0] = 0;
+        if (stage_p) {
+            const int mb = rb + ASG_RND_BITS;
+            const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
+            // (a pair may straddle n when n is odd: the arrays are padded by one element)
+            if (j0 < n) { *reinterpret_cast<double2*>(p_lds + j0) = make_double2(asg_price(kst0.x, mb), asg_price(kst0.y, mb));
+                          *reinterpret_cast<int2*>(r_lds + j0) = make_int2(asg_key_row(kst0.x, rb), asg_key_row(kst0.y, rb)); }
+            if (j1 < n) { *reinterpret_cast<double2*>(p_lds + j1) = make_double2(asg_price(kst1.x, mb), asg_price(kst1.y, mb));
+                          *reinterpret_cast<int2*>(r_lds + j1) = make_int2(asg_key_row(kst1.x, rb), asg_key_row(kst1.y, rb)); }
+            if (j2 < n) { *reinterpret_cast<double2*>(p_lds + j2) = make_double2(asg_price(kst2.x, mb), asg_price(kst2.y, mb));
+                          *reinterpret_cast<int2*>(r_lds + j2) = make_int2(asg_key_row(kst2.x, rb), asg_key_row(kst2.y, rb)); }
+            if (j3 < n) { *reinterpret_cast<double2*>(p_lds + j3) = make_double2(asg_price(kst3.x, mb), asg_price(kst3.y, mb));
+                          *reinterpret_cast<int2*>(r_lds + j3) = make_int2(asg_key_row(kst3.x, rb), asg_key_row(kst3.y, rb)); }
+        }
+        __syncthreads();
+        const int nb = wide_bid(M, w, p_lds, r_lds, wave_gid, n_waves, pre_bc, stage_p, n, eps, tag, rb, rnd);
+        if (lane == 0 && nb) atomicAdd(&sh[0], nb);
+        __syncthreads();
+        payload = (unsigned)sh[0];
+    } else if (mode == MODE_SAP) {
+        double* sh_d = reinterpret_cast<double*>(step_lds);
+        int* sh_i = reinterpret_cast<int*>(step_lds + sizeof(double) * WT);
+        wide_relax(M, w, st, sh_d, sh_i, sh_i + WT, n);
+    } else if (mode == MODE_UMIN0) {
+        wide_umin0(M, w, st, wave_gid, n_waves, n, reinterpret_cast<float*>(step_lds));
+    } else if (mode == MODE_INITRED) {
+        wide_initred(M, w, reinterpret_cast<double*>(step_lds), n, st->rb);
+    } else if (mode == MODE_UMIN) {
+        wide_umin(M, w, st, wave_gid, n_waves, false, n);
+    } else if (mode == MODE_COLRED) {
+        wide_colred(M, w, st, reinterpret_cast<double*>(step_lds), n);
+    } else if (mode == MODE_ROOTMIN) {
+        wide_umin(M, w, st, wave_gid, n_waves, true, n); wide_ms_reset(w, n);
+    } else if (mode == MODE_CERT) {
+        wide_cert(M, w, st, wave_gid, n_waves, (wave_gid < n) ? w.a[wave_gid] : 0, reinterpret_cast<double*>(step_lds), n);
+    } else if (blockIdx.x == 0) {
+        if (mode == MODE_CONVERT) {
+            const int nF = ctrl_convert(w, st, sh);
+            if (threadIdx.x == 0) {
+                if (nF == 0) asg_enter_cert(st);
+                asg_st(&st->next_mode, nF == 0 ? MODE_CERT : MODE_UMIN);
+            }
+        } else {      // MODE_MS_FINISH
+            const bool use_lds = (n <= 6144);
+            ctrl_ms_finish(w, st, reinterpret_cast<int*>(step_lds), reinterpret_cast<int*>(step_lds) + n, use_lds, shd, shi, sh);
+            if (threadIdx.x == 0) {
+                const int nF = st->nF;
+                int nm = MODE_ROOTMIN;
+                if (st->error) nm = MODE_DONE;
+                else if (nF == 0) { asg_enter_cert(st); nm = MODE_CERT; }
+                else if (st->sparse && nF <= st->handoff) nm = MODE_BUILD;
+                asg_st(&st->next_mode, nm);
+            }
+        }
+    }
+    if (asg_arrive_last(st, &sh[30], payload)) step_ctrl(w, st, mode, n, sh[31]);
 }
 
 // ---------------------------------------------------------------- build ------
@@ -1264,7 +1240,7 @@ __global__ __launch_bounds__(SP_BUILD_WAVES * 64) void asg_build(AsgWs w, int n_
     gfp M = ASG_GLOBAL(st->Mptr);
     if (mode != MODE_BUILD || st->error) return;
     wide_build(M, w, st, build_lds);
-    if (asg_arrive_last(st, sh_flag) && threadIdx.x == 0) { asg_book(st, mode); st->mode = MODE_SOLVER; }
+    if (asg_arrive_last(st, sh_flag, 0u) && threadIdx.x == 0) { asg_book(st, mode); st->mode = MODE_SOLVER; }
 }
 
 // --------------------------------------------------------------- solver ------
@@ -1299,10 +1275,12 @@ __global__ void asg_trivial(const float* M, int n, int* perm, int* certified, do
 // host thread / workspace into hipGraphs and replayed (a solve is ~200 launches; with several
 // couplings in flight on different streams the host launch rate would be the limit).  Falls back
 // to plain launches when the stream cannot be captured (the legacy default stream) or CFM_ASG_GRAPH=0.
-enum { PRG_A8 = 0, PRG_C8 = 1, PRG_END = 2, PRG_BULK_A = 3, PRG_BULK_C = 4, PRG_COUNT = 5 };
+//   PRG_BULK   `bulk` x asg_step                                  (unpolled head of a solve)
+//   PRG_CHUNK  `chunk` x asg_step, asg_build, asg_solve, 2 x asg_step   (polled; progresses from any state)
+enum { PRG_CHUNK = 0, PRG_BULK = 1, PRG_COUNT = 2 };
 struct AsgGraph {
-    void* ws = nullptr; int n = 0, chunk = 0, bulk_a = 0, bulk_c = 0, blocks = 0, sparse = 0;
-    hipGraphExec_t exec[PRG_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* ws = nullptr; int n = 0, chunk = 0, bulk = 0, blocks = 0, sparse = 0;
+    hipGraphExec_t exec[PRG_COUNT] = {nullptr, nullptr};
     hipStream_t stream = nullptr; int disabled = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
@@ -1320,7 +1298,7 @@ static int asg_raise_lds() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     std::call_once(once[dev], [dev] {
-        hipError_t e1 = hipFuncSetAttribute((const void*)asg_f1, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipError_t e1 = hipFuncSetAttribute((const void*)asg_step, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
         hipError_t e2 = hipFuncSetAttribute((const void*)asg_build, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
         hipError_t e3 = hipFuncSetAttribute((const void*)asg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ok[dev] = (e1 == hipSuccess ? 1 : 0) | (e2 == hipSuccess && e3 == hipSuccess ? 2 : 0);
@@ -1334,26 +1312,18 @@ static int asg_raise_lds() {
 static thread_local int* g_pinned = nullptr;
 
 struct AsgLaunch {
-    AsgWs w; int n, blocks; size_t lds_f1, lds_f2, lds_build, lds_solve; int sparse; hipStream_t s;
-    void f1() const { hipLaunchKernelGGL(asg_f1, dim3(blocks), dim3(WT), lds_f1, s, w, n); }
-    void f2() const { hipLaunchKernelGGL(asg_f2, dim3(blocks), dim3(WT), lds_f2, s, w, n); }
-    void end() const {
+    AsgWs w; int n, blocks; size_t lds_step, lds_build, lds_solve; int sparse; hipStream_t s;
+    void step() const { hipLaunchKernelGGL(asg_step, dim3(blocks), dim3(WT), lds_step, s, w, n); }
+    void program(int prg, int chunk, int bulk) const {
+        if (prg == PRG_BULK) { for (int c = 0; c < bulk; ++c) step(); return; }
+        for (int c = 0; c < chunk; ++c) step();
         if (sparse) {
             hipLaunchKernelGGL(asg_build, dim3(blocks), dim3(SP_BUILD_WAVES * 64), lds_build, s, w, n);
             hipLaunchKernelGGL(asg_solve, dim3(1), dim3(SP_T), lds_solve, s, w, n);
+            step(); step();      // certificate + whatever the guess missed
         }
-        f2(); f2();
     }
-    void program(int prg, int chunk, int bulk_a, int bulk_c) const {
-        if (prg == PRG_A8) for (int c = 0; c < chunk; ++c) f1();
-        else if (prg == PRG_C8) for (int c = 0; c < chunk; ++c) f2();
-        else if (prg == PRG_END) end();
-        else if (prg == PRG_BULK_A) for (int c = 0; c < bulk_a; ++c) f1();
-        else if (prg == PRG_BULK_C) for (int c = 0; c < bulk_c; ++c) f2();
-    }
-    int count(int prg, int chunk, int bulk_a, int bulk_c) const {
-        return prg == PRG_A8 || prg == PRG_C8 ? chunk : prg == PRG_END ? (sparse ? 4 : 2) : prg == PRG_BULK_A ? bulk_a : bulk_c;
-    }
+    int count(int prg, int chunk, int bulk) const { return prg == PRG_BULK ? bulk : chunk + (sparse ? 4 : 0); }
 };
 
 static int asg_run(const float* M, int B, int* perm, int* certified, double* total_cost, int* stats,
@@ -1381,11 +1351,14 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     if (wide_blocks < 1) wide_blocks = 1;
     L.blocks = wide_blocks;
     const int raised = asg_raise_lds();
-    const bool stage_p = (n <= WIDE_PLDS_MAX) && ((n & 3) == 0);
-    L.lds_f1 = (stage_p ? (size_t)n * sizeof(double) : 0) + 8 * WT + 64;      // prices | 8 KiB scratch | flags
-    if (L.lds_f1 > 64 * 1024 && !(raised & 1)) return CFM_EINVAL;
-    L.lds_f2 = sizeof(double) * WT + 2 * sizeof(int) * WT;
-    if (n <= 6144 && (size_t)2 * n * sizeof(int) > L.lds_f2) L.lds_f2 = (size_t)2 * n * sizeof(int);   // path walks of MS_FINISH
+    L.lds_step = sizeof(double) * WT + 2 * sizeof(int) * WT;                      // relax merge buffers
+    if (n <= WIDE_PLDS_MAX) {                                                       // bid rounds: prices + owner rows
+        const size_t need = (size_t)((n + 1) & ~1) * sizeof(double) + (size_t)(n + 2) * sizeof(int);
+        if (need > L.lds_step) L.lds_step = need;
+    }
+    if (n <= 6144 && (size_t)2 * n * sizeof(int) > L.lds_step) L.lds_step = (size_t)2 * n * sizeof(int);   // path walks of MS_FINISH
+    L.lds_step = (L.lds_step + 15) & ~(size_t)15;
+    if (L.lds_step > 64 * 1024 && !(raised & 1)) return CFM_EINVAL;
     L.sparse = (use_sparse && n <= SP_NMAX && (raised & 2)) ? 1 : 0;
     L.lds_build = sp_build_lds_bytes(n); L.lds_solve = sp_solver_lds_bytes(n);
 
@@ -1405,21 +1378,20 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     int rc = cfm_status();
     if (rc) return rc;
 
-    const int chunk = P.chunk > 0 ? P.chunk : 8;
-    const bool blind = n >= 1024;
-    const int bulk_a = blind ? P.bulk_a : 0, bulk_c = blind ? P.bulk_c : 0;
+    const int chunk = P.chunk > 0 ? P.chunk : 10;
+    const int bulk = (n >= 1024) ? P.bulk : 0;
     AsgGraph& G = g_graph;
     bool use_graph = asg_graph_enabled() && !G.disabled && n >= 256;
-    if (use_graph && !(G.exec[0] && G.ws == ws && G.n == n && G.chunk == chunk && G.bulk_a == bulk_a &&
-                       G.bulk_c == bulk_c && G.blocks == wide_blocks && G.sparse == L.sparse && G.stream == s)) {
+    if (use_graph && !(G.exec[0] && G.ws == ws && G.n == n && G.chunk == chunk && G.bulk == bulk &&
+                       G.blocks == wide_blocks && G.sparse == L.sparse && G.stream == s)) {
         for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
         hipError_t e = hipSuccess;
         for (int prg = 0; prg < PRG_COUNT && e == hipSuccess; ++prg) {
-            if (L.count(prg, chunk, bulk_a, bulk_c) == 0) continue;
+            if (L.count(prg, chunk, bulk) == 0) continue;
             hipGraph_t graph = nullptr;
             e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (e != hipSuccess) break;
-            L.program(prg, chunk, bulk_a, bulk_c);
+            L.program(prg, chunk, bulk);
             e = hipStreamEndCapture(s, &graph);
             if (e == hipSuccess && graph) e = hipGraphInstantiate(&G.exec[prg], graph, nullptr, nullptr, 0);
             if (graph) (void)hipGraphDestroy(graph);
@@ -1431,7 +1403,7 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
             for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
             G.disabled = 1; use_graph = false;     // e.g. the legacy default stream
         } else {
-            G.ws = ws; G.n = n; G.chunk = chunk; G.bulk_a = bulk_a; G.bulk_c = bulk_c; G.blocks = wide_blocks;
+            G.ws = ws; G.n = n; G.chunk = chunk; G.bulk = bulk; G.blocks = wide_blocks;
             G.sparse = L.sparse; G.stream = s;
         }
     }
@@ -1440,22 +1412,21 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
 
     long launched = 0;
     auto run = [&](int prg) -> int {
-        const int cnt = L.count(prg, chunk, bulk_a, bulk_c);
+        const int cnt = L.count(prg, chunk, bulk);
         if (cnt == 0) return 0;
         launched += cnt;
         if (use_graph) return cfm_hip(hipGraphLaunch(G.exec[prg], s));
-        L.program(prg, chunk, bulk_a, bulk_c);
+        L.program(prg, chunk, bulk);
         return cfm_status();
     };
-    // The bulk goes out unpolled (a solve at n = 4096 takes ~100 f1 and ~75 f2 launches); the rest in
-    // chunks chosen from the last polled mode, each followed by a 64-byte copy of the state into its
-    // own pinned slot and an event, with the NEXT chunk already queued when the host waits for a
-    // slot: no idle gap.  A wrong guess costs a few no-op launches, never correctness.
-    rc = run(PRG_BULK_A); if (rc) return rc;
-    rc = run(PRG_BULK_C); if (rc) return rc;
-    int guess = blind ? PRG_C8 : PRG_A8, cur = 0;
+    // The head goes out unpolled (a solve at n = 4096 takes ~180 steps before the list solver); the rest
+    // in chunks that make progress from any state, each followed by a 64-byte copy of the state into
+    // its own pinned slot and an event, with the NEXT chunk already queued when the host waits for a
+    // slot: no idle gap.  A kernel that does not own the current mode is a ~2 us no-op.
+    rc = run(PRG_BULK); if (rc) return rc;
+    int cur = 0;
     auto issue = [&](int slot) -> int {
-        int r2 = run(guess); if (r2) return r2;
+        int r2 = run(PRG_CHUNK); if (r2) return r2;
         r2 = cfm_hip(hipMemcpyAsync(g_pinned + 16 * slot, L.w.st, 64, hipMemcpyDeviceToHost, s)); if (r2) return r2;
         return cfm_hip(hipEventRecord(G.ev[slot], s));
     };
@@ -1468,7 +1439,6 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
         if (err) return CFM_ENOCONV;
         if (mode == MODE_DONE) { if (cert_out) *cert_out = hs[3]; break; }
         if (launched >= P.max_launches) return CFM_ETIMEOUT;
-        guess = (mode <= MODE_CONVERT) ? PRG_A8 : (mode == MODE_BUILD || mode == MODE_SOLVER) ? PRG_END : PRG_C8;
         cur ^= 1;
     }
     // the look-ahead chunk is still in flight: it is a string of no-ops on a finished state, but the

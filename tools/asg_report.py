@@ -115,15 +115,21 @@ def main():
     with torch.cuda.stream(torch.cuda.Stream()):
         timing(dev, a.seeds, label="default")
         if a.sweep:
-            for ba, bc in ((96, 64), (112, 80), (88, 56)):
-                lib.cfm_assign_set_bulk(ba, bc); timing(dev, 1, label=f"bulk {ba}/{bc}")
-            lib.cfm_assign_set_bulk(104, 72)
-            for h in (4, 10, 16):
+            for b in (128, 192, 0):
+                lib.cfm_assign_set_bulk(b, 0); timing(dev, 1, label=f"bulk {b}")
+            lib.cfm_assign_set_bulk(160, 0)
+            for c in (6, 16):
+                lib.cfm_assign_set_params(0, 0, 0, -1, 0, -1, c); timing(dev, 1, label=f"chunk {c}")
+            lib.cfm_assign_set_params(0, 0, 0, -1, 0, -1, 10)
+            for h in (4, 10):
                 lib.cfm_assign_set_handoff(h); timing(dev, 1, label=f"handoff {h}")
             lib.cfm_assign_set_handoff(6)
             for th in (4.0, 7.0):
                 lib.cfm_assign_set_params(th, 0, 0, -1, 0, -1, 0); timing(dev, 1, label=f"theta {th}")
             lib.cfm_assign_set_params(5.0, 0, 0, -1, 0, -1, 0)
+            for ac in (10, 25):
+                lib.cfm_assign_set_params(0, 0, 0, -1, 0, ac, 0); timing(dev, 1, label=f"arr_cap {ac}")
+            lib.cfm_assign_set_params(0, 0, 0, -1, 0, 15, 0)
             lib.cfm_assign_set_mode(0); timing(dev, 1, label="dense only (no list solver)"); lib.cfm_assign_set_mode(1)
         timing(dev, 1, B=8192, d=50, label="B=8192 d=50")
         timing(dev, 1, B=1024, d=784, label="B=1024")
