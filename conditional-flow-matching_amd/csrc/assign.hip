@@ -257,6 +257,15 @@ static inline AsgWs asg_carve(void* ws, int n) {
 
 extern "C" size_t cfm_asg_ws_bytes_internal(int n) { return asg_ws_bytes(n); }
 
+// Tuning aid (library built with -DSP_PROFILE only): the solver's cycle counters of the last solve on
+// `ws` — [0..4] init / fast batches / collect / a-posteriori test / augmentation, [5] dense batches,
+// [6] fast batches run, [7] batches, [9..14] stages of a fast batch, [15] pending-list entries seen.
+extern "C" int cfm_assign_debug_solver(const void* ws, int n, long long* out16) {
+    if (!ws || !out16 || n < 2) return CFM_EINVAL;
+    AsgWs w = asg_carve(const_cast<void*>(ws), n);
+    return cfm_hip(hipMemcpy(out16, w.part_d, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+}
+
 // The cost matrix pointer comes out of the state block, so the compiler cannot prove it global and
 // would emit FLAT loads (which also count on the LDS counter and stall the LDS price reads of a bid):
 // the kernels cast it to the global address space once.

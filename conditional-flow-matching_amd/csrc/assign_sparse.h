@@ -904,7 +904,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
     }
 #ifdef SP_PROFILE
     if (tid == 0) {
-        long long* out = reinterpret_cast<long long*>(reinterpret_cast<char*>(st) + 256);
+        long long* out = reinterpret_cast<long long*>(w.part_d);     // (scratch of the former split relax rounds)
         for (int q = 0; q < 5; ++q) out[q] = dbg[q];
         out[5] = dbg[5]; out[6] = nfast; out[7] = batches; out[8] = L.ri[126]; for (int q = 0; q < 6; ++q) out[9 + q] = fbv[q]; out[15] = L.ri[125];
     }
