@@ -177,6 +177,7 @@ struct SList {
 
 struct AsgWs {
     AsgState* st;
+    unsigned long long* arrive_sub;   // 16 first-level arrival words, one per 128-byte line
     double* p;        // prices (= -v), phase C on
     double* bidval;   // u_i (row minima)
     double* dist;     // SAP labels
@@ -222,12 +223,13 @@ __device__ __forceinline__ SList slist(const AsgWs& w, int c) {
 static inline size_t asg_ws_bytes(int n) {
     size_t N = ((size_t)n + 3) & ~(size_t)3;     // every array starts 16-byte aligned
     size_t lists = (n <= 4096) ? N * 64 * 8 + 8 * N : 0;
-    return 512 + 8 * N * (4 + 4) + 4 * N * (10 + 6) + 64 + 16 + 16 * N * MS_YMAX + lists + 256;
+    return 512 + 2048 + 8 * N * (4 + 4) + 4 * N * (10 + 6) + 64 + 16 + 16 * N * MS_YMAX + lists + 256;
 }
 
 static inline AsgWs asg_carve(void* ws, int n) {
     AsgWs w; char* q = (char*)ws; size_t N = ((size_t)n + 3) & ~(size_t)3;
     w.st = (AsgState*)q; q += 512;
+    w.arrive_sub = (unsigned long long*)q; q += 2048;
     w.p = (double*)q; q += 8 * N;
     w.bidval = (double*)q; q += 8 * N;
     w.dist = (double*)q; q += 8 * N;
@@ -296,20 +298,34 @@ __device__ __forceinline__ void asg_st(int* p, int v) { __hip_atomic_store(p, v,
 __device__ __forceinline__ void asg_st(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, ASG_AGENT); }
 
 // Every workgroup of a launch calls this once, after its share of the step: returns true (in all
-// its threads) in the workgroup that arrives last.  Each wave first waits until its own stores and
-// atomics have been performed, so everything the others contributed through device-scope atomics
-// is complete when the last ticket is drawn.  The arrival word also carries a payload (the
-// workgroup's bidders in a bid round): ONE device-scope round trip per workgroup, and the last
-// arriver gets the sum with its ticket (sh_flag[1]).
-__device__ __forceinline__ bool asg_arrive_last(AsgState* st, int* sh_flag, unsigned payload) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// its threads) in the workgroup that arrives last.  `wait`: the step published results through
+// device-scope atomics that the control step reads — every wave then first waits until its own
+// atomics have been performed, so they are complete when the last ticket is drawn.  (Bid rounds
+// need no wait: their atomics are read by the next launch, and the bidder count travels in the
+// arrival word itself.)  Arrivals on ONE device-scope word serialise at ~11 ns each (3 us for 256
+// workgroups, measured): the arrival is two-level, 16 first-level words in separate cache lines
+// (blockIdx % 16), whose last arrivers forward the group's payload sum to the top word.
+#define ASG_ARRIVE_GROUPS 16
+__device__ __forceinline__ bool asg_arrive_last(AsgState* st, unsigned long long* sub, int* sh_flag,
+                                                unsigned payload, bool wait) {
+    if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long t = __hip_atomic_fetch_add(&st->arrive, (1ull << 32) | (unsigned long long)payload,
+        const unsigned G = gridDim.x < ASG_ARRIVE_GROUPS ? gridDim.x : ASG_ARRIVE_GROUPS;
+        const unsigned g = blockIdx.x % G;
+        const unsigned gsize = (gridDim.x - g + G - 1) / G;        // workgroups with blockIdx % G == g
+        unsigned long long* c = sub + 16 * g;
+        const unsigned long long t = __hip_atomic_fetch_add(c, (1ull << 32) | (unsigned long long)payload,
                                                             __ATOMIC_RELAXED, ASG_AGENT);
-        const int last = ((unsigned)(t >> 32) == gridDim.x - 1u) ? 1 : 0;
-        if (last) asg_st(&st->arrive, 0ull);
-        sh_flag[0] = last; sh_flag[1] = (int)((unsigned)t + payload);
+        int last = 0; unsigned total = 0;
+        if ((unsigned)(t >> 32) == gsize - 1u) {
+            asg_st(c, 0ull);
+            const unsigned gp = (unsigned)t + payload;
+            const unsigned long long t2 = __hip_atomic_fetch_add(&st->arrive, (1ull << 32) | (unsigned long long)gp,
+                                                                 __ATOMIC_RELAXED, ASG_AGENT);
+            if ((unsigned)(t2 >> 32) == G - 1u) { last = 1; asg_st(&st->arrive, 0ull); total = (unsigned)t2 + gp; }
+        }
+        sh_flag[0] = last; sh_flag[1] = (int)total;
     }
     __syncthreads();
     return sh_flag[0] != 0;
@@ -688,25 +704,23 @@ __device__ __forceinline__ void wide_colred(gfp M, const AsgWs& w, const AsgStat
 // Close a column group's round (wave 0, lane <-> column k): take the merged minimum, append an
 // improved assigned column to the NEXT list, and contribute the labels of the group's free columns
 // to the round's radius words (ordered min / max, one pair of atomics per group).
-__device__ __forceinline__ void relax_close(gfp M, const AsgWs& w, AsgState* st,
-                                            const SList& L, const SList& Nx, int n, int k, bool ok, double pk,
-                                            double dfree, double best, int bi, int bt) {
-    double dk = INFINITY; int ow = 0;
-    if (ok) { dk = w.dist[k]; ow = w.owner[k]; }
+__device__ __forceinline__ void relax_close(const AsgWs& w, AsgState* st, const SList& L, const SList& Nx,
+                                            int k, bool ok, double dfree, double best, int bi, int bt,
+                                            double dk, int ow, double rjk) {
+    // dk / ow / rjk (label, owner, owner's matched-edge value of column k) were requested at the start of
+    // the group, so the close is: compare, store, one append atomic, the entry
     if (ok && best < dk) {
         w.dist[k] = best; w.pred[k] = bi; dk = best;
         if (ow >= 0 && best < dfree) {
             const int idx = atomicAdd(&st->nN, 1);
             Nx.col[idx] = k; Nx.row[idx] = ow; Nx.base[idx] = best; Nx.root[idx] = L.root[bt];   // the winner's tree
-            Nx.rj[idx] = (double)M[(size_t)ow * n + k] + pk;
+            Nx.rj[idx] = rjk;
         }
     }
     const bool fr = ok && ow < 0;
     const double mx = wave_max_d(fr ? dk : -INFINITY), mn = wave_min_d(fr ? dk : INFINITY);
-    if ((threadIdx.x & 63) == 0 && mn < INFINITY) {       // mn < inf <=> the group has a free column with a finite label ...
-        atomicMin(&st->fr_min, d2ord(mn));
-    }
-    if ((threadIdx.x & 63) == 0 && mx > -INFINITY) atomicMax(&st->fr_max, d2ord(mx));   // ... inf labels count for the max
+    if ((threadIdx.x & 63) == 0 && mn < INFINITY) atomicMin(&st->fr_min, d2ord(mn));      // a free column with a finite label
+    if ((threadIdx.x & 63) == 0 && mx > -INFINITY) atomicMax(&st->fr_max, d2ord(mx));     // infinite labels count for the max
 }
 
 // Relax every listed row.  A workgroup owns 16 columns; a wave covers 4 list entries x 16 columns per
@@ -729,6 +743,9 @@ __device__ __forceinline__ void wide_relax(gfp M, const AsgWs& w, AsgState* st,
         const int k = g * 16 + cl;
         const bool ok = k < n;
         const double pk = ok ? w.p[k] : 0.0;
+        // what the close of the column needs, requested now (wave 0 only uses it)
+        double dk0 = INFINITY; int ow0 = 0;
+        if (wv == 0 && sub == 0 && ok) { dk0 = w.dist[k]; ow0 = w.owner[k]; }
         double best = INFINITY; int bi = 0x7fffffff, br = 0;     // br: list index of the best entry (its tree is looked up at the end)
         for (int t0 = wv * (4 * Q); t0 < nS; t0 += NW * 4 * Q) {
             int ri[Q]; double bs[Q], rj[Q]; float c[Q];
@@ -764,6 +781,8 @@ __device__ __forceinline__ void wide_relax(gfp M, const AsgWs& w, AsgState* st,
             if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = r2; }
         }
         if (sub == 0) { sh_d[wv * 16 + cl] = best; sh_i[wv * 16 + cl] = bi; sh_r[wv * 16 + cl] = br; }
+        double rjk = 0.0;
+        if (wv == 0 && sub == 0 && ok && ow0 >= 0) rjk = (double)M[(size_t)ow0 * n + k] + pk;    // in flight across the barrier
         __syncthreads();
         if (wv == 0) {
             const bool okc = ok && sub == 0;
@@ -780,7 +799,7 @@ __device__ __forceinline__ void wide_relax(gfp M, const AsgWs& w, AsgState* st,
                 const double c2 = __shfl_xor(best, o, 64); const int i2 = __shfl_xor(bi, o, 64), r2 = __shfl_xor(br, o, 64);
                 if (c2 < best || (c2 == best && i2 < bi)) { best = c2; bi = i2; br = r2; }
             }
-            relax_close(M, w, st, L, Nx, n, k, okc, pk, dfree, best, bi, br);
+            relax_close(w, st, L, Nx, k, okc, dfree, best, bi, br, dk0, ow0, rjk);
         }
         __syncthreads();
     }
@@ -1237,7 +1256,8 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w, int n_host) {
             }
         }
     }
-    if (asg_arrive_last(st, &sh[30], payload)) step_ctrl(w, st, mode, n, sh[31]);
+    const bool wait = (mode == MODE_SAP || mode == MODE_UMIN0 || mode == MODE_CERT || mode == MODE_CONVERT || mode == MODE_MS_FINISH);
+    if (asg_arrive_last(st, w.arrive_sub, &sh[30], payload, wait)) step_ctrl(w, st, mode, n, sh[31]);
 }
 
 // ---------------------------------------------------------------- build ------
@@ -1249,7 +1269,7 @@ __global__ __launch_bounds__(SP_BUILD_WAVES * 64) void asg_build(AsgWs w, int n_
     gfp M = ASG_GLOBAL(st->Mptr);
     if (mode != MODE_BUILD || st->error) return;
     wide_build(M, w, st, build_lds);
-    if (asg_arrive_last(st, sh_flag, 0u) && threadIdx.x == 0) { asg_book(st, mode); st->mode = MODE_SOLVER; }
+    if (asg_arrive_last(st, w.arrive_sub, sh_flag, 0u, false) && threadIdx.x == 0) { asg_book(st, mode); st->mode = MODE_SOLVER; }
 }
 
 // --------------------------------------------------------------- solver ------
@@ -1268,6 +1288,7 @@ __global__ void asg_init(AsgWs w, AsgState h) {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&h);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(w.st);
     for (int q = threadIdx.x; q < (int)(sizeof(AsgState) / 8); q += blockDim.x) dst[q] = src[q];
+    for (int q = threadIdx.x; q < 2048 / 8; q += blockDim.x) w.arrive_sub[q] = 0ull;
 }
 
 __global__ void asg_trivial(const float* M, int n, int* perm, int* certified, double* total_cost,

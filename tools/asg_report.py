@@ -121,7 +121,7 @@ def main():
             for c in (6, 16):
                 lib.cfm_assign_set_params(0, 0, 0, -1, 0, -1, c); timing(dev, 1, label=f"chunk {c}")
             lib.cfm_assign_set_params(0, 0, 0, -1, 0, -1, 10)
-            for h in (4, 10):
+            for h in (2, 4, 10):
                 lib.cfm_assign_set_handoff(h); timing(dev, 1, label=f"handoff {h}")
             lib.cfm_assign_set_handoff(6)
             for th in (4.0, 7.0):
