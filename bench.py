@@ -9,17 +9,22 @@ One "step" = one pass of the hot path over one synthetic minibatch already resid
     -> MLP(785-512-512-512-784) forward, MSE loss, backward, Adam step           (PyTorch-ROCm)
 Schedule (--pipeline N, default 3): the coupling depends only on the data, so the couplings of
 the next N batches are computed on side streams (background threads, cfm_amd.prefetch) while the
-model steps on batch k, like data-loader workers; the exact-assignment solver is a chain of small
-latency-bound kernels, so a second coupling in flight fills the CUs the first leaves idle.  The
-pipeline starts empty inside the timed region and is drained inside it: K timed steps contain
-exactly K couplings and K model updates.  Host RNG draws stay on the main thread, in order.
---pipeline 0 runs everything strictly one after the other.
+model steps on batch k, like data-loader workers.  The pipeline starts empty inside the timed
+region and is drained inside it: K timed steps contain exactly K couplings and K model updates.
+Host RNG draws stay on the main thread, in order.  `value` is that schedule; `value_sequential`
+is the same K steps strictly one after the other (what an unmodified training script gets).
 N > 1: one process per GPU (torchrun), every rank couples its own minibatch (no collective in
-the OT path), the model is data parallel (gradient all-reduce over RCCL), weak scaling.
-Rank 0 prints ONE JSON line.
+the OT path), the model is data parallel (gradient all-reduce over RCCL), and the final x_t of the
+timed region is all-gathered once (the north star's "all-gather of the final samples"), inside
+the timed region; weak scaling.  Rank 0 prints ONE JSON line.
+
+Also in the line (rank 0, N = 1): `roofline` of the dominant kernel (asg_step, per solve, from an
+un-overlapped leg), `c2` / `c5` (BASELINE configs[1] / configs[4]: Sinkhorn iterations/s and, for
+C5, the dopri5 sampling time), `c1_solve_ms` (exact-OT latency at B = 256) and `cpu_baseline`.
 """
 import argparse
 import collections
+import ctypes
 import json
 import os
 import sys
@@ -33,7 +38,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md)
+F32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32-input MFMA peak
 
 
 def synth_batches(B, d, n, seed, dev):
@@ -49,53 +55,208 @@ def synth_batches(B, d, n, seed, dev):
     return out
 
 
-def sinkhorn_leg(dev, iters=200):
-    """Sinkhorn iterations/s on config C2 (8gaussians -> moons, B=4096, d=2, eps=0.05)."""
+# --------------------------------------------------------------------------- the timed loop
+def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, depth=0):
+    """`count` steps starting at pool index `first`: every step = one coupling + one model update,
+    all of them inside this call (a prefetch pipeline starts empty and is drained).  Returns the
+    last (t, xt, ut).  Device agnostic: `couple(x0, x1, drawn)` and `model_step(t, xt, ut)` are the
+    caller's; the CPU multi-process test drives this with CPU stand-ins."""
+    last = None
+    if not depth or prefetcher is None:
+        for k in range(count):
+            x0, x1 = pool[(first + k) % len(pool)]
+            last = couple(x0, x1, draw())
+            model_step(*last)
+        return last
+    inflight, submitted = collections.deque(), 0
+    while submitted < min(depth, count):
+        inflight.append(prefetcher.submit(*pool[(first + submitted) % len(pool)], hook=couple, draw=draw)); submitted += 1
+    for k in range(count):
+        last = inflight.popleft().result()
+        if submitted < count:
+            inflight.append(prefetcher.submit(*pool[(first + submitted) % len(pool)], hook=couple, draw=draw)); submitted += 1
+        model_step(*last)
+    return last
+
+
+def timed_region(D, sync, pool, warmup, steps, couple, model_step, draw, prefetcher, depth, device=None):
+    """Warm-up, barrier + sync, K steps + ONE all-gather of the final samples, sync + barrier; the
+    MAX over ranks of the elapsed time.  Returns (elapsed_s, gathered_final_xt)."""
+    run_steps(pool, 0, warmup, couple, model_step, draw, prefetcher, depth)
+    D.barrier(); sync()
+    t0 = time.perf_counter()
+    last = run_steps(pool, warmup, steps, couple, model_step, draw, prefetcher, depth)
+    gathered = D.all_gather_samples(last[1]) if last is not None else None
+    sync(); D.barrier()
+    return D.max_over_ranks(time.perf_counter() - t0, device), gathered
+
+
+# --------------------------------------------------------------------------- side legs (rank 0, N = 1)
+def sinkhorn_leg(dev, cfg, reg, iters=200):
+    """Sinkhorn iterations/s (one iteration = one g-update + one f-update = two LSE passes over M)."""
     import cfm_amd.optimal_transport as ot
     import cfm_oracle as oracle
-    x0, x1 = oracle.config_inputs("C2")
+    x0, x1 = oracle.config_inputs(cfg)
     M = ot.cost_matrix(x0.to(dev), x1.to(dev))
-    ot.sinkhorn_log(M, 0.05, max_iter=20, stop_thr=0.0)
+    ot.sinkhorn_log(M, reg, max_iter=20, stop_thr=0.0)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ot.sinkhorn_log(M, 0.05, max_iter=iters, stop_thr=0.0)
+    ot.sinkhorn_log(M, reg, max_iter=iters, stop_thr=0.0)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    B = M.shape[0]
-    per_iter_bytes = 2 * 4 * B * B + 16 * B
+    B0, B1 = M.shape
+    per_iter_bytes = 2 * 4 * B0 * B1 + 16 * B0
     gbs = per_iter_bytes * iters / (ms * 1e-3) / 1e9
-    return {"iters_per_s": iters / (ms * 1e-3), "ms_per_iter": ms / iters,
+    note = ("2 LSE passes over the fp32 cost matrix per iteration; the %d MiB matrix is %s" %
+            (4 * B0 * B1 >> 20, "Infinity-Cache resident (256 MiB)" if 4 * B0 * B1 <= (200 << 20) else "HBM streamed"))
+    return {"config": f"{cfg}: B={B0}, d={x0.shape[1]}, eps={reg}", "sinkhorn_iters_per_s": iters / (ms * 1e-3),
+            "ms_per_iter": ms / iters,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                         "note": "2 passes over the 64 MiB cost matrix per iteration (Infinity-Cache resident)"}}
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_iter": per_iter_bytes, "note": note}}
 
 
-def cpu_baseline(B, d, max_seconds=30.0):
-    """Oracle restatement of the reference CPU path (OTPlanSampler('exact').sample_plan +
-    sample_location_and_conditional_flow) timed on this box's host cores, bounded sample."""
+def c5_ode_leg(dev):
+    """C5 sampling: dopri5 (atol = rtol = 1e-4, t_span = linspace(0, 1, 100)) through the 51-64-64-64-50
+    SELU MLP field on B = 8192 points (single-cell_example.ipynb cells 5-9 shape)."""
+    import cfm_amd
+    import cfm_oracle as oracle
+    from cfm_amd.ode import NeuralODE
+    from cfm_amd.utils import torch_wrapper
+    x0, _ = oracle.config_inputs("C5")
+    torch.manual_seed(0)
+    model = cfm_amd.MLP(dim=50, time_varying=True, w=64).to(dev)
+    node = NeuralODE(torch_wrapper(model), solver="dopri5", sensitivity="adjoint", atol=1e-4, rtol=1e-4)
+    ts = torch.linspace(0, 1, 100)
+    x = x0.to(dev)
+    node.trajectory(x, ts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        node.trajectory(x, ts)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    flops = node.nfe * 2 * x.shape[0] * (51 * 64 + 64 * 64 + 64 * 64 + 64 * 50)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"dopri5_ms": ms, "nfe": int(node.nfe), "step_attempts": int(node.n_steps),
+            "roofline_ode": {"bound": "mfma", "achieved": tf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / F32_PEAK_TFLOPS,
+                             "note": "nfe x MLP flops / wall; a chain of dependent 64-wide layer products "
+                                     "(latency bound, not MFMA-throughput bound)"}}
+
+
+def c1_latency(dev, reps=20):
+    """Exact-OT coupling latency at the reference's tutorial size (B = 256, d = 2; BASELINE configs[0])."""
+    import cfm_amd.optimal_transport as ot
+    import cfm_oracle as oracle
+    x0, x1 = oracle.config_inputs("C1")
+    a, b = x0.to(dev), x1.to(dev)
+    samp = ot.OTPlanSampler(method="exact")
+    for _ in range(3):
+        samp.sample_plan(a, b)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); samp.sample_plan(a, b); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    M = ot.cost_matrix(a, b, matrix_cores=False)
+    tsolve = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); ot.assign_exact(M); tsolve.append(time.perf_counter() - t0)
+    return {"sample_plan_ms": float(np.median(ts) * 1e3), "solve_ms": float(np.median(tsolve) * 1e3)}
+
+
+def cpu_baseline(B, d, budget_s=25.0):
+    """The reference's CPU step restated by the oracle — OTPlanSampler('exact').sample_plan +
+    sample_location_and_conditional_flow (optimal_transport.py:63-145, conditional_flow_matching.py:159-199)
+    — timed on this box's host cores with a per-stage breakdown: torch.cdist ** 2, the exact solve
+    (SciPy LSAP in float64: the stand-in for POT's network simplex, which is not installable here; it is
+    single threaded whatever num_threads says, and an UPPER bound on POT's time), the reference's own
+    O(B^2) sample_map (dense float64 plan, flatten, / sum, np.random.choice) and the eager gather + x_t / u_t."""
     import cfm_oracle as oracle
     x0, x1 = oracle.config_inputs("C3", B=B)
     torch.manual_seed(0); np.random.seed(0)
-    times = []
+    threads_max = torch.get_num_threads()
+
+    def one(nthreads):
+        torch.set_num_threads(nthreads)
+        t = [time.perf_counter()]
+        M = oracle.ref_cost_f32(x0, x1); t.append(time.perf_counter())
+        perm = oracle.exact_perm(M); t.append(time.perf_counter())
+        pi = oracle.perm_plan(perm)                               # pot.emd returns the dense plan
+        i, j = oracle.sample_map_reference(pi, B); t.append(time.perf_counter())
+        a0, a1 = x0[i], x1[j]
+        tt = torch.rand(B).type_as(x0); eps = torch.randn_like(a0)
+        oracle.xt_ut("icfm", a0, a1, tt, eps, 0.0); t.append(time.perf_counter())
+        return np.diff(t)
+
     t_start = time.perf_counter()
-    while len(times) < 2 and (time.perf_counter() - t_start) < max_seconds:
-        t0 = time.perf_counter()
-        oracle.ot_cfm_step(x0, x1, sigma=0.0)
-        times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": B / best, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"{len(times)} step(s) of B={B}, d={d}: torch.cdist**2 + SciPy LSAP (stand-in for "
-                      f"POT emd, single thread) + flattened-cdf sampling + eager xt/ut; best {best:.2f} s/step; "
-                      f"host has {os.cpu_count()} cores, torch intra-op threads {torch.get_num_threads()}"}
+    one(threads_max)                                              # warm-up
+    per = (time.perf_counter() - t_start)
+    nrun = int(max(1, min(5, (budget_s - per) // max(per, 1e-3) - 1)))
+    runs = np.array([one(threads_max) for _ in range(nrun)])
+    run1 = one(1)                                                 # torch intra-op threads = 1 (reference default for emd)
+    torch.set_num_threads(threads_max)
+    med = np.median(runs, axis=0)
+    total = float(med.sum())
+    return {"value": B / total, "unit": "samples/s", "cores": 1, "kind": "port",
+            "s_per_step_median": total, "s_per_step_min": float(runs.sum(1).min()), "runs": int(nrun),
+            "breakdown_s": {"cdist2": float(med[0]), "exact_solve_scipy_lsap": float(med[1]),
+                            "sample_map_dense_choice": float(med[2]), "gather_xt_ut": float(med[3])},
+            "s_per_step_torch_threads_1": float(run1.sum()),
+            "sample": f"{nrun} timed step(s) after 1 warm-up of B={B}, d={d} (median): torch.cdist**2 + SciPy LSAP f64 "
+                      f"(stand-in for POT emd; single threaded: the solve is 1 core whatever num_threads is, so "
+                      f"cores=1 although torch used {threads_max} intra-op threads for cdist / gathers) + the "
+                      f"reference's dense-plan np.random.choice sampling + eager xt/ut; host has {os.cpu_count()} cores"}
+
+
+def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
+    """Dominant kernel of the step: asg_step (every chip-wide step of the exact-assignment state machine).
+    Un-overlapped solves on one stream.  Algorithmic bytes per SURVEY §8d: 4 B per row scan (the fp32 cost
+    row) + 8 B prices per sweep (= per launch).  Launch durations: the device books the time of every
+    step on its own 100 MHz clock (cfm_assign_debug_times); HIP events bracket each solve on its stream."""
+    Ms = [ot.cost_matrix(x0, x1, matrix_cores=False) for (x0, x1) in pool[:nsolves]]
+    ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
+    for M in Ms[:2]:
+        ot.assign_exact(M)
+    ev_ms, step_us, steps, scans, solver_us = [], [], [], [], []
+    for M in Ms:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); perm, info = ot.assign_exact(M, return_info=True); e1.record(); torch.cuda.synchronize()
+        buf = (ctypes.c_double * 32)()
+        _lib.check(lib.cfm_assign_debug_times(_lib.ptr(ws), buf), "cfm_assign_debug_times")
+        t = np.array(list(buf))
+        ev_ms.append(e0.elapsed_time(e1)); step_us.append(float(t[:11].sum())); solver_us.append(float(t[11:13].sum()))
+        steps.append(info["stats"][6]); scans.append(info["stats"][5])
+    steps_m, scans_m = float(np.mean(steps)), float(np.mean(scans))
+    bytes_solve = scans_m * 4.0 * B + steps_m * 8.0 * B
+    t_step = float(np.mean(step_us)) * 1e-6
+    gbs = bytes_solve / t_step / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r2_asg_pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("asg_step_hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": "asg_step (cfm_assign_exact_f32)",
+            "launches_per_solve": steps_m, "avg_launch_us": float(np.mean(step_us)) / steps_m,
+            "algorithmic_bytes_per_launch": bytes_solve / steps_m, "row_scans_per_solve": scans_m,
+            "solve_ms": float(np.mean(ev_ms)), "list_solver_ms": float(np.mean(solver_us)) * 1e-3,
+            "note": "latency-bound chain of ~200 dependent launches per solve (each >= 1.6 us of launch boundary): "
+                    "the figure of merit is solve_ms; achieved = (4B per row scan + 8B prices per launch) / summed "
+                    "asg_step time of an un-overlapped solve; traffic (if present) = HBM bytes per launch from the "
+                    "committed rocprofv3 --pmc passes (profiles/), FETCH x2 + WRITE"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=784)
     ap.add_argument("--width", type=int, default=512)
@@ -105,7 +266,7 @@ def main():
                     help="N > 0: up to N couplings of the next batches in flight on side streams while the "
                          "model steps on batch k (cfm_amd.prefetch); 0: strictly sequential")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sinkhorn", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the C1 / C2 / C5 / roofline legs")
     args = ap.parse_args()
 
     import cfm_amd
@@ -116,9 +277,7 @@ def main():
     lib_ = _lib.load()
     if os.environ.get("CFM_ASG_BLOCKS"):     # experiment knob: grid cap of the assignment's wide kernel
         lib_.cfm_assign_set_wide_blocks(int(os.environ["CFM_ASG_BLOCKS"]))
-    if os.environ.get("CFM_ASG_STOPE"):
-        lib_.cfm_assign_set_stop_early(float(os.environ["CFM_ASG_STOPE"]))
-    if os.environ.get("CFM_ASG_DENSE"):      # experiment knob: no candidate-list solver (small LDS launches)
+    if os.environ.get("CFM_ASG_DENSE"):      # experiment knob: no candidate-list solver
         lib_.cfm_assign_set_mode(0)
     rank, local, world = D.init_from_env()
     if world != args.gpus and rank == 0:
@@ -139,118 +298,79 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     np.random.seed(D.shard_seed(1, rank)); torch.manual_seed(D.shard_seed(1, rank))
 
-    asg_events, stats_log = [], []
-
     def draw():
         """the host RNG calls of one coupling, in the reference's order (np.random.choice draw of
         sample_map, ref:118; t from the CPU torch generator, conditional_flow_matching.py:190)"""
         return np.random.random_sample(B), torch.rand(B)
 
-    def couple(x0, x1, drawn, timed=True):
+    def couple(x0, x1, drawn):
         """cost -> exact assignment -> sampling -> fused gather + xt/ut, on the CURRENT stream."""
         u_host, t_host = drawn
-        if timed:
-            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         M = ot.cost_matrix(x0, x1, matrix_cores=False)     # as OTPlanSampler(method="exact") does
-        if timed:
-            ea.record()
-        perm, info = ot.assign_exact(M, return_info=True)
-        if timed:
-            eb.record(); asg_events.append((ea, eb)); stats_log.append(info["stats"])
+        perm = ot.assign_exact(M)
         u = torch.from_numpy(u_host).to(dev)
         i, j = ot.sample_perm(perm, u, B)
         return fm._sample(x0, x1, t_host.type_as(x0), False, idx=(i, j))
 
     def model_step(t, xt, ut):
+        if args.mode != "train":
+            return
         opt.zero_grad(set_to_none=True)
         vt = model(torch.cat([xt, t[:, None]], dim=-1))
         loss = torch.mean((vt - ut) ** 2)
         loss.backward()
         opt.step()
 
-    def run(first, count, timed):
-        """`count` steps starting at pool index `first`; every step = one coupling + one model
-        update, all of them inside this call (the pipeline starts empty and is drained)."""
-        if not args.pipeline:
-            for k in range(count):
-                x0, x1 = pool[(first + k) % len(pool)]
-                t, xt, ut = couple(x0, x1, draw(), timed)
-                if args.mode == "train":
-                    model_step(t, xt, ut)
-            return
-        hook = lambda a, b, drawn: couple(a, b, drawn, timed)       # noqa: E731
-        inflight, submitted = collections.deque(), 0
-        while submitted < min(args.pipeline, count):
-            inflight.append(pre.submit(*pool[(first + submitted) % len(pool)], hook=hook, draw=draw)); submitted += 1
-        for k in range(count):
-            t, xt, ut = inflight.popleft().result()
-            if submitted < count:
-                inflight.append(pre.submit(*pool[(first + submitted) % len(pool)], hook=hook, draw=draw)); submitted += 1
-            if args.mode == "train":
-                model_step(t, xt, ut)
-
     pre = None
     if args.pipeline:
         from cfm_amd.prefetch import CouplingPrefetcher
         pre = CouplingPrefetcher(fm, dev, workers=args.pipeline)
-    run(0, args.warmup, False)
-    D.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup, args.steps, True)
-    torch.cuda.synchronize(); D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed, gathered = timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple, model_step,
+                                     draw, pre, args.pipeline, dev)
     if pre is not None:
         pre.close()
-    # transparency leg (untimed for `value`): the same step strictly sequential, no overlap at all
-    seq_ms = None
+    assert gathered is None or gathered.shape[0] == world * B
+    # the same K steps strictly one after the other (no overlap at all): what an unmodified script gets
+    seq_s = None
     if args.pipeline and world == 1:
-        keep = args.pipeline
-        args.pipeline = 0
-        n_seq = min(10, args.steps)
+        n_seq = min(20, args.steps)
+        run_steps(pool, 0, 2, couple, model_step, draw)
         torch.cuda.synchronize(); ts = time.perf_counter()
-        run(args.warmup + args.steps, n_seq, False)
-        torch.cuda.synchronize(); seq_ms = (time.perf_counter() - ts) / n_seq * 1e3
-        args.pipeline = keep
+        run_steps(pool, args.warmup, n_seq, couple, model_step, draw)
+        torch.cuda.synchronize(); seq_s = (time.perf_counter() - ts) / n_seq
 
     if rank != 0:
         return
     value = world * B * args.steps / elapsed
-    asg_ms = [a.elapsed_time(b) for a, b in asg_events]
-    scans = [s[5] for s in stats_log]
-    # algorithmic bytes of the assignment: every row scan reads one fp32 cost row + the fp64 prices
-    asg_bytes = [sc * (4 * B + 8 * B) for sc in scans]
-    asg_gbs_solve = sum(asg_bytes) / (sum(asg_ms) * 1e-3) / 1e9 if asg_ms else 0.0
-    # with several couplings in flight the solves overlap in time: the rate the chip sustains on this
-    # kernel family is all their bytes over the wall time of the timed region (model steps included)
-    asg_gbs = sum(asg_bytes) / elapsed / 1e9 if (args.pipeline and asg_ms) else asg_gbs_solve
     out = {
         "metric": "OT-CFM train-step samples/sec (B=4096,d=784)", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C3: MNIST-shaped d=784, B=4096 per GPU, ExactOptimalTransportConditionalFlowMatcher "
-                               "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd + Adam (PyTorch-ROCm)",
+                               "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd + Adam (PyTorch-ROCm)"
+                               + ("; one all-gather of the final x_t over RCCL inside the timed region" if world > 1 else ""),
                    "batch_per_gpu": B, "dim": d, "mlp_width": args.width, "mode": args.mode,
                    "schedule": (f"couplings of the next {args.pipeline} batch(es) in flight on side streams during "
                                 "the model step" if args.pipeline else "sequential"),
                    "parallelism": f"dp{world}" if world > 1 else "single"},
-        "roofline": {"bound": "hbm", "achieved": asg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": asg_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "per_solve_GBps": asg_gbs_solve,
-                     "kernel": "asg_wide+asg_ctrl (cfm_assign_exact_f32)",
-                     "note": "algorithmic bytes = row scans x (4B cost row + 8B prices); irregular, latency-bound; "
-                             "achieved = bytes of all solves / wall time of the timed region when couplings are "
-                             "pipelined (solves overlap in time), per_solve_GBps = bytes / HIP-event duration of a "
-                             "solve on its own stream; traffic: see profiles/*pmc_FETCH_SIZE.csv (x2-corrected "
-                             "fetch 1.8 GB per solve < 5.5 GB algorithmic: rows are re-read from L2 / MALL)"},
-        "assign_ms_per_step": float(np.mean(asg_ms)) if asg_ms else None,
-        "ms_per_step_sequential": seq_ms,
-        "assign_stats_mean": [float(x) for x in np.mean(np.array(stats_log), axis=0)] if stats_log else None,
+        "value_sequential": (B / seq_s) if seq_s else None,
+        "ms_per_step_sequential": seq_s * 1e3 if seq_s else None,
     }
-    if not args.no_sinkhorn:
-        sk = sinkhorn_leg(dev)
-        out["sinkhorn_iters_per_s"] = sk["iters_per_s"]
-        out["roofline_sinkhorn"] = sk["roofline"]
+    if world == 1 and not args.no_legs:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            out["roofline"] = assign_roofline(dev, pool, lib_, _lib, ot, B)
+            out["c1"] = c1_latency(dev)
+        c2 = sinkhorn_leg(dev, "C2", 0.05)
+        out["c2"] = c2
+        out["sinkhorn_iters_per_s"] = c2["sinkhorn_iters_per_s"]
+        out["roofline_sinkhorn"] = c2["roofline"]
+        c5 = sinkhorn_leg(dev, "C5", 0.1)
+        c5.update(c5_ode_leg(dev))
+        out["c5"] = c5
+    else:
+        out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                           "traffic": None, "note": "reported at N = 1 only"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, d)
     print(json.dumps(out))

@@ -22,7 +22,7 @@ class CouplingPrefetcher:
 
     def __init__(self, flow_matcher, device=None, workers=1):
         self.fm = flow_matcher
-        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._tls = threading.local()
         self._pool = _cf.ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="cfm-coupling")
 
@@ -34,6 +34,9 @@ class CouplingPrefetcher:
         return s
 
     def _work(self, x0, x1, ready, hook, drawn):
+        if self.device.type != "cuda":           # host tensors (the CPU multi-process tests): plain worker thread
+            return (hook(x0, x1, drawn) if hook is not None
+                    else self.fm.sample_location_and_conditional_flow(x0, x1)), None
         stream = self._stream()
         with torch.cuda.stream(stream):
             stream.wait_event(ready)                  # x0 / x1 were produced on the caller's stream
@@ -48,8 +51,10 @@ class CouplingPrefetcher:
     def submit(self, x0, x1, hook=None, draw=None):
         """``draw()`` (optional) runs NOW, on the calling thread, and its result is handed to
         ``hook(x0, x1, drawn)`` — keep every host RNG call in there when ``workers`` > 1."""
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(self.device))
+        ready = None
+        if self.device.type == "cuda":
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
         drawn = draw() if draw is not None else None
         return _Handle(self._pool.submit(self._work, x0, x1, ready, hook, drawn), self.device)
 
@@ -63,6 +68,8 @@ class _Handle:
 
     def result(self):
         out, done = self._fut.result()
+        if done is None:
+            return out
         cur = torch.cuda.current_stream(self._device)
         cur.wait_event(done)
         for t in out:

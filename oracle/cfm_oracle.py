@@ -177,6 +177,17 @@ def sample_map_given_u(pi, u):
     return np.divmod(choice_flat(p, u), pi.shape[1])
 
 
+def sample_map_reference(pi, batch_size):
+    """OTPlanSampler.sample_map as the reference runs it (optimal_transport.py:116-121): flatten the
+    dense plan, renormalise, np.random.choice over all B0 * B1 entries (consumes batch_size uniforms
+    of the global np.random stream), divmod.  O(B^2); used by bench.py's cpu_baseline leg and to pin
+    sample_map_given_u / sample_perm_given_u."""
+    p = pi.flatten()
+    p = p / p.sum()
+    choices = np.random.choice(pi.shape[0] * pi.shape[1], p=p, size=batch_size, replace=True)
+    return np.divmod(choices, pi.shape[1])
+
+
 def sample_perm_given_u(perm, u):
     """O(B) restatement for a permutation plan: only the B non-zeros matter."""
     B = len(perm)
@@ -509,3 +520,102 @@ def dopri5_trajectory(f, x, t_span, atol, rtol, return_log=False):
             dt = f32(1e-12)
     out = np.stack(sol)
     return (out, {"steps": steps, "nfe": nfe, "log": log}) if return_log else out
+
+
+# ----------------------------------------------------------------------------- ODE, second restatement
+def dopri5_trajectory_torch(f, x, t_span, atol, rtol, dtype=torch.float64, return_log=False):
+    """A SECOND, independent restatement of torchdyn's adaptive odeint, written as
+    torchdyn itself is: eager torch tensors, with the state, t, dt and the error ratio all carried
+    in ONE dtype (torchdyn inherits the dtype of x; the reference feeds it float32, and float64
+    gives the reference-arithmetic answer).  It shares no code with dopri5_trajectory above (whose
+    scalar controller deliberately runs in float32 like the device driver) — tests compare the
+    accept / reject sequences of the two and of the HIP driver.  f(t, y) -> dy, torch tensors."""
+    x = torch.as_tensor(x).to(dtype)
+    t_span = torch.as_tensor(t_span).to(dtype)
+    atol_, rtol_ = torch.tensor(float(np.float32(atol)), dtype=dtype), torch.tensor(float(np.float32(rtol)), dtype=dtype)
+    c = torch.tensor(DP_C, dtype=dtype)
+    a = [torch.tensor(r, dtype=dtype) for r in DP_A]
+    bsol = torch.tensor(DP_BSOL, dtype=dtype)
+    berr = torch.tensor([s - e for s, e in zip(DP_BSOL, DP_BALT)], dtype=dtype)
+
+    def hairer_norm(z):
+        return z.abs().pow(2).mean().sqrt()
+
+    nfe = 0
+
+    def ev(t, y):
+        nonlocal nfe
+        nfe += 1
+        return f(t, y).to(dtype)
+
+    t, T = t_span[0], t_span[-1]
+    k1 = ev(t, x)
+    # init_step (Hairer II.4), order 5
+    scale = atol_ + x.abs() * rtol_
+    d0, d1 = hairer_norm(x / scale), hairer_norm(k1 / scale)
+    h0 = torch.tensor(1e-6, dtype=dtype) if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    f1 = ev(t + h0, x + h0 * k1)
+    d2 = hairer_norm((f1 - k1) / scale) / h0
+    if d1 <= 1e-15 and d2 <= 1e-15:
+        h1 = torch.max(torch.tensor(1e-6, dtype=dtype), h0 * 1e-3)
+    else:
+        h1 = (0.01 / torch.max(d1, d2)) ** (1.0 / 6.0)
+    dt = torch.min(100 * h0, h1)
+
+    t_eval, ckpt = t_span[1:], 0
+    sol, log, steps = [x], [], 0
+    while t < T:
+        if t + dt > T:
+            dt = T - t
+        dt_old, flag = dt, False
+        if ckpt < len(t_eval) and t + dt > t_eval[ckpt]:
+            dt_old, flag = dt, True
+            dt = t_eval[ckpt] - t
+        # one Dormand-Prince step (FSAL: k1 carried over)
+        ks = [k1]
+        y = x
+        for s in range(6):
+            y = x + dt * sum(a[s][q] * ks[q] for q in range(s + 1))
+            ks.append(ev(t + c[s] * dt, y))
+        x_new = y
+        x_err = dt * sum(berr[q] * ks[q] for q in range(7))
+        error_scaled = x_err / (atol_ + rtol_ * torch.max(x.abs(), x_new.abs()))
+        error_ratio = hairer_norm(error_scaled)
+        accept = bool(error_ratio <= 1)
+        steps += 1
+        log.append((float(t), float(dt), float(error_ratio), accept))
+        if accept:
+            lands = ckpt < len(t_eval) and (flag or bool(t + dt == t_eval[ckpt]))
+            if lands:
+                t = t_eval[ckpt]; sol.append(x_new); ckpt += 1
+            else:
+                t = t + dt
+            x, k1 = x_new, ks[6]
+        if flag:
+            dt = dt_old - dt
+        # adapt_step(safety 0.9, min 0.2, max 10, order 5)
+        if error_ratio == 0:
+            dt = dt * 10.0
+        else:
+            min_factor = 1.0 if error_ratio < 1 else 0.2
+            factor = min(10.0, max(float(0.9 / error_ratio ** 0.2), min_factor))
+            dt = dt * factor
+        if not dt > 1e-12:
+            dt = torch.tensor(1e-12, dtype=dtype)
+    out = torch.stack(sol)
+    return (out, {"steps": steps, "nfe": nfe, "log": log}) if return_log else out
+
+
+def mlp_field_torch(weights, biases, dtype=torch.float64):
+    """torch_wrapper(MLP) as a torch callable f(t, y) in `dtype` (models.py:10-21, utils.py:51-52)."""
+    Ws = [torch.as_tensor(np.asarray(W)).to(dtype) for W in weights]
+    bs = [torch.as_tensor(np.asarray(b)).to(dtype) for b in biases]
+
+    def f(t, y):
+        h = torch.cat([y.to(dtype), torch.as_tensor(t, dtype=dtype).reshape(1, 1).expand(y.shape[0], 1)], 1)
+        for l, (W, b) in enumerate(zip(Ws, bs)):
+            h = h @ W.T + b
+            if l != len(Ws) - 1:
+                h = torch.nn.functional.selu(h)
+        return h
+    return f

@@ -14,6 +14,8 @@ Fixture provenance
                       real, solver = stand-in).
   sinkhorn_cases.npz  oracle float64 log-domain Sinkhorn (POT loop semantics) + restated Knopp.
   ode_cases.npz       oracle torchdyn-style euler / dopri5 on a seeded MLP field.
+  ode2_cases.npz      (round 2) d = 50 / d = 784 fields and controller cases with rejected steps,
+                      with the accept / reject logs of two independent restatements.
   ub_cases.npz        reference OTPlanSampler("unbalanced" / "partial") wrapper over the restated
                       POT loops (in-repo unbalanced statement; recalled partial Dykstra loop).
 """
@@ -145,6 +147,64 @@ def ode_cases():
     return out
 
 
+def _seeded_mlp(d, w, seed):
+    torch.manual_seed(seed)
+    lins = [torch.nn.Linear(d + 1, w), torch.nn.Linear(w, w), torch.nn.Linear(w, w), torch.nn.Linear(w, d)]
+    return [l.weight.detach().numpy().copy() for l in lins], [l.bias.detach().numpy().copy() for l in lins]
+
+
+def ode2_cases():
+    """Round 2: (i) a single-cell-shaped field (d = 50, w = 64: the fused small-field drivers);
+    (ii) controller cases whose step sequence is NOT dictated by t_span — a field that varies fast in
+    t, t_span = [0, 1], including one with rejected steps — each recorded with the accept / reject log
+    of BOTH restatements (cfm_oracle.dopri5_trajectory: float64 state, float32 scalar controller;
+    cfm_oracle.dopri5_trajectory_torch in float32 = what torchdyn does with float32 inputs, and in
+    float64); (iii) a C3-shaped field (d = 784, w = 512: the layer-per-kernel path)."""
+    out = {}
+    # (i)
+    Ws, bs = _seeded_mlp(50, 64, 11)
+    for k, (W, b) in enumerate(zip(Ws, bs)):
+        out[f"s_W{k}"] = W; out[f"s_b{k}"] = b
+    x0, _ = oracle.config_inputs("C5", B=48)
+    x = x0.numpy(); ts = np.linspace(0, 1, 7).astype(np.float32)
+    f = lambda t, y: oracle.mlp_forward_f64(Ws, bs, y, t)
+    out["s_x"] = x; out["s_t_span"] = ts
+    out["s_euler"] = oracle.euler_trajectory(f, x, ts)
+    tr, info = oracle.dopri5_trajectory(f, x, ts, 1e-4, 1e-4, return_log=True)
+    out["s_dopri5"] = tr; out["s_steps"] = info["steps"]; out["s_nfe"] = info["nfe"]
+    # (ii)
+    W0, b0 = _seeded_mlp(2, 64, 0)
+    xg = oracle.eight_gaussians(64, 5).numpy()
+    out["c_x"] = xg
+    for name, tw, ow, ts, tol in (("a", 30.0, 4.0, [0.0, 1.0], 1e-5), ("b", 80.0, 8.0, [0.0, 1.0], 1e-5),
+                                  ("c", 200.0, 10.0, [0.0, 1.0], 1e-5), ("d", 200.0, 10.0, [0.0, 0.25, 0.5, 0.75, 1.0], 1e-4)):
+        Wc = [w.copy() for w in W0]; Wc[0][:, 2] *= tw; Wc[3] *= ow
+        ts = np.asarray(ts, dtype=np.float32)
+        fc = lambda t, y: oracle.mlp_forward_f64(Wc, b0, y, t)
+        tr, info = oracle.dopri5_trajectory(fc, xg, ts, tol, tol, return_log=True)
+        out[f"c_{name}_tw"] = tw; out[f"c_{name}_ow"] = ow; out[f"c_{name}_t_span"] = ts; out[f"c_{name}_tol"] = tol
+        out[f"c_{name}_traj"] = tr; out[f"c_{name}_steps"] = info["steps"]; out[f"c_{name}_nfe"] = info["nfe"]
+        out[f"c_{name}_accept"] = np.array([l[3] for l in info["log"]])
+        for dt, tag in ((torch.float32, "t32"), (torch.float64, "t64")):
+            tr2, info2 = oracle.dopri5_trajectory_torch(oracle.mlp_field_torch(Wc, b0, dt), xg, ts, tol, tol, dtype=dt, return_log=True)
+            out[f"c_{name}_{tag}_accept"] = np.array([l[3] for l in info2["log"]])
+            out[f"c_{name}_{tag}_traj"] = tr2.double().numpy()
+    for k, (W, b) in enumerate(zip(W0, b0)):
+        out[f"c_W{k}"] = W; out[f"c_b{k}"] = b
+    # (iii): weights are regenerated from the seed by the test (3 MB otherwise); only x and the results are stored
+    Wl, bl = _seeded_mlp(784, 512, 5)
+    g = torch.Generator().manual_seed(17)
+    xl = torch.randn(24, 784, generator=g).numpy()
+    tl = np.linspace(0, 1, 4).astype(np.float32)
+    fl = lambda t, y: oracle.mlp_forward_f64(Wl, bl, y, t)
+    out["l_x"] = xl; out["l_t_span"] = tl
+    out["l_euler"] = oracle.euler_trajectory(fl, xl, tl).astype(np.float32)      # (float32 storage: 6e-8 << the 1e-5 parity bar)
+    tr, info = oracle.dopri5_trajectory(fl, xl, tl, 1e-4, 1e-4, return_log=True)
+    out["l_dopri5"] = tr.astype(np.float32); out["l_steps"] = info["steps"]; out["l_nfe"] = info["nfe"]
+    out["l_W0_checksum"] = float(np.abs(Wl[0]).sum())         # guards the seed -> weights reproduction
+    return out
+
+
 def ub_cases(ot):
     """Reference OTPlanSampler(method="unbalanced" | "partial") wrapper (real code) over the
     stand-in's restated POT loops, plus the docstring KAT of the in-repo unbalanced statement."""
@@ -179,12 +239,17 @@ def ub_cases(ot):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ode2":       # oracle-only fixtures: no reference import needed
+        np.savez_compressed(os.path.join(HERE, "ode2_cases.npz"), **ode2_cases())
+        print("ode2_cases.npz", os.path.getsize(os.path.join(HERE, "ode2_cases.npz")))
+        return
     cfm, ot = ref_import.import_reference()
     np.savez_compressed(os.path.join(HERE, "ub_cases.npz"), **ub_cases(ot))
     np.savez_compressed(os.path.join(HERE, "fm_cases.npz"), **fm_cases(cfm))
     np.savez_compressed(os.path.join(HERE, "ot_cases.npz"), **ot_cases(ot))
     np.savez_compressed(os.path.join(HERE, "sinkhorn_cases.npz"), **sinkhorn_cases())
     np.savez_compressed(os.path.join(HERE, "ode_cases.npz"), **ode_cases())
+    np.savez_compressed(os.path.join(HERE, "ode2_cases.npz"), **ode2_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
