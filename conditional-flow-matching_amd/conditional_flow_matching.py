@@ -62,6 +62,16 @@ def _fused_xt_ut(variant, sigma, x0, x1, t, eps, idx=None, xt_in=None, want_xt=T
     return fin(xt), fin(ut)
 
 
+def _native(fn):
+    """Marks the built-in (kernel-backed) implementation of an overridable method: a subclass that
+    replaces any of them is detected by the absence of the mark."""
+    fn._cfm_native = True
+    return fn
+
+
+_OVERRIDABLE = ("compute_mu_t", "compute_sigma_t", "sample_xt", "compute_conditional_flow")
+
+
 class ConditionalFlowMatcher:
     """Independent conditional flow matching (ref:41-217)."""
 
@@ -70,25 +80,95 @@ class ConditionalFlowMatcher:
     def __init__(self, sigma: Union[float, int] = 0.0):
         self.sigma = sigma
 
+    # -- which path -----------------------------------------------------------------------------
+    # The fused kernel evaluates the CLASS's closed forms in fp32 and does not build an autograd
+    # graph.  The reference composes sample_location_and_conditional_flow out of the overridable
+    # methods (ref:189-199) and keeps everything differentiable in the input dtype; so whenever a
+    # subclass overrides one of them, an input requires grad, or the inputs are not fp32, the same
+    # composition runs in eager torch instead (through the overrides).
+    def _customised(self):
+        cls = type(self)
+        return any(not getattr(getattr(cls, m), "_cfm_native", False) for m in _OVERRIDABLE)
+
+    @staticmethod
+    def _needs_eager(*tensors):
+        for z in tensors:
+            if isinstance(z, torch.Tensor) and (z.dtype != torch.float32 or
+                                                (z.requires_grad and torch.is_grad_enabled())):
+                return True
+        return False
+
+    def _impl(self, name):
+        """The user's override of `name`, or the eager restatement of the built-in one."""
+        f = getattr(type(self), name)
+        return getattr(self, name) if not getattr(f, "_cfm_native", False) else getattr(self, "_eager_" + name)
+
+    # -- eager restatements of the built-in closed forms (all variants; reference operation order) --
+    def _eager_compute_mu_t(self, x0, x1, t):
+        t = pad_t_like_x(t, x0)
+        v = self._variant
+        if v == _lib.VARIANT_TARGET:
+            return t * x1                                                    # ref:349-350
+        if v == _lib.VARIANT_VP:
+            return torch.cos(math.pi / 2 * t) * x0 + torch.sin(math.pi / 2 * t) * x1   # ref:588-589
+        return t * x1 + (1 - t) * x0                                         # ref:82-83
+
+    def _eager_compute_sigma_t(self, t):
+        v = self._variant
+        if v == _lib.VARIANT_TARGET:
+            return 1 - (1 - self.sigma) * t                                  # ref:368
+        if v == _lib.VARIANT_SB:
+            return self.sigma * torch.sqrt(t * (1 - t))                      # ref:446
+        return self.sigma                                                    # ref:101-102
+
+    def _eager_sample_xt(self, x0, x1, t, epsilon):
+        mu_t = self._impl("compute_mu_t")(x0, x1, t)                         # ref:126-129
+        sigma_t = pad_t_like_x(self._impl("compute_sigma_t")(t), x0)
+        return mu_t + sigma_t * epsilon
+
+    def _eager_compute_conditional_flow(self, x0, x1, t, xt):
+        v = self._variant
+        if v == _lib.VARIANT_TARGET:
+            tp = pad_t_like_x(t, x1)
+            return (x1 - (1 - self.sigma) * xt) / (1 - (1 - self.sigma) * tp)    # ref:393-394
+        if v == _lib.VARIANT_SB:
+            tp = pad_t_like_x(t, x0)
+            mu_t = self._impl("compute_mu_t")(x0, x1, tp)                    # ref:474-478
+            return (1 - 2 * tp) / (2 * tp * (1 - tp) + 1e-8) * (xt - mu_t) + x1 - x0
+        if v == _lib.VARIANT_VP:
+            tp = pad_t_like_x(t, x0)
+            return math.pi / 2 * (torch.cos(math.pi / 2 * tp) * x1 - torch.sin(math.pi / 2 * tp) * x0)   # ref:617-618
+        return x1 - x0                                                       # ref:153-154
+
     # -- closed forms, each evaluated by the fused kernel --
+    @_native
     def compute_mu_t(self, x0, x1, t):
         """t * x1 + (1 - t) * x0 (ref:62-83): the kernel's xt with eps = 0 (mu + 0 = mu)."""
+        if self._needs_eager(x0, x1, t):
+            return self._eager_compute_mu_t(x0, x1, t)
         xt, _ = _fused_xt_ut(self._variant, self.sigma, x0, x1, self._t_vec(t, x0),
                              torch.zeros_like(x0))
         return xt
 
+    @_native
     def compute_sigma_t(self, t):
         """sigma (ref:85-102)."""
         del t
         return self.sigma
 
+    @_native
     def sample_xt(self, x0, x1, t, epsilon):
         """mu_t + sigma_t * epsilon (ref:104-129)."""
+        if self._customised() or self._needs_eager(x0, x1, t, epsilon):
+            return self._eager_sample_xt(x0, x1, t, epsilon)
         xt, _ = _fused_xt_ut(self._variant, self.sigma, x0, x1, self._t_vec(t, x0), epsilon)
         return xt
 
+    @_native
     def compute_conditional_flow(self, x0, x1, t, xt):
         """ut(x1|x0) (ref:131-154; overrides :370-394, :448-478, :591-618)."""
+        if self._customised() or self._needs_eager(x0, x1, t, xt):
+            return self._eager_compute_conditional_flow(x0, x1, t, xt)
         _, ut = _fused_xt_ut(self._variant, self.sigma, x0, x1, self._t_vec(t, x0), None, xt_in=xt,
                              want_xt=False)
         return ut
@@ -107,8 +187,18 @@ class ConditionalFlowMatcher:
         if t is None:
             t = torch.rand(x0.shape[0]).type_as(x0)
         assert len(t) == x0.shape[0], "t has to have batch size dimension"
-        eps = self.sample_noise_like(x0)
-        xt, ut = _fused_xt_ut(self._variant, self.sigma, x0, x1, t, eps, idx=idx)
+        if self._customised() or self._needs_eager(x0, x1, t):
+            # the reference's composition, through the overridable methods; the OT pairing is a plain
+            # (differentiable) index gather
+            if idx is not None:
+                i, j = idx
+                x0, x1 = x0[i.to(x0.device)], x1[j.to(x1.device)]
+            eps = self.sample_noise_like(x0)
+            xt = self._impl("sample_xt")(x0, x1, t, eps)
+            ut = self._impl("compute_conditional_flow")(x0, x1, t, xt)
+        else:
+            eps = self.sample_noise_like(x0)
+            xt, ut = _fused_xt_ut(self._variant, self.sigma, x0, x1, t, eps, idx=idx)
         if return_noise:
             return t, xt, ut, eps
         return t, xt, ut
@@ -160,6 +250,7 @@ class TargetConditionalFlowMatcher(ConditionalFlowMatcher):
 
     _variant = _lib.VARIANT_TARGET
 
+    @_native
     def compute_sigma_t(self, t):
         """1 - (1 - sigma) t (ref:352-368)."""
         return 1 - (1 - self.sigma) * t
@@ -179,6 +270,7 @@ class SchrodingerBridgeConditionalFlowMatcher(_OTMixin, ConditionalFlowMatcher):
         self.ot_method = ot_method
         self.ot_sampler = OTPlanSampler(method=ot_method, reg=2 * self.sigma**2)
 
+    @_native
     def compute_sigma_t(self, t):
         """sigma * sqrt(t (1 - t)) (ref:429-446)."""
         return self.sigma * torch.sqrt(t * (1 - t))

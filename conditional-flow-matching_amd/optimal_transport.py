@@ -228,6 +228,15 @@ def sample_pi(pi_dev, u01):
     return i, j
 
 
+def take_rows(x, idx):
+    """x[idx] for device index vectors: the byte-copy kernel, unless x carries an autograd graph
+    (a learned encoder in front of the coupling, ref:145 keeps x0[i] differentiable) — then a plain
+    differentiable index gather."""
+    if x.requires_grad and torch.is_grad_enabled():
+        return x[idx.to(x.device)]
+    return gather_rows(x.detach().to(idx.device), idx).to(x.device)
+
+
 def gather_rows(src, idx):
     """src[idx] along dim 0 on the GPU (src: contiguous device tensor, idx: device int64)."""
     lib = _lib.load()
@@ -406,8 +415,8 @@ class OTPlanSampler:
         r"""Compute the OT plan and draw source and target samples from it (ref:123-145)."""
         i, j = self._sample_indices(x0, x1, replace=replace)
         dev = i.device
-        g0 = gather_rows(x0.detach().to(dev), i).to(x0.device)
-        g1 = gather_rows(x1.detach().to(dev), j).to(x1.device)
+        g0 = take_rows(x0, i)
+        g1 = take_rows(x1, j)
         return g0, g1
 
     def sample_plan_with_scipy(self, x0, x1):
@@ -428,10 +437,10 @@ class OTPlanSampler:
         i, j = self._sample_indices(x0, x1, replace=replace)
         dev = i.device
         return (
-            gather_rows(x0.detach().to(dev), i).to(x0.device),
-            gather_rows(x1.detach().to(dev), j).to(x1.device),
-            gather_rows(y0.detach().to(dev), i).to(y0.device) if y0 is not None else None,
-            gather_rows(y1.detach().to(dev), j).to(y1.device) if y1 is not None else None,
+            take_rows(x0, i),
+            take_rows(x1, j),
+            take_rows(y0, i) if y0 is not None else None,
+            take_rows(y1, j) if y1 is not None else None,
         )
 
     def _solve_many(self, pairs, workers=3):

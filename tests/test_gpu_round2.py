@@ -162,7 +162,15 @@ def test_ode_controller_cases_vs_golden(dev, golden_dir, name):
     tol = float(d[f"c_{name}_tol"])
     node = _node(Wc, bc, 2, 64, "dopri5", tol, dev)
     tr = node.trajectory(torch.from_numpy(d["c_x"]), torch.from_numpy(d[f"c_{name}_t_span"])).cpu().numpy()
-    assert node.n_steps == int(d[f"c_{name}_steps"]) and node.nfe == int(d[f"c_{name}_nfe"]), (node.n_steps, node.nfe)
+    steps, nfe = int(d[f"c_{name}_steps"]), int(d[f"c_{name}_nfe"])
+    if name == "b":
+        # the knife-edge case (see tests/test_oracle_round2.py): whether the last step lands on T in one
+        # attempt depends on the last ulp of t + dt; the float64-control restatement and the device take
+        # one attempt (6 evaluations) more than the float32-control restatements.  Same states either way.
+        alt = len(d["c_b_t64_accept"])
+        assert (node.n_steps, node.nfe) in ((steps, nfe), (alt, nfe + 6 * (alt - steps))), (node.n_steps, node.nfe)
+    else:
+        assert node.n_steps == steps and node.nfe == nfe, (node.n_steps, node.nfe)
     ref = d[f"c_{name}_traj"]
     assert np.abs(tr - ref).max() <= 1e-5 * np.abs(ref).max(), np.abs(tr - ref).max() / np.abs(ref).max()
     assert np.abs(tr - d[f"c_{name}_t32_traj"]).max() <= 2e-5 * np.abs(ref).max()
@@ -206,3 +214,68 @@ def test_sample_trajectory_sinkhorn_more_couplings_than_workers(dev, workers, mo
         idx.append(np.array([np.random.choice(64, p=pi[i] / pi[i].sum()) for i in idx[-1]]))
     ref = np.stack([X[:, t].numpy()[idx[t]] for t in range(8)], axis=1)
     assert np.array_equal(out, ref)
+
+
+# ------------------------------------------------------------------------------------ API semantics
+def test_subclass_overrides_are_honoured(dev):
+    """A user subclass that overrides one of the composing methods (how the reference defines its own
+    variants, ref:189-199) must not silently get the built-in closed forms of the fused kernel."""
+    from cfm_amd.conditional_flow_matching import ConditionalFlowMatcher, ExactOptimalTransportConditionalFlowMatcher
+
+    class Quad(ConditionalFlowMatcher):
+        def compute_mu_t(self, x0, x1, t):
+            t = t.reshape(-1, *([1] * (x0.dim() - 1)))
+            return t * t * x1 + (1 - t * t) * x0
+
+        def compute_conditional_flow(self, x0, x1, t, xt):
+            t = t.reshape(-1, *([1] * (x0.dim() - 1)))
+            return 2 * t * (x1 - x0)
+
+    g = torch.Generator().manual_seed(0)
+    x0, x1 = torch.randn(32, 5, generator=g), torch.randn(32, 5, generator=g)
+    fm = Quad(sigma=0.25)
+    torch.manual_seed(3)
+    t, xt, ut, eps = fm.sample_location_and_conditional_flow(x0, x1, return_noise=True)
+    tp = t[:, None]
+    assert torch.equal(xt, tp * tp * x1 + (1 - tp * tp) * x0 + 0.25 * eps)
+    assert torch.equal(ut, 2 * tp * (x1 - x0))
+
+    class HalfFlow(ExactOptimalTransportConditionalFlowMatcher):
+        def compute_conditional_flow(self, x0, x1, t, xt):
+            return 0.5 * (x1 - x0)
+
+    fm2, ref = HalfFlow(sigma=0.0), ExactOptimalTransportConditionalFlowMatcher(sigma=0.0)
+    np.random.seed(5); torch.manual_seed(5)
+    t2, xt2, ut2 = fm2.sample_location_and_conditional_flow(x0, x1)
+    np.random.seed(5); torch.manual_seed(5)
+    t3, xt3, ut3 = ref.sample_location_and_conditional_flow(x0, x1)
+    assert torch.equal(t2, t3) and torch.equal(xt2, xt3) and torch.equal(ut2, 0.5 * ut3)
+
+
+def test_gradients_and_float64_flow_through(dev):
+    """The reference keeps xt / ut differentiable w.r.t. x0 / x1 and in their dtype (a learned encoder in
+    front of the matcher): inputs that require grad or are float64 take the eager composition."""
+    from cfm_amd.conditional_flow_matching import (ExactOptimalTransportConditionalFlowMatcher,
+                                                   SchrodingerBridgeConditionalFlowMatcher)
+    g = torch.Generator().manual_seed(1)
+    z0, z1 = torch.randn(48, 4, generator=g), torch.randn(48, 4, generator=g)
+    w = torch.nn.Parameter(torch.eye(4) * 1.5)
+    fm = ExactOptimalTransportConditionalFlowMatcher(sigma=0.1)
+    np.random.seed(2); torch.manual_seed(2)
+    t, xt, ut = fm.sample_location_and_conditional_flow(z0 @ w, z1)
+    assert xt.requires_grad and ut.requires_grad
+    (xt.sum() + ut.sum()).backward()
+    assert w.grad is not None and torch.isfinite(w.grad).all() and w.grad.abs().sum() > 0
+    # same numbers as the fused path on detached inputs
+    np.random.seed(2); torch.manual_seed(2)
+    t_, xt_, ut_ = fm.sample_location_and_conditional_flow((z0 @ w).detach(), z1)
+    assert torch.equal(t, t_)
+    torch.testing.assert_close(xt.detach(), xt_, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ut.detach(), ut_, rtol=1e-6, atol=1e-6)
+    # float64 stays float64
+    sb = SchrodingerBridgeConditionalFlowMatcher(sigma=0.5)
+    np.random.seed(4); torch.manual_seed(4)
+    t64, xt64, ut64 = sb.sample_location_and_conditional_flow(z0.double(), z1.double())
+    assert xt64.dtype == torch.float64 and ut64.dtype == torch.float64
+    x0s, x1s = fm.ot_sampler.sample_plan((z0 @ w), z1)
+    assert x0s.requires_grad

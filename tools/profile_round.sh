@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+#   kernel stats of the default bench command, HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the
+#   exact-assignment solves, MFMA-busy counters of the MFMA-bearing kernels.  Summaries land in gpurun_out/prof/.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/prof; rm -rf $O; mkdir -p $O/raw
+rocprofv3 --kernel-trace --output-format csv -d $O/raw/bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_trace.json.log 2>&1
+python tools/prof_summary.py stats $O/raw/bench $O/bench_kernel_stats.csv
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/raw/asg_$C -- python tools/asg_trace.py run > $O/asg_$C.log 2>&1
+  python tools/prof_summary.py pmc $O/raw/asg_$C $O/asg_pmc_$C.csv
+done
+rocprofv3 --kernel-trace --output-format csv -d $O/raw/asg_trace -- python tools/asg_trace.py run > /dev/null 2>&1
+python tools/asg_trace.py summary $O/raw/asg_trace > $O/asg_trace_summary.txt 2>&1
+python tools/prof_summary.py stats $O/raw/asg_trace $O/asg_kernel_stats.csv
+rocprofv3 --kernel-trace --output-format csv -d $O/raw/mfma_trace -- python tools/mfma_probe.py > /dev/null 2>&1
+python tools/prof_summary.py stats $O/raw/mfma_trace $O/mfma_kernel_stats.csv
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/raw/mfma_pmc -- python tools/mfma_probe.py > $O/mfma_pmc.log 2>&1
+python tools/prof_summary.py pmc $O/raw/mfma_pmc $O/mfma_pmc.csv
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/raw/mfma_pmc2 -- python tools/mfma_probe.py > $O/mfma_pmc2.log 2>&1
+python tools/prof_summary.py pmc $O/raw/mfma_pmc2 $O/mfma_pmc2.csv
+rocprofv3 -L 2>/dev/null | grep -i -E "mfma|FETCH_SIZE|WRITE_SIZE|MfmaUtil" | head -40 > $O/counters_available.txt
+rm -rf $O/raw
+ls -la $O
