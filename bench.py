@@ -6,7 +6,8 @@
 One "step" = one pass of the hot path over one synthetic minibatch already resident in HBM
 (config C3: x0 ~ N(0,I) in R^784, x1 MNIST-like, B = 4096 per GPU):
     cost matrix -> exact OT assignment -> plan sampling -> fused gather + xt/ut  (HIP kernels)
-    -> MLP(785-512-512-512-784) forward, MSE loss, backward, Adam step           (PyTorch-ROCm)
+    -> MLP(785-512-512-512-784) forward, backward (fp32-MFMA HIP kernels behind an autograd.Function),
+       MSE loss (eager elementwise ops), one-launch Adam (HIP)
 Schedule (--pipeline N, default 3): the coupling depends only on the data, so the couplings of
 the next N batches are computed on side streams (background threads, cfm_amd.prefetch) while the
 model steps on batch k, like data-loader workers.  The pipeline starts empty inside the timed
@@ -295,7 +296,7 @@ def main():
     model = cfm_amd.MLP(dim=d, time_varying=True, w=args.width).to(dev)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index])
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = cfm_amd.FusedAdam(model.parameters(), lr=1e-3)      # one-launch torch.optim.Adam arithmetic
     np.random.seed(D.shard_seed(1, rank)); torch.manual_seed(D.shard_seed(1, rank))
 
     def draw():
@@ -348,7 +349,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C3: MNIST-shaped d=784, B=4096 per GPU, ExactOptimalTransportConditionalFlowMatcher "
-                               "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd + Adam (PyTorch-ROCm)"
+                               "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd (fp32-MFMA HIP kernels) + fused Adam (HIP)"
                                + ("; one all-gather of the final x_t over RCCL inside the timed region" if world > 1 else ""),
                    "batch_per_gpu": B, "dim": d, "mlp_width": args.width, "mode": args.mode,
                    "schedule": (f"couplings of the next {args.pipeline} batch(es) in flight on side streams during "

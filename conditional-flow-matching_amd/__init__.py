@@ -16,6 +16,7 @@ from .conditional_flow_matching import (  # noqa: F401
     pad_t_like_x,
 )
 from .models import MLP  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
 from .optimal_transport import OTPlanSampler, wasserstein  # noqa: F401
 
 __version__ = "0.1.0"

@@ -18,7 +18,7 @@ _lock = threading.Lock()
 _lib = None
 
 # ops (include/cfm_gfx950.h)
-OP_SINKHORN, OP_ASSIGN, OP_SAMPLE_DENSE, OP_MLP, OP_ODE, OP_UNBALANCED, OP_COST = 1, 2, 3, 4, 5, 6, 7
+OP_SINKHORN, OP_ASSIGN, OP_SAMPLE_DENSE, OP_MLP, OP_ODE, OP_UNBALANCED, OP_COST, OP_MLP_TRAIN = 1, 2, 3, 4, 5, 6, 7, 8
 VARIANT_ICFM, VARIANT_SB, VARIANT_TARGET, VARIANT_VP = 0, 1, 2, 3
 
 ERRORS = {
@@ -61,6 +61,9 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp]),
     "cfm_gather_rows": (_i, [_vp, _vp, _i, _sz, _vp, _vp]),
     "cfm_mlp_forward_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "cfm_mlp_forward_train_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "cfm_mlp_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cfm_adam_step_f32": (_i, [_vp, _i, _d, _d, _d, _d, _d, _i, _vp]),
     "cfm_ode_euler_mlp_f32": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "cfm_ode_dopri5_mlp_f32": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp,
                                    _vp, _vp]),

@@ -178,3 +178,24 @@ extern "C" int cfm_mlp_forward_f32(const float* x, const float* t, int t_per_row
     return cfm_mlp_forward_impl(x, t, 0.f, t != nullptr, t_per_row, W, b, dims, n_layers, B, out, ws,
                                 (hipStream_t)stream);
 }
+
+// Training forward: the same layer kernels, every hidden activation kept in a caller buffer
+// (hidden[l] : [B, dims[l + 1]], l = 0 .. n_layers - 2) for cfm_mlp_backward_f32 (mlp_train.hip).
+// x already holds every input column (the reference concatenates the time itself:
+// net(torch.cat([xt, t[:, None]], -1)), examples/images/cifar10/train_cifar10.py:147).
+extern "C" int cfm_mlp_forward_train_f32(const float* x, const float* const* W, const float* const* b,
+                                         const int* dims, int n_layers, int B, float* const* hidden,
+                                         float* out, void* stream) {
+    if (!x || !W || !b || !dims || !out || n_layers < 1 || B < 0) return CFM_EINVAL;
+    if (n_layers > 1 && !hidden) return CFM_EINVAL;
+    if (B == 0) return 0;
+    const float* cur = x;
+    for (int l = 0; l < n_layers; ++l) {
+        float* dst = (l == n_layers - 1) ? out : hidden[l];
+        int rc = launch_layer(cur, dims[l], W[l], dims[l], b[l], nullptr, 0.f, 0, -1, B, dims[l], dims[l + 1], dst,
+                              l != n_layers - 1, (hipStream_t)stream);
+        if (rc) return rc;
+        cur = dst;
+    }
+    return 0;
+}

@@ -1,10 +1,11 @@
 """MLP vector field — drop-in for ``torchcfm.models.MLP`` (ref: torchcfm/models/models.py:4-21).
 
 Same module tree (``self.net = Sequential(Linear, SELU, Linear, SELU, Linear, SELU,
-Linear)``) so reference ``state_dict``s load unchanged.  Training (autograd) goes
-through PyTorch-ROCm as the north star prescribes; the inference forward —
-what the ODE solve evaluates hundreds of times — runs on the fp32-MFMA HIP
-kernels (``cfm_mlp_forward_f32``).
+Linear)``) so reference ``state_dict``s load unchanged.  Both directions run on the
+fp32-MFMA HIP kernels: inference (what the ODE solve evaluates hundreds of times)
+through ``cfm_mlp_forward_f32``, training through an ``autograd.Function`` over
+``cfm_mlp_forward_train_f32`` / ``cfm_mlp_backward_f32`` (dgrad with fused SELU',
+split-K wgrad, bias grads); ``cfm_amd.optim.FusedAdam`` is the one-launch optimizer step.
 """
 import ctypes
 
@@ -12,6 +13,61 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
+
+
+class _MLPTrainFunction(torch.autograd.Function):
+    """forward / backward of Linear-SELU ... -Linear on the fp32-MFMA HIP kernels
+    (cfm_mlp_forward_train_f32 / cfm_mlp_backward_f32).  Arguments: x [B, in], then W_0, b_0, W_1, ..."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        lib = _lib.load()
+        dev = x.device
+        n = len(params) // 2
+        Ws = [params[2 * l].detach().contiguous() for l in range(n)]
+        bs = [params[2 * l + 1].detach().contiguous() for l in range(n)]
+        xd = x.detach().contiguous()
+        B = xd.shape[0]
+        dims = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
+        hidden = [torch.empty((B, dims[l + 1]), dtype=torch.float32, device=dev) for l in range(n - 1)]
+        out = torch.empty((B, dims[n]), dtype=torch.float32, device=dev)
+        Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in Ws])
+        bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs])
+        hp = (ctypes.c_void_p * max(1, n - 1))(*([h.data_ptr() for h in hidden] or [0]))
+        cd = (ctypes.c_int * (n + 1))(*dims)
+        check(lib.cfm_mlp_forward_train_f32(ptr(xd), Wp, bp, cd, n, B, hp, ptr(out), stream_ptr()),
+              "cfm_mlp_forward_train_f32")
+        ctx.save_for_backward(xd, *hidden, *Ws)
+        ctx.dims, ctx.n = dims, n
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        lib = _lib.load()
+        n, dims = ctx.n, ctx.dims
+        saved = ctx.saved_tensors
+        acts, Ws = saved[:n], saved[n:]
+        dev = dout.device
+        B = dout.shape[0]
+        dout = dout.contiguous().float()
+        dW = [torch.empty_like(w) for w in Ws]
+        db = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) for w in Ws]
+        dx = torch.empty_like(acts[0]) if ctx.needs_input_grad[0] else None
+        maxw = max(dims)
+        maxp = max(dims[l] * dims[l + 1] for l in range(n))
+        ws = _lib.workspace(_lib.OP_MLP_TRAIN, B, maxw, maxp, dev)
+        ap = (ctypes.c_void_p * n)(*[a.data_ptr() for a in acts])
+        Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in Ws])
+        dWp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in dW])
+        dbp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in db])
+        cd = (ctypes.c_int * (n + 1))(*dims)
+        check(lib.cfm_mlp_backward_f32(ap, Wp, cd, n, B, ptr(dout), dWp, dbp, ptr(dx), ptr(ws), stream_ptr()),
+              "cfm_mlp_backward_f32")
+        grads = [dx]
+        for l in range(n):
+            grads += [dW[l], db[l]]
+        return tuple(grads)
 
 
 class MLP(torch.nn.Module):
@@ -81,11 +137,22 @@ class MLP(torch.nn.Module):
                                       ptr(ws), stream_ptr()), "cfm_mlp_forward_f32")
         return out.to(x.device)
 
+    hip_training = True     # class switch: False sends the autograd path through PyTorch-ROCm (hipBLASLt)
+
     def forward(self, x):
-        # ref:20-21.  Autograd path = PyTorch-ROCm; no-grad inference = HIP kernels.
+        # ref:20-21.  fp32 CUDA tensors: forward AND backward on the fp32-MFMA HIP kernels (an
+        # autograd.Function); no-grad inference: the inference kernels.  Anything else (CPU modules and
+        # tensors in the CPU tests, other dtypes, double backward) is the plain module graph.
         if torch.is_grad_enabled() or not torch.cuda.is_available():
             if not x.is_cuda and not torch.is_grad_enabled():
                 _lib.require_gpu()  # raises: no silent CPU inference path
+            lins = self._linears()
+            if (self.hip_training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+                    and all(l.weight.is_cuda and l.weight.dtype == torch.float32 and l.bias is not None for l in lins)):
+                params = []
+                for l in lins:
+                    params += [l.weight, l.bias]
+                return _MLPTrainFunction.apply(x, *params)
             return self.net(x)
         return self.forward_hip(x)
 

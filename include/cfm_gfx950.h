@@ -47,6 +47,7 @@ extern "C" {
 #define CFM_OP_ODE           5
 #define CFM_OP_UNBALANCED    6   /* also the partial (Dykstra) solver */
 #define CFM_OP_COST          7   /* cfm_sqeuclid_cost_ws_f32 (B0, B1, d)  */
+#define CFM_OP_MLP_TRAIN     8   /* cfm_mlp_backward_f32 (B, widest layer, largest weight's element count) */
 
 /* variants for cfm_sample_xt_ut_f32 (reference class in parentheses) */
 #define CFM_VARIANT_ICFM   0  /* ConditionalFlowMatcher / ExactOT...          */
@@ -226,6 +227,29 @@ int cfm_mlp_forward_f32(const float* x, const float* t, int t_per_row,
                         const float* const* W, const float* const* b,
                         const int* dims, int n_layers, int B, float* out, void* ws,
                         void* stream);
+
+/* K10 (training) — the same network with its hidden activations kept, its backward pass and the
+ * optimizer step.  Replaces what autograd and torch.optim.Adam execute for
+ *   vt = net(torch.cat([xt, t[:, None]], -1)); loss.backward(); optim.step()
+ *   examples/images/cifar10/train_cifar10.py:141-151, torchcfm/models/models.py:10-21.
+ * Forward: x [B, dims[0]] already holds every input column (the caller concatenated the time);
+ * hidden: host array of n_layers-1 device buffers, hidden[l] [B, dims[l+1]] <- selu(z_l).
+ * Backward: acts: host array of n_layers device pointers (acts[0] = x, acts[l] = hidden[l-1]);
+ * dout [B, dims[n_layers]]; writes dW[l] [dims[l+1], dims[l]], db[l] [dims[l+1]] and, when dx is not
+ * NULL, dx [B, dims[0]].  Split-K partial sums are reduced in a fixed order (deterministic).
+ * ws: cfm_workspace_bytes(CFM_OP_MLP_TRAIN, B, widest layer incl. input/output, largest dims[l]*dims[l+1]). */
+int cfm_mlp_forward_train_f32(const float* x, const float* const* W, const float* const* b,
+                              const int* dims, int n_layers, int B, float* const* hidden,
+                              float* out, void* stream);
+int cfm_mlp_backward_f32(const float* const* acts, const float* const* W, const int* dims, int n_layers,
+                         int B, const float* dout, float* const* dW, float* const* db, float* dx,
+                         void* ws, void* stream);
+/* One torch.optim.Adam step (amsgrad=False, maximize=False) on n_tensors fp32 tensors in ONE launch.
+ * table: DEVICE array of n_tensors records {float* param; const float* grad; float* exp_avg;
+ * float* exp_avg_sq; uint64 numel} (40 bytes each).  step >= 1 is the step count AFTER this update
+ * (bias corrections 1 - beta^step are formed in double on the host, as torch does). */
+int cfm_adam_step_f32(const void* table, int n_tensors, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, int step, void* stream);
 
 /* K11 — ODE solve of dx/dt = MLP([x, t]) on a time grid (torchdyn-style).
  * Replaces NeuralODE(torch_wrapper(model), solver=...).trajectory(x, t_span)

@@ -424,6 +424,41 @@ def mlp_forward_f64(weights, biases, x, t=None):
     return h
 
 
+def mlp_backward_f64(weights, biases, x, dout):
+    """Gradients of sum(out * dout) for the Linear-SELU x3 + Linear network (models.py:10-21) in
+    float64: what autograd computes for the reference's loss.backward() (train_cifar10.py:149).
+    x: [B, in] (time column already concatenated).  Returns (out, dW list, db list, dx)."""
+    h = [np.asarray(x, dtype=np.float64)]
+    zs = []
+    n = len(weights)
+    for l, (W, b) in enumerate(zip(weights, biases)):
+        z = h[-1] @ np.asarray(W, dtype=np.float64).T + np.asarray(b, dtype=np.float64)
+        zs.append(z)
+        h.append(SELU_SCALE * np.where(z > 0, z, SELU_ALPHA * np.expm1(z)) if l != n - 1 else z)
+    g = np.asarray(dout, dtype=np.float64)
+    dW, db = [None] * n, [None] * n
+    for l in range(n - 1, -1, -1):
+        dW[l] = g.T @ h[l]
+        db[l] = g.sum(0)
+        g = g @ np.asarray(weights[l], dtype=np.float64)
+        if l > 0:
+            g = g * (SELU_SCALE * np.where(zs[l - 1] > 0, 1.0, SELU_ALPHA * np.exp(zs[l - 1])))
+    return h[-1], dW, db, g
+
+
+def adam_step_f64(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam's update (amsgrad=False) in float64: the reference's optimizer
+    (train_cifar10.py:93,150).  Returns the new (p, m, v)."""
+    p, g, m, v = (np.asarray(z, dtype=np.float64) for z in (p, g, m, v))
+    if weight_decay:
+        g = g + weight_decay * p
+    m = m + (1 - beta1) * (g - m)
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    denom = np.sqrt(v) / math.sqrt(bc2) + eps
+    return p - (lr / bc1) * m / denom, m, v
+
+
 # ----------------------------------------------------------------------------- ODE (K11)
 DP_C = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
 DP_A = [

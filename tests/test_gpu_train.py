@@ -1,0 +1,127 @@
+"""GPU (-m gpu): the training step of the MLP vector field on the HIP kernels — forward / backward
+through the autograd.Function against the float64 oracle (<= 1e-5 relative) and against PyTorch's own
+autograd on the same weights; the fused Adam against torch.optim.Adam (bit-equal state after one and
+after several steps on identical gradients) and against the float64 update."""
+import numpy as np
+import pytest
+import torch
+
+import cfm_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from cfm_amd import _lib
+    _lib.load()
+    return _lib.require_gpu()
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("B,d,w", [(96, 2, 64), (300, 50, 64), (512, 784, 512), (4096, 784, 512), (130, 7, 33)])
+def test_mlp_forward_backward_vs_f64_oracle(dev, B, d, w):
+    import cfm_amd
+    torch.manual_seed(B + d)
+    m = cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, d + 1, generator=g)
+    ut = torch.randn(B, d, generator=g)
+    xin = x.to(dev).requires_grad_(True)
+    vt = m(xin)
+    assert vt.grad_fn is not None and "MLPTrain" in type(vt.grad_fn).__name__      # the HIP path, not the module graph
+    loss = torch.mean((vt - ut.to(dev)) ** 2)
+    loss.backward()
+    Ws = [l.weight.detach().cpu().numpy() for l in m._linears()]
+    bs = [l.bias.detach().cpu().numpy() for l in m._linears()]
+    out_o = oracle.mlp_forward_f64(Ws, bs, x.numpy())
+    dout = 2.0 * (out_o - ut.numpy().astype(np.float64)) / (B * d)
+    _, dW, db, dx = oracle.mlp_backward_f64(Ws, bs, x.numpy(), dout)
+    assert _rel(vt.detach().cpu().numpy(), out_o) <= 1e-5
+    for l, lin in enumerate(m._linears()):
+        assert _rel(lin.weight.grad.cpu().numpy(), dW[l]) <= 1e-5, ("dW", l, _rel(lin.weight.grad.cpu().numpy(), dW[l]))
+        assert _rel(lin.bias.grad.cpu().numpy(), db[l]) <= 1e-5, ("db", l)
+    assert _rel(xin.grad.cpu().numpy(), dx) <= 1e-5
+    # and the same numbers as PyTorch's autograd over the module graph (hipBLASLt), to fp32 round-off
+    m2 = cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev)
+    m2.load_state_dict(m.state_dict())
+    m2.hip_training = False
+    x2 = x.to(dev).requires_grad_(True)
+    loss2 = torch.mean((m2(x2) - ut.to(dev)) ** 2)
+    loss2.backward()
+    assert float(loss) == pytest.approx(float(loss2), rel=1e-5)
+    for a, b in zip(m._linears(), m2._linears()):
+        assert _rel(a.weight.grad.cpu().numpy(), b.weight.grad.cpu().numpy().astype(np.float64)) <= 2e-5
+
+
+def test_backward_is_deterministic(dev):
+    import cfm_amd
+    torch.manual_seed(0)
+    m = cfm_amd.MLP(dim=784, time_varying=True, w=512).to(dev)
+    x = torch.randn(4096, 785, device=dev)
+    ut = torch.randn(4096, 784, device=dev)
+    grads = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        torch.mean((m(x) - ut) ** 2).backward()
+        grads.append([p.grad.clone() for p in m.parameters()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_bit_equal_to_torch_adam(dev, wd):
+    import cfm_amd
+    from cfm_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    a = cfm_amd.MLP(dim=50, time_varying=True, w=64).to(dev)
+    b = cfm_amd.MLP(dim=50, time_varying=True, w=64).to(dev)
+    b.load_state_dict(a.state_dict())
+    oa = FusedAdam(a.parameters(), lr=2e-4, weight_decay=wd)
+    ob = torch.optim.Adam(b.parameters(), lr=2e-4, weight_decay=wd)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    p0 = [p.detach().cpu().double().numpy() for p in a.parameters()]
+    first_grads = None
+    for step in range(1, 6):
+        grads = [torch.randn(p.shape, generator=g) * (10.0 ** float(torch.randint(-4, 2, (1,), generator=g))) for p in a.parameters()]
+        if first_grads is None:
+            first_grads = [x.double().numpy() for x in grads]
+        for pa, pb, gr in zip(a.parameters(), b.parameters(), grads):
+            pa.grad = gr.to(dev).clone(); pb.grad = gr.to(dev).clone()
+        oa.step(); ob.step()
+        for (pa, pb) in zip(a.parameters(), b.parameters()):
+            sa, sb = oa.state[pa], ob.state[pb]
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]), ("exp_avg", step)
+            assert torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), ("exp_avg_sq", step)
+            assert torch.equal(pa, pb), ("param", step, float((pa - pb).abs().max()))
+            assert int(sa["step"]) == int(sb["step"]) == step
+        if step == 1:
+            for pa, pz, gz in zip(a.parameters(), p0, first_grads):
+                ref, _, _ = oracle.adam_step_f64(pz, gz, np.zeros_like(pz), np.zeros_like(pz), 1, lr=2e-4, weight_decay=wd)
+                assert np.abs(pa.detach().cpu().double().numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_training_loop_matches_pytorch_loop(dev):
+    """Five OT-CFM steps with (HIP forward/backward + FusedAdam) and with (module graph + torch.optim.Adam)
+    from the same initial weights and the same batches: the losses agree to fp32 round-off."""
+    import cfm_amd
+    from cfm_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    a = cfm_amd.MLP(dim=2, time_varying=True, w=64).to(dev)
+    b = cfm_amd.MLP(dim=2, time_varying=True, w=64).to(dev)
+    b.load_state_dict(a.state_dict()); b.hip_training = False
+    oa, ob = FusedAdam(a.parameters()), torch.optim.Adam(b.parameters())
+    fm = cfm_amd.ExactOptimalTransportConditionalFlowMatcher(sigma=0.1)
+    la, lb = [], []
+    for k in range(5):
+        x0, x1 = oracle.config_inputs("C1", rank=k)
+        np.random.seed(k); torch.manual_seed(k)
+        t, xt, ut = fm.sample_location_and_conditional_flow(x0.to(dev), x1.to(dev))
+        for m, o, log in ((a, oa, la), (b, ob, lb)):
+            o.zero_grad(set_to_none=True)
+            loss = torch.mean((m(torch.cat([xt, t[:, None]], dim=-1)) - ut) ** 2)
+            loss.backward(); o.step(); log.append(float(loss))
+    np.testing.assert_allclose(la, lb, rtol=2e-4)

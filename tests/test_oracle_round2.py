@@ -93,3 +93,33 @@ def test_ode2_fixture_is_what_the_oracle_computes(golden_dir):
                     method="DOP853", rtol=1e-10, atol=1e-12)
     end = sol.y[:, -1].reshape(n, dd)
     assert np.abs(tr[-1] - end).max() <= 1e-3 * max(1.0, np.abs(end).max())       # O(atol = rtol = 1e-4)
+
+
+def test_mlp_backward_oracle_equals_torch_autograd_f64():
+    torch.manual_seed(2)
+    lins = [torch.nn.Linear(6, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 5)]
+    net = torch.nn.Sequential(lins[0], torch.nn.SELU(), lins[1], torch.nn.SELU(), lins[2], torch.nn.SELU(), lins[3]).double()
+    x = torch.randn(20, 6, dtype=torch.float64, requires_grad=True)
+    dout = torch.randn(20, 5, dtype=torch.float64)
+    out = net(x)
+    (out * dout).sum().backward()
+    Ws = [l.weight.detach().numpy() for l in lins]; bs = [l.bias.detach().numpy() for l in lins]
+    o, dW, db, dx = oracle.mlp_backward_f64(Ws, bs, x.detach().numpy(), dout.numpy())
+    np.testing.assert_allclose(o, out.detach().numpy(), rtol=1e-12, atol=1e-12)
+    for l, lin in enumerate(lins):
+        np.testing.assert_allclose(dW[l], lin.weight.grad.numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(db[l], lin.bias.grad.numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(dx, x.grad.numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_adam_oracle_equals_torch_adam_f64():
+    torch.manual_seed(4)
+    p = torch.nn.Parameter(torch.randn(7, 3, dtype=torch.float64))
+    p0 = p.detach().numpy().copy()
+    opt = torch.optim.Adam([p], lr=3e-3, weight_decay=0.02)
+    m = np.zeros_like(p0); v = np.zeros_like(p0); q = p0
+    for step in range(1, 4):
+        g = torch.randn(7, 3, dtype=torch.float64)
+        p.grad = g.clone(); opt.step()
+        q, m, v = oracle.adam_step_f64(q, g.numpy(), m, v, step, lr=3e-3, weight_decay=0.02)
+        np.testing.assert_allclose(q, p.detach().numpy(), rtol=1e-12, atol=1e-14)
