@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, in
                                                  const float* __restrict__ bias,
                                                  const float* __restrict__ tptr, float tval,
                                                  int t_per_row, int tcol, int B, int K, int N,
-                                                 float* __restrict__ out, int tiles_n) {
+                                                 float* __restrict__ out, int tiles_n,
+                                                 float* __restrict__ zout = nullptr) {
     constexpr int BK = 32, LD = BK + 1;
     constexpr int WM = BM / 2, WN = BN / 2;          // per-wave tile (2x2 waves)
     constexpr int MT = WM / 32, NT = WN / 32;        // 32x32 MFMA tiles per wave
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, in
                 if (gr >= B) continue;
                 float v = acc[m][nn][r] + bv;
                 if (tcol >= 0) v = fmaf(t_per_row ? tptr[gr] : tsc, wt, v);
+                if (zout) zout[(size_t)gr * N + gc] = v;      // training: the pre-activation (SELU' needs exp(z), not h)
                 if (ACT) v = selu_f(v);
                 out[(size_t)gr * N + gc] = v;
             }
@@ -131,16 +133,16 @@ extern "C" size_t cfm_mlp_ws_bytes_internal(int B, int width) {
 // one layer launch; picks the tile so the grid covers the chip
 static int launch_layer(const float* X, int lda, const float* W, int ldw, const float* bias,
                         const float* t, float tval, int t_per_row, int tcol, int B, int K, int N, float* out,
-                        bool act, hipStream_t s) {
+                        bool act, hipStream_t s, float* zout = nullptr) {
     const long tiles128 = (long)((B + 127) / 128) * ((N + 127) / 128);
     if (tiles128 >= 512) {
         const int tm = (B + 127) / 128, tn = (N + 127) / 128;
-        if (act) hipLaunchKernelGGL((mlp_layer<128, 128, true>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn);
-        else     hipLaunchKernelGGL((mlp_layer<128, 128, false>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn);
+        if (act) hipLaunchKernelGGL((mlp_layer<128, 128, true>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
+        else     hipLaunchKernelGGL((mlp_layer<128, 128, false>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
     } else {
         const int tm = (B + 63) / 64, tn = (N + 63) / 64;
-        if (act) hipLaunchKernelGGL((mlp_layer<64, 64, true>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn);
-        else     hipLaunchKernelGGL((mlp_layer<64, 64, false>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn);
+        if (act) hipLaunchKernelGGL((mlp_layer<64, 64, true>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
+        else     hipLaunchKernelGGL((mlp_layer<64, 64, false>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
     }
     return cfm_status();
 }
@@ -179,21 +181,24 @@ extern "C" int cfm_mlp_forward_f32(const float* x, const float* t, int t_per_row
                                 (hipStream_t)stream);
 }
 
-// Training forward: the same layer kernels, every hidden activation kept in a caller buffer
-// (hidden[l] : [B, dims[l + 1]], l = 0 .. n_layers - 2) for cfm_mlp_backward_f32 (mlp_train.hip).
+// Training forward: the same layer kernels, every hidden layer's activation h_l = selu(z_l) AND
+// pre-activation z_l kept in caller buffers (hidden[l], preact[l] : [B, dims[l + 1]], l = 0 .. n_layers - 2)
+// for cfm_mlp_backward_f32 (mlp_train.hip): h is the next layer's wgrad operand, z gives
+// selu'(z) = scale * alpha * exp(z) without the cancellation of h + scale * alpha.
 // x already holds every input column (the reference concatenates the time itself:
 // net(torch.cat([xt, t[:, None]], -1)), examples/images/cifar10/train_cifar10.py:147).
 extern "C" int cfm_mlp_forward_train_f32(const float* x, const float* const* W, const float* const* b,
                                          const int* dims, int n_layers, int B, float* const* hidden,
-                                         float* out, void* stream) {
+                                         float* const* preact, float* out, void* stream) {
     if (!x || !W || !b || !dims || !out || n_layers < 1 || B < 0) return CFM_EINVAL;
-    if (n_layers > 1 && !hidden) return CFM_EINVAL;
+    if (n_layers > 1 && (!hidden || !preact)) return CFM_EINVAL;
     if (B == 0) return 0;
     const float* cur = x;
     for (int l = 0; l < n_layers; ++l) {
-        float* dst = (l == n_layers - 1) ? out : hidden[l];
+        const bool last = (l == n_layers - 1);
+        float* dst = last ? out : hidden[l];
         int rc = launch_layer(cur, dims[l], W[l], dims[l], b[l], nullptr, 0.f, 0, -1, B, dims[l], dims[l + 1], dst,
-                              l != n_layers - 1, (hipStream_t)stream);
+                              !last, (hipStream_t)stream, last ? nullptr : preact[l]);
         if (rc) return rc;
         cur = dst;
     }

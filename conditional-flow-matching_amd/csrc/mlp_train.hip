@@ -5,10 +5,11 @@
 // execute in the reference's training loop (examples/images/cifar10/train_cifar10.py:141-151:
 // vt = net(...); loss = mean((vt - ut)^2); loss.backward(); optim.step()):
 //
-//   forward (training)   the same mlp_layer kernels as inference (mlp.hip); the activations
-//                        h_l = selu(z_l) are kept — selu'(z) is a function of h alone
-//                        (z > 0: scale; z <= 0: h + scale * alpha), so no pre-activation is stored
-//   dgrad                dz_{l-1} = (dz_l . W_l) * selu'(h_{l-1})     [B,N] x [N,K]  ("NN")
+//   forward (training)   the same mlp_layer kernels as inference (mlp.hip), keeping h_l = selu(z_l) (the
+//                        next wgrad's operand) and z_l (selu'(z) = scale * alpha * exp(z): recovering it from
+//                        h as h + scale * alpha cancels catastrophically for saturated units — measured
+//                        1.7e-3 relative error on the first layer's gradient at d = 784)
+//   dgrad                dz_{l-1} = (dz_l . W_l) * selu'(z_{l-1})     [B,N] x [N,K]  ("NN")
 //   wgrad                dW_l = dz_l^T . h_{l-1}                      [N,B] x [B,K]  ("TN"), the
 //                        contraction runs over the batch: split over S batch chunks so that a 512 x 512
 //                        gradient still fills the chip, partial sums reduced in a fixed order
@@ -28,9 +29,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SELU_SCALE 1.0507009873554805f
 #define SELU_ALPHA 1.6732632423543772f
 
-// selu'(z) from h = selu(z)
-__device__ __forceinline__ float selu_grad_from_out(float h) {
-    return h > 0.f ? SELU_SCALE : h + SELU_SCALE * SELU_ALPHA;
+// selu'(z)
+__device__ __forceinline__ float selu_grad(float z) {
+    return z > 0.f ? SELU_SCALE : (SELU_SCALE * SELU_ALPHA) * expf(z);
 }
 
 enum { EPI_PLAIN = 0, EPI_SELU_GRAD = 1 };
@@ -43,7 +44,7 @@ template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A, int lda,
                                                      const float* __restrict__ Bm, int ldb,
                                                      float* __restrict__ C, int ldc, size_t split_stride,
-                                                     const float* __restrict__ H,     // EPI_SELU_GRAD: activations [M, ldc]
+                                                     const float* __restrict__ H,     // EPI_SELU_GRAD: pre-activations [M, ldc]
                                                      int M, int N, int Kc, int k_chunk, int tiles_n) {
     constexpr int BK = 32;
     constexpr int LDA = A_KMAJOR ? BM : BK + 1, LDB = B_KMAJOR ? BN : BK + 1;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
                 const int gr = row0 + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (gr >= M) continue;
                 float v = acc[m][nn][r];
-                if (EPI == EPI_SELU_GRAD) v *= selu_grad_from_out(H[(size_t)gr * ldc + gc]);
+                if (EPI == EPI_SELU_GRAD) v *= selu_grad(H[(size_t)gr * ldc + gc]);
                 Cs[(size_t)gr * ldc + gc] = v;
             }
         }
@@ -199,12 +200,13 @@ static int launch_gemm(const float* A, int lda, const float* Bm, int ldb, float*
 }
 
 // Backward through all layers.  acts[l] = h_l (l = 0: the network input [B, dims[0]]; l = 1 .. n-1: the
-// saved hidden activations); dout [B, dims[n]].  Writes dW[l] ([dims[l+1], dims[l]]), db[l] and, if dx is
-// not NULL, the input gradient [B, dims[0]].
-extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const* W, const int* dims, int n_layers,
-                                    int B, const float* dout, float* const* dW, float* const* db, float* dx,
-                                    void* ws, void* stream) {
+// saved hidden activations), preact[l] = z_l for l = 1 .. n-1 (preact[0] unused); dout [B, dims[n]].
+// Writes dW[l] ([dims[l+1], dims[l]]), db[l] and, if dx is not NULL, the input gradient [B, dims[0]].
+extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const* preact, const float* const* W,
+                                    const int* dims, int n_layers, int B, const float* dout, float* const* dW,
+                                    float* const* db, float* dx, void* ws, void* stream) {
     if (!acts || !W || !dims || !dout || !dW || !db || n_layers < 1 || B < 0 || !ws) return CFM_EINVAL;
+    if (n_layers > 1 && !preact) return CFM_EINVAL;
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     int maxw = 0; size_t maxp = 0;
@@ -238,7 +240,7 @@ extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const
         // dgrad: dz_prev[B,K] = (dz[B,N] . W[N,K]) * selu'(h_prev)
         if (l > 0) {
             float* dst = gbuf[l & 1];
-            rc = launch_gemm<false, true, EPI_SELU_GRAD>(dz, N, W[l], K, dst, K, 0, acts[l], B, K, N, 1, s);
+            rc = launch_gemm<false, true, EPI_SELU_GRAD>(dz, N, W[l], K, dst, K, 0, preact[l], B, K, N, 1, s);
             if (rc) return rc;
             dz = dst;
         } else if (dx) {
@@ -259,6 +261,8 @@ extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const
 // The scalar factors arrive as the fp32 roundings of the Python doubles torch computes them with.
 struct AdamTable { float* p; const float* g; float* m; float* v; unsigned long long n; };
 
+// (the contraction pattern below is the one that is bit-equal to torch's foreach kernels on ROCm 7 /
+//  torch 2.10, found by probing the alternatives: tools/probe/adam_probe.py)
 __global__ __launch_bounds__(256) void adam_multi(const AdamTable* __restrict__ tab, int n_tensors,
                                                   float w1, float beta2, float w2, float bc2_sqrt, float eps,
                                                   float step_size, float weight_decay) {
@@ -269,11 +273,11 @@ __global__ __launch_bounds__(256) void adam_multi(const AdamTable* __restrict__ 
             const float p = T.p[e];
             if (weight_decay != 0.f) g = fmaf(weight_decay, p, g);
             float m = T.m[e], v = T.v[e];
-            m = fmaf(w1, g - m, m);
-            v = fmaf(w2 * g, g, v * beta2);
-            const float denom = sqrtf(v) / bc2_sqrt + eps;
+            m = fmaf(w1, g - m, m);                                   // lerp
+            v = fmaf(w2, __fmul_rn(g, g), __fmul_rn(v, beta2));       // mul_, then addcmul_
+            const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
             T.m[e] = m; T.v[e] = v;
-            T.p[e] = fmaf(-step_size, m / denom, p);
+            T.p[e] = fmaf(-step_size, __fdiv_rn(m, denom), p);        // addcdiv_
         }
     }
 }

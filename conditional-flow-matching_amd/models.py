@@ -30,14 +30,16 @@ class _MLPTrainFunction(torch.autograd.Function):
         B = xd.shape[0]
         dims = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
         hidden = [torch.empty((B, dims[l + 1]), dtype=torch.float32, device=dev) for l in range(n - 1)]
+        preact = [torch.empty((B, dims[l + 1]), dtype=torch.float32, device=dev) for l in range(n - 1)]
         out = torch.empty((B, dims[n]), dtype=torch.float32, device=dev)
         Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in Ws])
         bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs])
         hp = (ctypes.c_void_p * max(1, n - 1))(*([h.data_ptr() for h in hidden] or [0]))
+        zp = (ctypes.c_void_p * max(1, n - 1))(*([z.data_ptr() for z in preact] or [0]))
         cd = (ctypes.c_int * (n + 1))(*dims)
-        check(lib.cfm_mlp_forward_train_f32(ptr(xd), Wp, bp, cd, n, B, hp, ptr(out), stream_ptr()),
+        check(lib.cfm_mlp_forward_train_f32(ptr(xd), Wp, bp, cd, n, B, hp, zp, ptr(out), stream_ptr()),
               "cfm_mlp_forward_train_f32")
-        ctx.save_for_backward(xd, *hidden, *Ws)
+        ctx.save_for_backward(xd, *hidden, *preact, *Ws)
         ctx.dims, ctx.n = dims, n
         return out
 
@@ -47,7 +49,7 @@ class _MLPTrainFunction(torch.autograd.Function):
         lib = _lib.load()
         n, dims = ctx.n, ctx.dims
         saved = ctx.saved_tensors
-        acts, Ws = saved[:n], saved[n:]
+        acts, preact, Ws = saved[:n], saved[n:2 * n - 1], saved[2 * n - 1:]
         dev = dout.device
         B = dout.shape[0]
         dout = dout.contiguous().float()
@@ -58,11 +60,12 @@ class _MLPTrainFunction(torch.autograd.Function):
         maxp = max(dims[l] * dims[l + 1] for l in range(n))
         ws = _lib.workspace(_lib.OP_MLP_TRAIN, B, maxw, maxp, dev)
         ap = (ctypes.c_void_p * n)(*[a.data_ptr() for a in acts])
+        zp = (ctypes.c_void_p * n)(*([0] + [z.data_ptr() for z in preact]))
         Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in Ws])
         dWp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in dW])
         dbp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in db])
         cd = (ctypes.c_int * (n + 1))(*dims)
-        check(lib.cfm_mlp_backward_f32(ap, Wp, cd, n, B, ptr(dout), dWp, dbp, ptr(dx), ptr(ws), stream_ptr()),
+        check(lib.cfm_mlp_backward_f32(ap, zp, Wp, cd, n, B, ptr(dout), dWp, dbp, ptr(dx), ptr(ws), stream_ptr()),
               "cfm_mlp_backward_f32")
         grads = [dx]
         for l in range(n):

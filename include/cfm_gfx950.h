@@ -233,17 +233,18 @@ int cfm_mlp_forward_f32(const float* x, const float* t, int t_per_row,
  *   vt = net(torch.cat([xt, t[:, None]], -1)); loss.backward(); optim.step()
  *   examples/images/cifar10/train_cifar10.py:141-151, torchcfm/models/models.py:10-21.
  * Forward: x [B, dims[0]] already holds every input column (the caller concatenated the time);
- * hidden: host array of n_layers-1 device buffers, hidden[l] [B, dims[l+1]] <- selu(z_l).
- * Backward: acts: host array of n_layers device pointers (acts[0] = x, acts[l] = hidden[l-1]);
+ * hidden / preact: host arrays of n_layers-1 device buffers [B, dims[l+1]] <- selu(z_l) / z_l.
+ * Backward: acts / preact: host arrays of n_layers device pointers (acts[0] = x, acts[l] = hidden[l-1],
+ * preact[l] = the forward's preact[l-1], preact[0] unused);
  * dout [B, dims[n_layers]]; writes dW[l] [dims[l+1], dims[l]], db[l] [dims[l+1]] and, when dx is not
  * NULL, dx [B, dims[0]].  Split-K partial sums are reduced in a fixed order (deterministic).
  * ws: cfm_workspace_bytes(CFM_OP_MLP_TRAIN, B, widest layer incl. input/output, largest dims[l]*dims[l+1]). */
 int cfm_mlp_forward_train_f32(const float* x, const float* const* W, const float* const* b,
                               const int* dims, int n_layers, int B, float* const* hidden,
-                              float* out, void* stream);
-int cfm_mlp_backward_f32(const float* const* acts, const float* const* W, const int* dims, int n_layers,
-                         int B, const float* dout, float* const* dW, float* const* db, float* dx,
-                         void* ws, void* stream);
+                              float* const* preact, float* out, void* stream);
+int cfm_mlp_backward_f32(const float* const* acts, const float* const* preact, const float* const* W,
+                         const int* dims, int n_layers, int B, const float* dout, float* const* dW,
+                         float* const* db, float* dx, void* ws, void* stream);
 /* One torch.optim.Adam step (amsgrad=False, maximize=False) on n_tensors fp32 tensors in ONE launch.
  * table: DEVICE array of n_tensors records {float* param; const float* grad; float* exp_avg;
  * float* exp_avg_sq; uint64 numel} (40 bytes each).  step >= 1 is the step count AFTER this update
