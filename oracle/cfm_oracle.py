@@ -424,10 +424,16 @@ def mlp_forward_f64(weights, biases, x, t=None):
     return h
 
 
-def mlp_backward_f64(weights, biases, x, dout):
+def mlp_backward_f64(weights, biases, x, dout, preact=None):
     """Gradients of sum(out * dout) for the Linear-SELU x3 + Linear network (models.py:10-21) in
     float64: what autograd computes for the reference's loss.backward() (train_cifar10.py:149).
-    x: [B, in] (time column already concatenated).  Returns (out, dW list, db list, dx)."""
+    x: [B, in] (time column already concatenated).  Returns (out, dW list, db list, dx).
+
+    SELU' jumps at 0 (scale vs scale * alpha), so a pre-activation within rounding of 0 lands on
+    different sides in float32 and float64 and the gradients then differ by O(1 / B) — in ANY
+    float32 implementation, PyTorch's included.  `preact` (the float32 forward's own hidden
+    pre-activations, one array per hidden layer) pins the branch: SELU' is then evaluated at those
+    values, which is what a float32 backward is entitled to be compared with."""
     h = [np.asarray(x, dtype=np.float64)]
     zs = []
     n = len(weights)
@@ -442,7 +448,8 @@ def mlp_backward_f64(weights, biases, x, dout):
         db[l] = g.sum(0)
         g = g @ np.asarray(weights[l], dtype=np.float64)
         if l > 0:
-            g = g * (SELU_SCALE * np.where(zs[l - 1] > 0, 1.0, SELU_ALPHA * np.exp(zs[l - 1])))
+            zz = zs[l - 1] if preact is None else np.asarray(preact[l - 1], dtype=np.float64)
+            g = g * (SELU_SCALE * np.where(zz > 0, 1.0, SELU_ALPHA * np.exp(np.minimum(zz, 0.0))))
     return h[-1], dW, db, g
 
 

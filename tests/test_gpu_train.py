@@ -22,39 +22,77 @@ def _rel(a, b):
     return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def _abi_step(m, x, ut, dev):
+    """cfm_mlp_forward_train_f32 + cfm_mlp_backward_f32 through ctypes (what the autograd.Function calls),
+    returning everything including the float32 pre-activations."""
+    import ctypes
+    from cfm_amd import _lib
+    lib = _lib.load()
+    lins = m._linears()
+    n = len(lins)
+    Ws = [l.weight.detach().contiguous() for l in lins]; bs = [l.bias.detach().contiguous() for l in lins]
+    dims = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
+    B = x.shape[0]
+    xd = x.to(dev).contiguous()
+    hidden = [torch.empty((B, dims[l + 1]), device=dev) for l in range(n - 1)]
+    preact = [torch.empty((B, dims[l + 1]), device=dev) for l in range(n - 1)]
+    out = torch.empty((B, dims[n]), device=dev)
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() if t is not None else 0 for t in ts])
+    cd = (ctypes.c_int * (n + 1))(*dims)
+    _lib.check(lib.cfm_mlp_forward_train_f32(_lib.ptr(xd), arr(Ws), arr(bs), cd, n, B, arr(hidden), arr(preact),
+                                             _lib.ptr(out), _lib.stream_ptr()), "fwd")
+    dout = (2.0 / (B * dims[n])) * (out - ut.to(dev))
+    dW = [torch.empty_like(w) for w in Ws]; db = [torch.empty(w.shape[0], device=dev) for w in Ws]
+    dx = torch.empty_like(xd)
+    ws = torch.empty(lib.cfm_workspace_bytes(_lib.OP_MLP_TRAIN, B, max(dims), max(dims[l] * dims[l + 1] for l in range(n))),
+                     dtype=torch.uint8, device=dev)
+    _lib.check(lib.cfm_mlp_backward_f32(arr([xd] + hidden), arr([None] + preact), arr(Ws), cd, n, B, _lib.ptr(dout),
+                                        arr(dW), arr(db), _lib.ptr(dx), _lib.ptr(ws), _lib.stream_ptr()), "bwd")
+    return out, dout, [z.cpu().numpy() for z in preact], dW, db, dx
+
+
 @pytest.mark.parametrize("B,d,w", [(96, 2, 64), (300, 50, 64), (512, 784, 512), (4096, 784, 512), (130, 7, 33)])
 def test_mlp_forward_backward_vs_f64_oracle(dev, B, d, w):
+    """The backward kernels against the float64 oracle, SELU' branch pinned by the float32 forward's own
+    pre-activations (see cfm_oracle.mlp_backward_f64); then the autograd.Function returns exactly these
+    gradients, and agrees with PyTorch's autograd over the module graph."""
     import cfm_amd
     torch.manual_seed(B + d)
     m = cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, d + 1, generator=g)
     ut = torch.randn(B, d, generator=g)
+    out, dout, preact, dW, db, dx = _abi_step(m, x, ut, dev)
+    Ws = [l.weight.detach().cpu().numpy() for l in m._linears()]
+    bs = [l.bias.detach().cpu().numpy() for l in m._linears()]
+    out_o, dW_o, db_o, dx_o = oracle.mlp_backward_f64(Ws, bs, x.numpy(), dout.cpu().numpy(), preact=preact)
+    assert _rel(out.cpu().numpy(), out_o) <= 1e-5
+    for l in range(len(Ws)):
+        assert _rel(dW[l].cpu().numpy(), dW_o[l]) <= 1e-5, ("dW", l, _rel(dW[l].cpu().numpy(), dW_o[l]))
+        assert _rel(db[l].cpu().numpy(), db_o[l]) <= 1e-5, ("db", l, _rel(db[l].cpu().numpy(), db_o[l]))
+    assert _rel(dx.cpu().numpy(), dx_o) <= 1e-5, _rel(dx.cpu().numpy(), dx_o)
+    # the autograd.Function: same kernels, same bits
     xin = x.to(dev).requires_grad_(True)
     vt = m(xin)
     assert vt.grad_fn is not None and "MLPTrain" in type(vt.grad_fn).__name__      # the HIP path, not the module graph
     loss = torch.mean((vt - ut.to(dev)) ** 2)
     loss.backward()
-    Ws = [l.weight.detach().cpu().numpy() for l in m._linears()]
-    bs = [l.bias.detach().cpu().numpy() for l in m._linears()]
-    out_o = oracle.mlp_forward_f64(Ws, bs, x.numpy())
-    dout = 2.0 * (out_o - ut.numpy().astype(np.float64)) / (B * d)
-    _, dW, db, dx = oracle.mlp_backward_f64(Ws, bs, x.numpy(), dout)
-    assert _rel(vt.detach().cpu().numpy(), out_o) <= 1e-5
+    assert torch.equal(vt.detach(), out)
     for l, lin in enumerate(m._linears()):
-        assert _rel(lin.weight.grad.cpu().numpy(), dW[l]) <= 1e-5, ("dW", l, _rel(lin.weight.grad.cpu().numpy(), dW[l]))
-        assert _rel(lin.bias.grad.cpu().numpy(), db[l]) <= 1e-5, ("db", l)
-    assert _rel(xin.grad.cpu().numpy(), dx) <= 1e-5
-    # and the same numbers as PyTorch's autograd over the module graph (hipBLASLt), to fp32 round-off
+        torch.testing.assert_close(lin.weight.grad, dW[l], rtol=1e-6, atol=1e-9)     # (dout formed by eager ops here)
+        torch.testing.assert_close(lin.bias.grad, db[l], rtol=1e-5, atol=1e-9)
+    # PyTorch's own autograd (module graph, hipBLASLt): equal up to float32 round-off — and up to SELU' kink
+    # flips, which is why the bound is on the loss and on a robust (median) statistic of the gradients
     m2 = cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev)
     m2.load_state_dict(m.state_dict())
     m2.hip_training = False
     x2 = x.to(dev).requires_grad_(True)
     loss2 = torch.mean((m2(x2) - ut.to(dev)) ** 2)
     loss2.backward()
-    assert float(loss) == pytest.approx(float(loss2), rel=1e-5)
+    assert float(loss.detach()) == pytest.approx(float(loss2.detach()), rel=1e-5)
     for a, b in zip(m._linears(), m2._linears()):
-        assert _rel(a.weight.grad.cpu().numpy(), b.weight.grad.cpu().numpy().astype(np.float64)) <= 2e-5
+        ga, gb = a.weight.grad.cpu().double().numpy(), b.weight.grad.cpu().double().numpy()
+        assert np.median(np.abs(ga - gb)) <= 1e-5 * np.abs(gb).max()
 
 
 def test_backward_is_deterministic(dev):
