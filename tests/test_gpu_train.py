@@ -82,7 +82,8 @@ def test_mlp_forward_backward_vs_f64_oracle(dev, B, d, w):
         torch.testing.assert_close(lin.weight.grad, dW[l], rtol=1e-6, atol=1e-9)     # (dout formed by eager ops here)
         torch.testing.assert_close(lin.bias.grad, db[l], rtol=1e-5, atol=1e-9)
     # PyTorch's own autograd (module graph, hipBLASLt): equal up to float32 round-off — and up to SELU' kink
-    # flips, which is why the bound is on the loss and on a robust (median) statistic of the gradients
+    # flips (one flipped unit-sample moves a whole gradient by O(1 / B)), hence the bound on the loss and on the
+    # direction of the gradients
     m2 = cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev)
     m2.load_state_dict(m.state_dict())
     m2.hip_training = False
@@ -91,8 +92,8 @@ def test_mlp_forward_backward_vs_f64_oracle(dev, B, d, w):
     loss2.backward()
     assert float(loss.detach()) == pytest.approx(float(loss2.detach()), rel=1e-5)
     for a, b in zip(m._linears(), m2._linears()):
-        ga, gb = a.weight.grad.cpu().double().numpy(), b.weight.grad.cpu().double().numpy()
-        assert np.median(np.abs(ga - gb)) <= 1e-5 * np.abs(gb).max()
+        ga, gb = a.weight.grad.cpu().double().numpy().ravel(), b.weight.grad.cpu().double().numpy().ravel()
+        assert ga @ gb / np.sqrt((ga @ ga) * (gb @ gb)) >= 1.0 - 1e-4
 
 
 def test_backward_is_deterministic(dev):
