@@ -14,7 +14,9 @@
 //                        contraction runs over the batch: split over S batch chunks so that a 512 x 512
 //                        gradient still fills the chip, partial sums reduced in a fixed order
 //                        (deterministic, no atomics)
-//   bias grad            db_l = column sums of dz_l
+//   bias grad            db_l = column sums of dz_l, accumulated by the wgrad workgroups of the first tile column
+//                        from the dz tile they stage anyway; every split-K partial of the pass (weights and
+//                        biases of all layers) is reduced by ONE table-driven launch
 //   Adam                 one launch for every parameter tensor of the model (pointer table), torch.optim.Adam
 //                        arithmetic (lerp / addcmul / addcdiv order, bias corrections as Python doubles)
 //
@@ -45,7 +47,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
                                                      const float* __restrict__ Bm, int ldb,
                                                      float* __restrict__ C, int ldc, size_t split_stride,
                                                      const float* __restrict__ H,     // EPI_SELU_GRAD: pre-activations [M, ldc]
-                                                     int M, int N, int Kc, int k_chunk, int tiles_n) {
+                                                     int M, int N, int Kc, int k_chunk, int tiles_n,
+                                                     float* __restrict__ colsum = nullptr) {   // A_KMAJOR: sum_k A(i, k) per split -> colsum[s * M + i]
     constexpr int BK = 32;
     constexpr int LDA = A_KMAJOR ? BM : BK + 1, LDB = B_KMAJOR ? BN : BK + 1;
     constexpr int WM = BM / 2, WN = BN / 2;          // per-wave tile (2x2 waves)
@@ -102,11 +105,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
         }
     };
 
+    // bias gradient rides along: the workgroups of the first tile column add up their A tile (dz) over k
+    const bool do_colsum = A_KMAJOR && colsum != nullptr && tn == 0 && tid < BM;
+    float csum = 0.f;
     if (k_begin < k_end) fetch(k_begin);
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         stash();
         __syncthreads();
         if (k0 + BK < k_end) fetch(k0 + BK);            // in flight while the MFMAs run
+        if (A_KMAJOR && do_colsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDA + tid];
+        }
         const int fr = lane & 31, fk = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -129,6 +139,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
         }
         __syncthreads();
     }
+    if (A_KMAJOR && do_colsum && row0 + tid < M) colsum[(size_t)blockIdx.y * M + row0 + tid] = csum;
     // epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cs = C + (size_t)blockIdx.y * split_stride;
 #pragma unroll
@@ -149,52 +160,44 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
     }
 }
 
-// grad[e] = sum_s partial[s][e] in split order (deterministic)
-__global__ __launch_bounds__(256) void reduce_splits(const float* __restrict__ partial, size_t stride, int S,
-                                                     float* __restrict__ out, size_t n) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
-        float v = partial[e];
-        for (int s = 1; s < S; ++s) v += partial[(size_t)s * stride + e];
-        out[e] = v;
+// out[e] = sum_s partial[s * stride + e] in split order (deterministic), for every tensor of the table
+// (all weight and bias gradients of a backward pass in ONE launch)
+struct ReduceJob { const float* partial; float* out; unsigned long long stride, n; int S, pad; };
+#define MLP_MAX_LAYERS 16
+struct ReduceTable { ReduceJob job[2 * MLP_MAX_LAYERS]; int count; };
+
+__global__ __launch_bounds__(256) void reduce_splits_multi(ReduceTable T) {
+    for (int q = blockIdx.y; q < T.count; q += gridDim.y) {
+        const ReduceJob J = T.job[q];
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < J.n; e += (size_t)gridDim.x * 256) {
+            float v = J.partial[e];
+            for (int s = 1; s < J.S; ++s) v += J.partial[(size_t)s * J.stride + e];
+            J.out[e] = v;
+        }
     }
 }
 
-// db[n] = sum_b dz[b][n]: a workgroup owns 64 columns x a row slice, partial sums in a fixed order
-// (rows strided over the 4 waves, then the 4 waves, then the row slices by reduce_splits)
-__global__ __launch_bounds__(256) void bias_grad_partial(const float* __restrict__ dz, int B, int N,
-                                                         float* __restrict__ partial, int rows_per_slice) {
-    __shared__ float sh[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * rows_per_slice;
-    const int r1 = (r0 + rows_per_slice < B) ? r0 + rows_per_slice : B;
-    float acc = 0.f;
-    if (c < N)
-        for (int r = r0 + wv; r < r1; r += 4) acc += dz[(size_t)r * N + c];
-    sh[wv][lane] = acc;
-    __syncthreads();
-    if (wv == 0 && c < N) partial[(size_t)blockIdx.y * N + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
-}
-
+#define MLP_MAX_SPLITS 32
 extern "C" size_t cfm_mlp_train_ws_bytes_internal(int B, int maxw, int max_params) {
-    // two [B, maxw] gradient buffers + split-K partials of the largest weight + bias partials
-    return sizeof(float) * ((size_t)2 * B * maxw + (size_t)32 * max_params + (size_t)64 * maxw) + 1024;
+    // two [B, maxw] gradient buffers + per-layer split-K partials (weights and biases; <= MLP_MAX_LAYERS layers
+    // are sized here by the largest one: callers pass the largest dims[l] * dims[l+1])
+    return sizeof(float) * ((size_t)2 * B * maxw + (size_t)MLP_MAX_SPLITS * ((size_t)max_params + maxw) * 4) + 1024;
 }
 
 template <bool AK, bool BK_, int EPI>
 static int launch_gemm(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, size_t split_stride,
-                       const float* H, int M, int N, int Kc, int S, hipStream_t s) {
+                       const float* H, int M, int N, int Kc, int S, hipStream_t s, float* colsum = nullptr) {
     int k_chunk = (Kc + S - 1) / S;
     k_chunk = (k_chunk + 31) / 32 * 32;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t128 * S >= 192) {
         const int tm = (M + 127) / 128, tn = (N + 127) / 128;
         hipLaunchKernelGGL((gemm_f32_mfma<128, 128, AK, BK_, EPI>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
-                           split_stride, H, M, N, Kc, k_chunk, tn);
+                           split_stride, H, M, N, Kc, k_chunk, tn, colsum);
     } else {
         const int tm = (M + 63) / 64, tn = (N + 63) / 64;
         hipLaunchKernelGGL((gemm_f32_mfma<64, 64, AK, BK_, EPI>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
-                           split_stride, H, M, N, Kc, k_chunk, tn);
+                           split_stride, H, M, N, Kc, k_chunk, tn, colsum);
     }
     return cfm_status();
 }
@@ -202,10 +205,12 @@ static int launch_gemm(const float* A, int lda, const float* Bm, int ldb, float*
 // Backward through all layers.  acts[l] = h_l (l = 0: the network input [B, dims[0]]; l = 1 .. n-1: the
 // saved hidden activations), preact[l] = z_l for l = 1 .. n-1 (preact[0] unused); dout [B, dims[n]].
 // Writes dW[l] ([dims[l+1], dims[l]]), db[l] and, if dx is not NULL, the input gradient [B, dims[0]].
+// Launches: per layer one wgrad (bias column sums ride along) and one dgrad, then ONE reduction of every
+// split-K partial (weights and biases of all layers).
 extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const* preact, const float* const* W,
                                     const int* dims, int n_layers, int B, const float* dout, float* const* dW,
                                     float* const* db, float* dx, void* ws, void* stream) {
-    if (!acts || !W || !dims || !dout || !dW || !db || n_layers < 1 || B < 0 || !ws) return CFM_EINVAL;
+    if (!acts || !W || !dims || !dout || !dW || !db || n_layers < 1 || n_layers > MLP_MAX_LAYERS || B < 0 || !ws) return CFM_EINVAL;
     if (n_layers > 1 && !preact) return CFM_EINVAL;
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -213,31 +218,26 @@ extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const
     for (int l = 0; l <= n_layers; ++l) maxw = dims[l] > maxw ? dims[l] : maxw;
     for (int l = 0; l < n_layers; ++l) { const size_t p = (size_t)dims[l] * dims[l + 1]; maxp = p > maxp ? p : maxp; }
     float* gbuf[2] = {(float*)ws, (float*)ws + (size_t)B * maxw};
-    float* part = gbuf[1] + (size_t)B * maxw;
-    float* bpart = part + (size_t)32 * maxp;
+    float* pool = gbuf[1] + (size_t)B * maxw;
+    const size_t pool_floats = (size_t)MLP_MAX_SPLITS * (maxp + maxw) * 4;
+    size_t used = 0;
+    ReduceTable T; T.count = 0;
     const float* dz = dout;
     for (int l = n_layers - 1; l >= 0; --l) {
         const int K = dims[l], N = dims[l + 1];
-        // wgrad: dW[N,K] = dz^T[N,B] . h[B,K], contraction over the batch, S splits
+        // wgrad: dW[N,K] = dz^T[N,B] . h[B,K], contraction over the batch, S splits; db partials ride along
         const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
         int S = 1;
-        while (S < 32 && tiles * S < 256 && B / (2 * S) >= 64) S *= 2;
-        int rc = launch_gemm<true, true, EPI_PLAIN>(dz, N, acts[l], K, S > 1 ? part : dW[l], K, (size_t)N * K, nullptr,
-                                                    N, K, B, S, s);
+        while (S < MLP_MAX_SPLITS && tiles * S < 256 && B / (2 * S) >= 64) S *= 2;
+        const size_t np = (size_t)N * K;
+        if (used + (size_t)S * (np + N) > pool_floats) return CFM_EINVAL;      // more layers than the workspace was sized for
+        float* part = pool + used; used += (size_t)S * np;
+        float* bpart = pool + used; used += (size_t)S * N;
+        int rc = launch_gemm<true, true, EPI_PLAIN>(dz, N, acts[l], K, part, K, np, nullptr, N, K, B, S, s, bpart);
         if (rc) return rc;
-        if (S > 1) {
-            const size_t np = (size_t)N * K;
-            hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((np + 255) / 256 < 2048 ? (np + 255) / 256 : 2048)), dim3(256), 0, s,
-                               part, np, S, dW[l], np);
-        }
-        // bias grad
-        int slices = (B + 255) / 256; if (slices > 64) slices = 64;
-        const int rps = (B + slices - 1) / slices;
-        hipLaunchKernelGGL(bias_grad_partial, dim3((N + 63) / 64, slices), dim3(256), 0, s, dz, B, N, bpart, rps);
-        hipLaunchKernelGGL(reduce_splits, dim3((N + 255) / 256), dim3(256), 0, s, bpart, (size_t)N, slices, db[l], (size_t)N);
-        rc = cfm_status();
-        if (rc) return rc;
-        // dgrad: dz_prev[B,K] = (dz[B,N] . W[N,K]) * selu'(h_prev)
+        T.job[T.count++] = ReduceJob{part, dW[l], np, np, S, 0};
+        T.job[T.count++] = ReduceJob{bpart, db[l], (unsigned long long)N, (unsigned long long)N, S, 0};
+        // dgrad: dz_prev[B,K] = (dz[B,N] . W[N,K]) * selu'(z_prev)
         if (l > 0) {
             float* dst = gbuf[l & 1];
             rc = launch_gemm<false, true, EPI_SELU_GRAD>(dz, N, W[l], K, dst, K, 0, preact[l], B, K, N, 1, s);
@@ -248,7 +248,8 @@ extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const
             if (rc) return rc;
         }
     }
-    return 0;
+    hipLaunchKernelGGL(reduce_splits_multi, dim3(256, T.count), dim3(256), 0, s, T);
+    return cfm_status();
 }
 
 // ------------------------------------------------------------------- Adam ----
