@@ -201,3 +201,63 @@ extern "C" int cfm_gather_rows(const void* src, const int64_t* idx, int n, size_
                        (const unsigned char*)src, idx, n, row_bytes, (unsigned char*)out, w16);
     return cfm_status();
 }
+
+// ---------------------------------------------------------------- SDE step ----
+// One Euler-Maruyama step of dy = (v + s) dt + g dW (SF2M sampling: the reference integrates
+// f = drift(x) + score(x), g = sigma with torchsde.sdeint(..., method="euler"),
+// examples/2D_tutorials/SF2M_tutorial.ipynb cell 5; runner/src/models/components/solver.py:157-182):
+//   y <- y + dt * (v [+ s]) + g * sqrt_dt * xi
+// v, s: drift and score network outputs, xi ~ N(0, 1) drawn by the caller's generator.  In place.
+__global__ __launch_bounds__(256) void sde_em_step_kernel(float* __restrict__ y, const float* __restrict__ v,
+                                                          const float* __restrict__ s, const float* __restrict__ xi,
+                                                          float dt, float g_sqrt_dt, float ssign, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        float f = v[e];
+        if (s) f = fmaf(ssign, s[e], f);
+        float r = fmaf(dt, f, y[e]);
+        if (xi) r = fmaf(g_sqrt_dt, xi[e], r);
+        y[e] = r;
+    }
+}
+
+extern "C" int cfm_sde_em_step_f32(float* y, const float* v, const float* s, const float* xi, double dt, double g,
+                                   double score_sign, size_t n, void* stream) {
+    if (!y || !v) return CFM_EINVAL;
+    if (n == 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sde_em_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, v, s, xi, (float)dt,
+                       (float)(g * sqrt(fabs(dt))), (float)score_sign, n);
+    return cfm_status();
+}
+
+// ------------------------------------------------------- mixture-RBF sums ----
+// sum over a squared-distance matrix D of sum_sigma exp(-D / (2 sigma^2)): the three kernel sums of the
+// mixture-RBF MMD (runner/src/models/components/mmd.py:43-63,80-110) without materialising any kernel
+// matrix.  fp64 accumulation, one atomic per workgroup.  out[0] += the sum (caller zeroes it).
+__global__ __launch_bounds__(256) void rbf_mix_sum_kernel(const float* __restrict__ D, size_t n,
+                                                          const float* __restrict__ gammas, int ng,
+                                                          double* __restrict__ out) {
+    double acc = 0.0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const float dsq = D[e];
+        float k = 0.f;
+        for (int q = 0; q < ng; ++q) k += expf(-gammas[q] * dsq);
+        acc += (double)k;
+    }
+    acc = wave_sum_d(acc);
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+extern "C" int cfm_rbf_mix_sum_f32(const float* D, size_t n, const float* gammas, int n_gamma, double* out,
+                                   void* stream) {
+    if (!D || !gammas || !out || n_gamma < 1) return CFM_EINVAL;
+    if (n == 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rbf_mix_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, D, n, gammas, n_gamma, out);
+    return cfm_status();
+}

@@ -252,6 +252,17 @@ int cfm_mlp_backward_f32(const float* const* acts, const float* const* preact, c
 int cfm_adam_step_f32(const void* table, int n_tensors, double lr, double beta1, double beta2, double eps,
                       double weight_decay, int step, void* stream);
 
+/* SF2M sampling — one Euler-Maruyama step  y <- y + dt (v + score_sign * s) + g sqrt(|dt|) xi,  in place.
+ * Replaces the step torchsde.sdeint(sde, x0, ts, method="euler") takes for the reference's SDE
+ * (f = drift + score, g = sigma): examples/2D_tutorials/SF2M_tutorial.ipynb cell 5,
+ * runner/src/models/components/solver.py:129-139,157-182.  s and xi may be NULL. */
+int cfm_sde_em_step_f32(float* y, const float* v, const float* s, const float* xi, double dt, double g,
+                        double score_sign, size_t n, void* stream);
+/* Mixture-RBF kernel sum  out[0] += sum_e sum_q exp(-gammas[q] * D[e])  over a squared-distance matrix D
+ * (n elements, device fp32; gammas device fp32[n_gamma]; out device double, zeroed by the caller).
+ * Replaces the K_XX / K_XY / K_YY matrices of mix_rbf_mmd2: runner/src/models/components/mmd.py:43-63,80-110. */
+int cfm_rbf_mix_sum_f32(const float* D, size_t n, const float* gammas, int n_gamma, double* out, void* stream);
+
 /* K11 — ODE solve of dx/dt = MLP([x, t]) on a time grid (torchdyn-style).
  * Replaces NeuralODE(torch_wrapper(model), solver=...).trajectory(x, t_span)
  *   call sites: examples/2D_tutorials/Flow_matching_tutorial.ipynb cells 11/16,

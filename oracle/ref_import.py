@@ -36,3 +36,28 @@ def import_reference():
         spec.loader.exec_module(m)
         mods[name] = m
     return mods["conditional_flow_matching"], mods["optimal_transport"]
+
+
+def import_runner_metrics():
+    """The reference's evaluation metrics module (runner/src/models/components/distribution_distances.py
+    with its siblings mmd.py / optimal_transport.py), unmodified, POT stand-in on the path."""
+    if not os.path.isdir(os.path.join(REFERENCE_ROOT, "runner")):
+        raise ImportError("reference runner tree not present")
+    here = os.path.dirname(os.path.abspath(__file__))
+    stand = os.path.join(here, "ot_standin")
+    if stand not in sys.path:
+        sys.path.insert(0, stand)
+    import importlib.util
+    import types
+    base = os.path.join(REFERENCE_ROOT, "runner", "src", "models", "components")
+    pkg = types.ModuleType("runner_ref_components")
+    pkg.__path__ = [base]
+    sys.modules["runner_ref_components"] = pkg
+    out = {}
+    for name in ("mmd", "optimal_transport", "distribution_distances"):
+        spec = importlib.util.spec_from_file_location(f"runner_ref_components.{name}", os.path.join(base, f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"runner_ref_components.{name}"] = m
+        spec.loader.exec_module(m)
+        out[name] = m
+    return out["distribution_distances"], out["mmd"]

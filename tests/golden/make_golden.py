@@ -14,6 +14,8 @@ Fixture provenance
                       real, solver = stand-in).
   sinkhorn_cases.npz  oracle float64 log-domain Sinkhorn (POT loop semantics) + restated Knopp.
   ode_cases.npz       oracle torchdyn-style euler / dopri5 on a seeded MLP field.
+  metrics_cases.npz   (round 2) reference runner metrics (compute_distribution_distances, mix_rbf_mmd2)
+                      imported unmodified from runner/src/models/components/.
   ode2_cases.npz      (round 2) d = 50 / d = 784 fields and controller cases with rejected steps,
                       with the accept / reject logs of two independent restatements.
   ub_cases.npz        reference OTPlanSampler("unbalanced" / "partial") wrapper over the restated
@@ -205,6 +207,30 @@ def ode2_cases():
     return out
 
 
+def metrics_cases():
+    """Round 2: the reference's own evaluation metrics (runner/src/models/components/
+    distribution_distances.py, imported unmodified) on seeded point clouds: regular [B, times, d]
+    tensors and a jagged list."""
+    dd, mmd = ref_import.import_runner_metrics()
+    out = {}
+    g = torch.Generator().manual_seed(123)
+    pred = torch.randn(96, 3, 5, generator=g)
+    true = torch.randn(96, 3, 5, generator=g) * 1.3 + 0.4
+    names, vals = dd.compute_distribution_distances(pred, true)
+    out["pred"], out["true"] = pred.numpy(), true.numpy()
+    out["names"] = np.array(names); out["values"] = np.array(vals, dtype=np.float64)
+    jag = [torch.randn(n, 5, generator=g) + 0.2 * k for k, n in enumerate((96, 96, 96))]
+    names_j, vals_j = dd.compute_distribution_distances(pred, jag)
+    for k, t in enumerate(jag):
+        out[f"jag{k}"] = t.numpy()
+    out["names_jagged"] = np.array(names_j); out["values_jagged"] = np.array(vals_j, dtype=np.float64)
+    one_p, one_t = pred[:, :1], true[:, :1]
+    names_1, vals_1 = dd.compute_distribution_distances(one_p, one_t)
+    out["names_single"] = np.array(names_1); out["values_single"] = np.array(vals_1, dtype=np.float64)
+    out["rbf_only"] = float(mmd.mix_rbf_mmd2(pred[:, 0], true[:, 0], sigma_list=[0.5, 2.0]))
+    return out
+
+
 def ub_cases(ot):
     """Reference OTPlanSampler(method="unbalanced" | "partial") wrapper (real code) over the
     stand-in's restated POT loops, plus the docstring KAT of the in-repo unbalanced statement."""
@@ -239,6 +265,10 @@ def ub_cases(ot):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":    # the reference's runner metrics, imported unmodified
+        np.savez_compressed(os.path.join(HERE, "metrics_cases.npz"), **metrics_cases())
+        print("metrics_cases.npz", os.path.getsize(os.path.join(HERE, "metrics_cases.npz")))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "ode2":       # oracle-only fixtures: no reference import needed
         np.savez_compressed(os.path.join(HERE, "ode2_cases.npz"), **ode2_cases())
         print("ode2_cases.npz", os.path.getsize(os.path.join(HERE, "ode2_cases.npz")))
@@ -250,6 +280,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "sinkhorn_cases.npz"), **sinkhorn_cases())
     np.savez_compressed(os.path.join(HERE, "ode_cases.npz"), **ode_cases())
     np.savez_compressed(os.path.join(HERE, "ode2_cases.npz"), **ode2_cases())
+    np.savez_compressed(os.path.join(HERE, "metrics_cases.npz"), **metrics_cases())
+    np.savez_compressed(os.path.join(HERE, "metrics_cases.npz"), **metrics_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -279,3 +279,79 @@ def test_gradients_and_float64_flow_through(dev):
     assert xt64.dtype == torch.float64 and ut64.dtype == torch.float64
     x0s, x1s = fm.ot_sampler.sample_plan((z0 @ w), z1)
     assert x0s.requires_grad
+
+
+# ------------------------------------------------------------------------------------ SF2M sampling, metrics
+def _two_fields(dev, d=2, w=64, seed=0):
+    import cfm_amd
+    torch.manual_seed(seed)
+    return cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev), cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev)
+
+
+def test_sdeint_without_noise_is_euler_on_drift_plus_score(dev):
+    from cfm_amd.sde import FlowScoreSDE, sdeint
+    v, s = _two_fields(dev)
+    x0 = oracle.eight_gaussians(128, 3)
+    ts = torch.linspace(0, 1, 21)
+    tr = sdeint(FlowScoreSDE(v, s, sigma=0.0), x0, ts, method="euler", dt=0.05).cpu().numpy()
+    Wv = [l.weight.detach().cpu().numpy() for l in v._linears()]; bv = [l.bias.detach().cpu().numpy() for l in v._linears()]
+    Ws = [l.weight.detach().cpu().numpy() for l in s._linears()]; bs = [l.bias.detach().cpu().numpy() for l in s._linears()]
+    f = lambda t, y: oracle.mlp_forward_f64(Wv, bv, y, t) + oracle.mlp_forward_f64(Ws, bs, y, t)
+    ref = oracle.euler_trajectory(f, x0.numpy(), ts.numpy())
+    assert tr.shape == ref.shape
+    assert np.abs(tr - ref).max() <= 1e-5 * np.abs(ref).max()
+    # reverse time: -drift + score evaluated at 1 - t (solver.py:32-35,129-133)
+    trb = sdeint(FlowScoreSDE(v, s, sigma=0.0, reverse=True), x0, ts, dt=0.05).cpu().numpy()
+    fb = lambda t, y: -oracle.mlp_forward_f64(Wv, bv, y, 1.0 - t) + oracle.mlp_forward_f64(Ws, bs, y, 1.0 - t)
+    refb = oracle.euler_trajectory(fb, x0.numpy(), ts.numpy())
+    assert np.abs(trb - refb).max() <= 1e-5 * np.abs(refb).max()
+
+
+def test_sdeint_hip_path_equals_eager_scheme_and_has_brownian_variance(dev):
+    from cfm_amd.sde import FlowScoreSDE, sdeint
+    v, s = _two_fields(dev, seed=4)
+    x0 = oracle.eight_gaussians(256, 1).to(dev)
+    ts = torch.linspace(0, 1, 11)
+    g1 = torch.Generator(device=dev).manual_seed(7)
+    a = sdeint(FlowScoreSDE(v, s, sigma=0.7), x0, ts, dt=0.02, generator=g1)
+
+    class Eager(torch.nn.Module):          # same scheme through the generic (callable) path
+        noise_type, sde_type = "diagonal", "ito"
+
+        def f(self, t, y):
+            x = torch.cat([y, t.repeat(y.shape[0])[:, None]], 1)
+            with torch.no_grad():
+                return v.net(x) + s.net(x)
+
+        def g(self, t, y):
+            return torch.ones_like(y) * 0.7
+    g2 = torch.Generator(device=dev).manual_seed(7)
+    b = sdeint(Eager(), x0, ts, dt=0.02, generator=g2)
+    assert a.shape == b.shape == (11, 256, 2)
+    assert float((a - b.cpu()).abs().max()) <= 2e-5 * float(b.abs().max())
+    # pure Brownian motion: zero fields, Var(y_1 - y_0) = sigma^2
+    for net in (v, s):
+        for p in net.parameters():
+            p.data.zero_()
+    y = sdeint(FlowScoreSDE(v, s, sigma=2.0), torch.zeros(20000, 2), torch.tensor([0.0, 1.0]), dt=0.01)
+    var = float((y[-1] - y[0]).var())
+    assert abs(var - 4.0) < 0.15, var
+
+
+def test_runner_metrics_vs_reference_fixture(dev, golden_dir):
+    """compute_distribution_distances / mix_rbf_mmd2 against values recorded from the reference's own
+    module (runner/src/models/components/distribution_distances.py, imported unmodified)."""
+    from cfm_amd import metrics
+    d = np.load(os.path.join(golden_dir, "metrics_cases.npz"))
+    pred, true = torch.from_numpy(d["pred"]), torch.from_numpy(d["true"])
+    names, vals = metrics.compute_distribution_distances(pred, true)
+    assert names == [str(n) for n in d["names"]]
+    np.testing.assert_allclose(np.array(vals, dtype=np.float64), d["values"], rtol=2e-5, atol=1e-7)
+    jag = [torch.from_numpy(d[f"jag{k}"]) for k in range(3)]
+    names, vals = metrics.compute_distribution_distances(pred, jag)
+    assert names == [str(n) for n in d["names_jagged"]]
+    np.testing.assert_allclose(np.array(vals, dtype=np.float64), d["values_jagged"], rtol=2e-5, atol=1e-7)
+    names, vals = metrics.compute_distribution_distances(pred[:, :1], true[:, :1])
+    assert names == [str(n) for n in d["names_single"]]
+    np.testing.assert_allclose(np.array(vals, dtype=np.float64), d["values_single"], rtol=2e-5, atol=1e-7)
+    assert float(metrics.mix_rbf_mmd2(pred[:, 0], true[:, 0], sigma_list=[0.5, 2.0])) == pytest.approx(float(d["rbf_only"]), rel=2e-5)
