@@ -51,7 +51,7 @@ def _grid(ts, dt):
     pts = [float(x) for x in ts]
     steps = []
     for a, b in zip(pts[:-1], pts[1:]):
-        n = max(1, int(math.ceil(abs(b - a) / dt - 1e-9)))
+        n = max(1, int(math.ceil(abs(b - a) / dt * (1.0 - 1e-6))))      # (ts usually arrives as float32: 0.05 is 0.0500000007)
         for k in range(n):
             steps.append((a + (b - a) * k / n, (b - a) / n, k == n - 1))
     return steps

@@ -328,7 +328,7 @@ def test_sdeint_hip_path_equals_eager_scheme_and_has_brownian_variance(dev):
     g2 = torch.Generator(device=dev).manual_seed(7)
     b = sdeint(Eager(), x0, ts, dt=0.02, generator=g2)
     assert a.shape == b.shape == (11, 256, 2)
-    assert float((a - b.cpu()).abs().max()) <= 2e-5 * float(b.abs().max())
+    assert float((a.cpu() - b.cpu()).abs().max()) <= 2e-5 * float(b.abs().max())
     # pure Brownian motion: zero fields, Var(y_1 - y_0) = sigma^2
     for net in (v, s):
         for p in net.parameters():
