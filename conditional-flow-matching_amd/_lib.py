@@ -48,6 +48,7 @@ SIGNATURES = {
     "cfm_scale_inv_f32": (_i, [_vp, _sz, _vp, _vp]),
     "cfm_sqrt_inplace_f32": (_i, [_vp, _sz, _vp]),
     "cfm_sinkhorn_log_f32": (_i, [_vp, _i, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cfm_sinkhorn_log_points_f32": (_i, [_vp, _vp, _i, _i, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfm_sinkhorn_potentials_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "cfm_sinkhorn_plan_f64": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),
     "cfm_sinkhorn_cost_f64": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),

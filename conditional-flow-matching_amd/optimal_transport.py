@@ -151,6 +151,31 @@ def sinkhorn_log(M, reg, max_iter=_SINKHORN_MAX_ITER, stop_thr=_SINKHORN_STOP_TH
     return r
 
 
+_POINTS_MAX_DIM = 8     # cfm_sinkhorn_log_points_f32: cost entries recomputed on the fly up to this dimension
+
+
+def sinkhorn_log_points(x0, x1, M, reg, max_iter=_SINKHORN_MAX_ITER, stop_thr=_SINKHORN_STOP_THR,
+                        check_every=_SINKHORN_CHECK_EVERY):
+    """The same solve for d <= 8 without streaming the matrix (cfm_sinkhorn_log_points_f32).  M — the fp32
+    matrix the direct cost kernel built from the same x0 / x1 — is only attached to the result for the
+    consumers that read it (dense sampling, plan, <pi, M>)."""
+    lib = _lib.load()
+    B0, d = x0.shape
+    B1 = x1.shape[0]
+    dev = x0.device
+    r = SinkhornResult()
+    r.f = torch.empty(B0, dtype=torch.float32, device=dev)
+    r.g = torch.empty(B1, dtype=torch.float32, device=dev)
+    r.iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    r.err = torch.zeros(1, dtype=torch.float32, device=dev)
+    r.ws = torch.empty(lib.cfm_workspace_bytes(_lib.OP_SINKHORN, B0, B1, 0), dtype=torch.uint8, device=dev)
+    r.reg, r.M = float(reg), M
+    check(lib.cfm_sinkhorn_log_points_f32(ptr(x0), ptr(x1), B0, B1, d, float(reg), int(max_iter), float(stop_thr),
+                                          int(check_every), ptr(r.f), ptr(r.g), ptr(r.iters), ptr(r.err),
+                                          ptr(r.ws), stream_ptr()), "cfm_sinkhorn_log_points_f32")
+    return r
+
+
 def sinkhorn_plan(r):
     lib = _lib.load()
     B0, B1 = r.M.shape
@@ -282,11 +307,11 @@ class OTPlanSampler:
         a = _lib.to_dev_f32(_flatten2(x0), dev)
         b = _lib.to_dev_f32(_flatten2(x1), dev)
         M = cost_matrix(a, b, squared=True, normalize=self.normalize_cost, matrix_cores=self.method != "exact")
-        return dev, M
+        return dev, M, a, b
 
     def _solve(self, x0, x1):
         """-> ("perm", perm), ("dense", SinkhornResult) or ("plan", device fp64 plan)."""
-        dev, M = self._prepare(x0, x1)
+        dev, M, a, b = self._prepare(x0, x1)
         if self.method == "unbalanced":
             plan, info = unbalanced_plan(M, self.reg, self.reg_m)
             self._last = info
@@ -303,7 +328,10 @@ class OTPlanSampler:
             perm = assign_exact(M)        # raises unless the fp64 certificate holds; nothing is read back
             self._last = {"certified": True}
             return "perm", perm, M
-        r = sinkhorn_log(M, self.reg)
+        if a.shape[1] <= _POINTS_MAX_DIM and not self.normalize_cost:
+            r = sinkhorn_log_points(a, b, M, self.reg)      # low-dimensional clouds: no pass over the matrix
+        else:
+            r = sinkhorn_log(M, self.reg)
         self._last = r
         return "dense", r, M
 

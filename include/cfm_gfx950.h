@@ -100,6 +100,16 @@ int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, int max_ite
                          double stop_thr, int check_every, float* f, float* g,
                          int* iters_done, float* last_err, void* ws, void* stream);
 
+/* K5, variant B — the same solve for low-dimensional clouds (1 <= d <= 8) with the cost entry
+ * recomputed from the coordinates inside the LSE passes instead of streamed from the B0 x B1 matrix
+ * (cdist at torchcfm/optimal_transport.py:84 + pot.sinkhorn at :51,87 in one: no B^2 traffic).  The
+ * entry is formed exactly as cfm_sqeuclid_cost_f32 forms it for d <= 8, so f, g and the potentials in
+ * `ws` belong to that matrix and feed cfm_plan_sample_dense / cfm_sinkhorn_plan_f64 / _cost_f64 unchanged.
+ * x0 [B0,d], x1 [B1,d]; everything else as cfm_sinkhorn_log_f32 (same ws size and layout). */
+int cfm_sinkhorn_log_points_f32(const float* x0, const float* x1, int B0, int B1, int d, double reg,
+                                int max_iter, double stop_thr, int check_every, float* f, float* g,
+                                int* iters_done, float* last_err, void* ws, void* stream);
+
 /* Copy the fp64 log-scalings u [B0], v [B1] left in `ws` by the last
  * cfm_sinkhorn_log_f32 call on it. */
 int cfm_sinkhorn_potentials_f64(const void* ws, int B0, int B1, double* u, double* v,

@@ -355,3 +355,52 @@ def test_runner_metrics_vs_reference_fixture(dev, golden_dir):
     assert names == [str(n) for n in d["names_single"]]
     np.testing.assert_allclose(np.array(vals, dtype=np.float64), d["values_single"], rtol=2e-5, atol=1e-7)
     assert float(metrics.mix_rbf_mmd2(pred[:, 0], true[:, 0], sigma_list=[0.5, 2.0])) == pytest.approx(float(d["rbf_only"]), rel=2e-5)
+
+
+# ------------------------------------------------------------------------------------ Sinkhorn, variant B
+@pytest.mark.parametrize("B0,B1,d,reg", [(4096, 4096, 2, 0.05), (1000, 777, 3, 0.2), (512, 640, 8, 1.0), (130, 65, 1, 0.5)])
+def test_sinkhorn_points_variant_equals_matrix_variant_and_oracle(dev, B0, B1, d, reg):
+    """cfm_sinkhorn_log_points_f32 (cost recomputed on the fly, d <= 8) against the float64 oracle on the fp32
+    matrix the direct cost kernel builds from the same clouds — and against the matrix-streaming solver."""
+    ot = _ot()
+    g = torch.Generator().manual_seed(B0 + d)
+    if d == 2 and B0 == 4096:
+        x0, x1 = oracle.config_inputs("C2")
+    else:
+        x0, x1 = torch.randn(B0, d, generator=g) * 1.5, torch.randn(B1, d, generator=g) + 0.7
+    a, b = x0.to(dev), x1.to(dev)
+    M = ot.cost_matrix(a, b)
+    for iters, thr in ((30, 0.0),):
+        r = ot.sinkhorn_log_points(a, b, M, reg, max_iter=iters, stop_thr=thr)
+        r2 = ot.sinkhorn_log(M, reg, max_iter=iters, stop_thr=thr)
+        u, v = _potentials(r, B0, B1, dev)
+        u2, v2 = _potentials(r2, B0, B1, dev)
+        uo, vo, it, err = sinkhorn_c.sinkhorn_log(M.cpu().numpy(), reg, numItermax=iters, stopThr=thr)
+        sc = max(np.abs(uo).max(), np.abs(vo).max(), 1.0)
+        assert int(r.iters.cpu()) == it
+        assert np.abs(u - uo).max() <= 1e-5 * sc and np.abs(v - vo).max() <= 1e-5 * sc, (np.abs(u - uo).max(), sc)
+        assert np.abs(u - u2).max() <= 1e-5 * sc and np.abs(v - v2).max() <= 1e-5 * sc
+        assert float(r.err.cpu()) == pytest.approx(err, rel=2e-2, abs=1e-10)
+    # convergence path (stopThr reached): same stopping iteration as the oracle
+    regc = max(reg, 2.0)
+    uo, vo, it, err = sinkhorn_c.sinkhorn_log(M.cpu().numpy(), regc)
+    r = ot.sinkhorn_log_points(a, b, M, regc)
+    assert int(r.iters.cpu()) == it and float(r.err.cpu()) < 1e-9
+    u, v = _potentials(r, B0, B1, dev)
+    sc = max(np.abs(uo).max(), np.abs(vo).max(), 1.0)
+    assert np.abs(u - uo).max() <= 1e-5 * sc and np.abs(v - vo).max() <= 1e-5 * sc
+
+
+def test_sampler_takes_points_variant_for_low_dimension(dev):
+    """OTPlanSampler(method='sinkhorn') on 2-D clouds: same sampled pairs as the reference-shaped host chain
+    on the plan this backend returns (get_map), i.e. the on-the-fly potentials feed the dense sampler."""
+    from cfm_amd.optimal_transport import OTPlanSampler
+    x0, x1 = oracle.config_inputs("C1")
+    s = OTPlanSampler(method="sinkhorn", reg=0.5)
+    np.random.seed(3)
+    a, b = s.sample_plan(x0, x1)
+    pi = s.get_map(x0, x1)
+    np.random.seed(3)
+    i, j = oracle.sample_map_reference(pi, 256)
+    assert torch.equal(a, x0[i]) and torch.equal(b, x1[j])
+    np.testing.assert_allclose(pi.sum(0), 1.0 / 256, rtol=1e-6)
