@@ -40,19 +40,26 @@ template <int D, bool PRECISE>
 __device__ __forceinline__ void pts_accumulate(const float (&own)[D], const float* __restrict__ pts_lds,
                                                const double* __restrict__ pot_lds, int first, int n_stage,
                                                double inv_reg, double& m, double& s_acc) {
-    // this lane's points of the staged chunk: first, first + 64, ...   (PTS_U of them per trip)
+    // this lane's points of the staged chunk: first, first + 64, ...   (PTS_U of them per trip).  The chunk is
+    // padded to a whole number of trips with potential = -inf entries, so the trip is branch free: its
+    // 2 x PTS_U LDS reads go out back to back (a per-point bounds test made every read wait for the previous one)
     for (int t0 = first; t0 < n_stage; t0 += 64 * PTS_U) {
+        float pc[PTS_U][D]; double pp[PTS_U];
+#pragma unroll
+        for (int k = 0; k < PTS_U; ++k) {
+            const int t = t0 + 64 * k;
+            pp[k] = pot_lds[t];
+#pragma unroll
+            for (int q = 0; q < D; ++q) pc[k][q] = pts_lds[t * D + q];
+        }
         double x[PTS_U];
         double mx = m;
 #pragma unroll
         for (int k = 0; k < PTS_U; ++k) {
-            const int t = t0 + 64 * k;
-            if (t < n_stage) {
-                float c = 0.f;
+            float c = 0.f;
 #pragma unroll
-                for (int q = 0; q < D; ++q) { const float df = own[q] - pts_lds[t * D + q]; c = fmaf(df, df, c); }
-                x[k] = fma(-(double)c, inv_reg, pot_lds[t]);
-            } else x[k] = SK_NEG;
+            for (int q = 0; q < D; ++q) { const float df = own[q] - pc[k][q]; c = fmaf(df, df, c); }
+            x[k] = fma(-(double)c, inv_reg, pp[k]);
             mx = fmax(mx, x[k]);
         }
         if (PRECISE) {
@@ -116,8 +123,9 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
     for (int c0 = 0; c0 < n_other; c0 += stage_cap) {
         const int n_stage = (n_other - c0 < stage_cap) ? n_other - c0 : stage_cap;
         __syncthreads();
-        for (int t = threadIdx.x; t < n_stage; t += PTS_T) pot_lds[t] = pot_other[c0 + t];
-        for (int e = threadIdx.x; e < n_stage * D; e += PTS_T) pts_lds[e] = other_pts[(size_t)c0 * D + e];
+        const int n_pad = (n_stage + 64 * PTS_U - 1) / (64 * PTS_U) * (64 * PTS_U);     // <= stage_cap (a multiple of it)
+        for (int t = threadIdx.x; t < n_pad; t += PTS_T) pot_lds[t] = (t < n_stage) ? pot_other[c0 + t] : SK_NEG;
+        for (int e = threadIdx.x; e < n_pad * D; e += PTS_T) pts_lds[e] = (e < n_stage * D) ? other_pts[(size_t)c0 * D + e] : 0.f;
         __syncthreads();
         const int first = wv * 4 + sub;          // lane-group (wave, sub) takes points first, first + 64, ...
         if (precise) pts_accumulate<D, true>(own, pts_lds, pot_lds, first, n_stage, inv_reg, m, s_acc);
@@ -216,8 +224,8 @@ extern "C" int cfm_sinkhorn_log_points_f32(const float* x0, const float* x1, int
     // stage as much of the other cloud as fits 128 KiB of LDS (8 B potential + 4 d B coordinates per point)
     const int n_max = B0 > B1 ? B0 : B1;
     int stage_cap = (128 * 1024) / (8 + 4 * d);
-    stage_cap = stage_cap / 64 * 64;
-    if (stage_cap > n_max) stage_cap = (n_max + 63) / 64 * 64;
+    stage_cap = stage_cap / (64 * PTS_U) * (64 * PTS_U);          // whole trips: 512 points
+    if (stage_cap > n_max) stage_cap = (n_max + 64 * PTS_U - 1) / (64 * PTS_U) * (64 * PTS_U);
     const size_t lds = (size_t)stage_cap * (8 + 4 * d);
     {
         static std::once_flag once;
