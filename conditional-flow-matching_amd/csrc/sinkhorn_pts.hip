@@ -31,23 +31,28 @@ struct SkState {
 };
 extern "C" size_t cfm_sk_ws_bytes_internal(int B0, int B1);
 
+#ifndef PTS_T
 #define PTS_T 1024
+#endif
 #define PTS_NW (PTS_T / 64)
 #define PTS_OWN 16           // own points per workgroup
+#ifndef PTS_U
 #define PTS_U 8              // other points per trip and lane
+#endif
+#define PTS_STRIDE (PTS_NW * 4)   // lane-groups (wave, sub) interleave the other side's points
 
 template <int D, bool PRECISE>
 __device__ __forceinline__ void pts_accumulate(const float (&own)[D], const float* __restrict__ pts_lds,
                                                const double* __restrict__ pot_lds, int first, int n_stage,
                                                double inv_reg, double& m, double& s_acc) {
-    // this lane's points of the staged chunk: first, first + 64, ...   (PTS_U of them per trip).  The chunk is
+    // this lane's points of the staged chunk: first, first + PTS_STRIDE, ...   (PTS_U of them per trip).  The chunk is
     // padded to a whole number of trips with potential = -inf entries, so the trip is branch free: its
     // 2 x PTS_U LDS reads go out back to back (a per-point bounds test made every read wait for the previous one)
-    for (int t0 = first; t0 < n_stage; t0 += 64 * PTS_U) {
+    for (int t0 = first; t0 < n_stage; t0 += PTS_STRIDE * PTS_U) {
         float pc[PTS_U][D]; double pp[PTS_U];
 #pragma unroll
         for (int k = 0; k < PTS_U; ++k) {
-            const int t = t0 + 64 * k;
+            const int t = t0 + PTS_STRIDE * k;
             pp[k] = pot_lds[t];
 #pragma unroll
             for (int q = 0; q < D; ++q) pc[k][q] = pts_lds[t * D + q];
@@ -77,9 +82,19 @@ __device__ __forceinline__ void pts_accumulate(const float (&own)[D], const floa
     }
 }
 
+// merge two (max, sum) pairs; the rescaling exp runs in fp32 unless the solve is in its precise phase
+// (the sums were accumulated with fp32 exps anyway)
+__device__ __forceinline__ void pts_merge(double& m, double& s, double m2, double s2, bool precise) {
+    const double mm = fmax(m, m2);
+    if (precise) s = s * exp(m - mm) + s2 * exp(m2 - mm);
+    else s = (double)((float)s * __expf((float)(m - mm)) + (float)s2 * __expf((float)(m2 - mm)));
+    m = mm;
+}
+
 // new_pot[o] = logw - LSE_t(pot_other[t] - |own_o - other_t|^2 / reg) for the 16 own points of the workgroup.
-// x0_first: own cloud is x0 (row update) -> the entry is (own - other)^2 = (x0 - x1)^2; for the column
-// update own = x1 and the difference has the other sign: its square is bit-identical.
+// For the row update own = x0, for the column update own = x1: the difference has the other sign, its
+// square is bit-identical.
+#define PTS_PRE 4            // points per thread of the first staged chunk that are requested in the prologue
 template <int D>
 __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ own_pts, const float* __restrict__ other_pts,
                                                      int n_own, int n_other, double inv_reg, double logw, double wgt,
@@ -95,9 +110,25 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane >> 4, ol = lane & 15;
     const int o = blockIdx.x * PTS_OWN + ol;
+#ifdef PTS_PROF
+    long long tp0 = clock64(), tp1 = 0, tp2 = 0;
+#endif
+    // A launch starts cold: everything the first chunk needs — the own point, this thread's share of the
+    // other cloud and of its potentials — is requested before the state block is looked at.
     float own[D];
 #pragma unroll
     for (int q = 0; q < D; ++q) own[q] = (o < n_own) ? own_pts[(size_t)o * D + q] : 0.f;
+    const int n_stage0 = n_other < stage_cap ? n_other : stage_cap;
+    double pre_pot[PTS_PRE]; float pre_pts[PTS_PRE][D];
+#pragma unroll
+    for (int k = 0; k < PTS_PRE; ++k) {
+        const int t = threadIdx.x + PTS_T * k;
+        const bool ok = t < n_stage0;
+        pre_pot[k] = ok ? pot_other[t] : SK_NEG;
+#pragma unroll
+        for (int q = 0; q < D; ++q) pre_pts[k][q] = ok ? other_pts[(size_t)t * D + q] : 0.f;
+    }
+    const double pold = (!row_update && check && o < n_own) ? pot_old[o] : 0.0;
     if (st->done) return;
     if (row_update) {
         // the convergence decision for the previous iteration: every workgroup derives it from the same data
@@ -122,37 +153,66 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
     double m = SK_NEG, s_acc = 0.0;
     for (int c0 = 0; c0 < n_other; c0 += stage_cap) {
         const int n_stage = (n_other - c0 < stage_cap) ? n_other - c0 : stage_cap;
+        const int n_pad = (n_stage + PTS_STRIDE * PTS_U - 1) / (PTS_STRIDE * PTS_U) * (PTS_STRIDE * PTS_U);     // <= stage_cap (a multiple of it)
         __syncthreads();
-        const int n_pad = (n_stage + 64 * PTS_U - 1) / (64 * PTS_U) * (64 * PTS_U);     // <= stage_cap (a multiple of it)
-        for (int t = threadIdx.x; t < n_pad; t += PTS_T) pot_lds[t] = (t < n_stage) ? pot_other[c0 + t] : SK_NEG;
-        for (int e = threadIdx.x; e < n_pad * D; e += PTS_T) pts_lds[e] = (e < n_stage * D) ? other_pts[(size_t)c0 * D + e] : 0.f;
+        if (c0 == 0) {
+#pragma unroll
+            for (int k = 0; k < PTS_PRE; ++k) {
+                const int t = threadIdx.x + PTS_T * k;
+                if (t < n_pad) {
+                    pot_lds[t] = pre_pot[k];
+#pragma unroll
+                    for (int q = 0; q < D; ++q) pts_lds[t * D + q] = pre_pts[k][q];
+                }
+            }
+            for (int t = threadIdx.x + PTS_T * PTS_PRE; t < n_pad; t += PTS_T) {
+                pot_lds[t] = (t < n_stage) ? pot_other[t] : SK_NEG;
+#pragma unroll
+                for (int q = 0; q < D; ++q) pts_lds[t * D + q] = (t < n_stage) ? other_pts[(size_t)t * D + q] : 0.f;
+            }
+        } else {
+            for (int t = threadIdx.x; t < n_pad; t += PTS_T) {
+                pot_lds[t] = (t < n_stage) ? pot_other[c0 + t] : SK_NEG;
+#pragma unroll
+                for (int q = 0; q < D; ++q) pts_lds[t * D + q] = (t < n_stage) ? other_pts[(size_t)(c0 + t) * D + q] : 0.f;
+            }
+        }
         __syncthreads();
-        const int first = wv * 4 + sub;          // lane-group (wave, sub) takes points first, first + 64, ...
+#ifdef PTS_PROF
+        tp1 = clock64();
+#endif
+        const int first = wv * 4 + sub;          // lane-group (wave, sub) takes points first, first + PTS_STRIDE, ...
         if (precise) pts_accumulate<D, true>(own, pts_lds, pot_lds, first, n_stage, inv_reg, m, s_acc);
         else         pts_accumulate<D, false>(own, pts_lds, pot_lds, first, n_stage, inv_reg, m, s_acc);
     }
-    // merge the 4 sub-groups of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48), then the waves
+#ifdef PTS_PROF
+    tp2 = clock64();
+#endif
+    // merge the 4 sub-groups of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48) ...
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-        const double m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s_acc, off, 64);
-        const double mm = fmax(m, m2);
-        s_acc = s_acc * exp(m - mm) + s2 * exp(m2 - mm);
-        m = mm;
-    }
+    for (int off = 16; off <= 32; off <<= 1)
+        pts_merge(m, s_acc, __shfl_xor(m, off, 64), __shfl_xor(s_acc, off, 64), precise != 0);
     if (sub == 0) { sm[wv][ol] = m; ss[wv][ol] = s_acc; }
+#ifdef PTS_PROF
+    long long tp3 = clock64();
+#endif
     __syncthreads();
+#ifdef PTS_PROF
+    long long tp4 = clock64();
+#endif
+    // ... then the 16 waves: lane (sub, ol) of wave 0 folds waves 4 sub .. 4 sub + 3, two more lane exchanges
     if (wv == 0) {
+        m = sm[sub * (PTS_NW / 4)][ol]; s_acc = ss[sub * (PTS_NW / 4)][ol];
+#pragma unroll
+        for (int w = 1; w < PTS_NW / 4; ++w) pts_merge(m, s_acc, sm[sub * (PTS_NW / 4) + w][ol], ss[sub * (PTS_NW / 4) + w][ol], precise != 0);
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1)
+            pts_merge(m, s_acc, __shfl_xor(m, off, 64), __shfl_xor(s_acc, off, 64), precise != 0);
         double e2 = 0.0;
         if (sub == 0 && o < n_own) {
-            double mm = sm[0][ol];
-#pragma unroll
-            for (int w = 1; w < PTS_NW; ++w) mm = fmax(mm, sm[w][ol]);
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < PTS_NW; ++w) tot += ss[w][ol] * exp(sm[w][ol] - mm);
-            const double pn = logw - (mm + log(tot));
+            const double pn = logw - (m + log(s_acc));
             if (!row_update && check) {
-                const double e = wgt * exp(pot_old[o] - pn) - wgt;      // column marginal of the previous iterate
+                const double e = wgt * exp(pold - pn) - wgt;      // column marginal of the previous iterate
                 e2 = e * e;
             }
             pot_new[o] = pn;
@@ -162,6 +222,12 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
             if (lane == 0) atomicAdd(&st->err2[slot], e2);
         }
     }
+#ifdef PTS_PROF
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+        long long* dbg = reinterpret_cast<long long*>(st) + 8 + (blockIdx.x ? 4 : 0);     // bytes 64.. of the 256-byte state block
+        dbg[0] = tp1 - tp0; dbg[1] = tp2 - tp1; dbg[2] = ((tp3 - tp2) << 32) | (tp4 - tp3); dbg[3] = clock64() - tp4;
+    }
+#endif
 }
 
 // (kernels of sinkhorn.hip, reused through their C entry points would need a header; the three small ones
@@ -224,8 +290,8 @@ extern "C" int cfm_sinkhorn_log_points_f32(const float* x0, const float* x1, int
     // stage as much of the other cloud as fits 128 KiB of LDS (8 B potential + 4 d B coordinates per point)
     const int n_max = B0 > B1 ? B0 : B1;
     int stage_cap = (128 * 1024) / (8 + 4 * d);
-    stage_cap = stage_cap / (64 * PTS_U) * (64 * PTS_U);          // whole trips: 512 points
-    if (stage_cap > n_max) stage_cap = (n_max + 64 * PTS_U - 1) / (64 * PTS_U) * (64 * PTS_U);
+    stage_cap = stage_cap / (PTS_STRIDE * PTS_U) * (PTS_STRIDE * PTS_U);          // whole trips
+    if (stage_cap > n_max) stage_cap = (n_max + PTS_STRIDE * PTS_U - 1) / (PTS_STRIDE * PTS_U) * (PTS_STRIDE * PTS_U);
     const size_t lds = (size_t)stage_cap * (8 + 4 * d);
     {
         static std::once_flag once;
