@@ -84,20 +84,25 @@ static inline int ode_blocks(size_t n) {
     return (int)(b < 2048 ? (b ? b : 1) : 2048);
 }
 
+// rendezvous area of the persistent small-field solver: 3 rows of SM_MAXGRID fp64 partial-sum slots
+#define SM_MAXGRID 1024
+#define ODE_SYNC_BYTES (3 * SM_MAXGRID * 8 + 128 + 1792)   // tail: profiling stamps (SM_PROF builds)
 extern "C" size_t cfm_ode_ws_bytes_internal(int B, int width, int d) {
-    return cfm_mlp_ws_bytes_internal(B, width) + sizeof(float) * (size_t)B * d * 10 + 512;
+    return cfm_mlp_ws_bytes_internal(B, width) + sizeof(float) * (size_t)B * d * 10 + 512 + ODE_SYNC_BYTES;
 }
 
 struct OdeWs {
     float* act;       // MLP activations
     float* k[7];
     float* x; float* xn; float* xt;
-    double* red;      // 8 doubles
+    double* red;      // 32 doubles
+    char* sync;       // ODE_SYNC_BYTES
 };
 
 static OdeWs ode_carve(void* ws, int B, int width, int d) {
     OdeWs w; char* q = (char*)ws;
     w.red = (double*)q; q += 256;
+    w.sync = q; q += ODE_SYNC_BYTES;
     w.act = (float*)q; q += cfm_align_up(cfm_mlp_ws_bytes_internal(B, width), 256) - 256 + 256;
     const size_t n = (size_t)B * d;
     for (int s = 0; s < 7; ++s) { w.k[s] = (float*)q; q += sizeof(float) * n; }
@@ -199,7 +204,7 @@ static int read_red(hipStream_t s, const double* dev, int count, double* host) {
 static int ode_dopri5_small(const float* const* W, const float* const* b, const int* dims, int B, int d,
                             const float* t_span, int n_t, float atol, float rtol, float* traj,
                             int* n_steps, int* nfe, float* xbuf, float* kbuf, float* tspan_dev,
-                            void* state_dev, double* red_dev, float t0, float dt0, int evals0, hipStream_t s);
+                            void* state_dev, char* sync_dev, float t0, float dt0, int evals0, hipStream_t s);
 
 extern "C" int cfm_ode_dopri5_mlp_f32(const float* const* W, const float* const* b, const int* dims,
                                       int n_layers, const float* x0, int B, const float* t_span,
@@ -266,7 +271,7 @@ extern "C" int cfm_ode_dopri5_mlp_f32(const float* const* W, const float* const*
     if (ode_small_enabled() && n_layers == 4 && dims[1] <= SM_WMAX && dims[2] <= SM_WMAX && dims[3] <= SM_WMAX &&
         d + 1 <= SM_WMAX && n >= (size_t)n_t)
         return ode_dopri5_small(W, b, dims, B, d, t_span, n_t, atol, rtol, traj, n_steps, nfe, w.x, w.k[0], w.xt,
-                                (void*)(w.red + 16), w.red + 6, t, dt, evals, s);
+                                (void*)(w.red + 16), w.sync, t, dt, evals, s);
 
     int ckpt = 1;  // next t_span index to land on
     const int max_attempts = 1000000;
@@ -335,18 +340,25 @@ extern "C" int cfm_ode_dopri5_mlp_f32(const float* const* W, const float* const*
 // attempt: 266 us per step at B = 8192, d = 50, w = 64 where the arithmetic is ~20 us.
 // Rows are independent inside a step (only the error norm couples them), so here ONE
 // kernel does the whole attempt: a workgroup keeps the four weight matrices in LDS
-// (66 KB), owns 64 rows, holds x and k1..k7 of its tile in MFMA accumulator layout in
-// registers, and runs the six stage evaluations back to back (v_mfma_f32_32x32x2_f32, the
-// same instruction, k order and epilogue as mlp_layer: bitwise the same field values).
+// (68 KB), owns 32 rows (B = 8192 -> 256 workgroups, one per CU), holds x and k1..k7 of its
+// tile in MFMA accumulator layout in registers (8 floats per variable and lane), and runs the
+// six stage evaluations back to back.  Wave w owns output columns 16w..16w+15 of all 32 rows:
+// two independent v_mfma_f32_16x16x4_f32 accumulator chains per wave (rows 0-15 / 16-31), the
+// same ascending-k fp32 fma chain and epilogue as mlp_layer: bitwise the same field values.
 // A second small kernel turns the summed error into the accept / reject decision and the
 // next step size ON THE DEVICE (same fp32 controller as the host loop above) and copies
 // accepted t_span landings into the trajectory; the host only pumps (step, control) pairs
 // and polls a 32-byte state block.
 // =====================================================================================
 #define SM_W 64
-#define SM_LD 65
+#define SM_LD 68     // row stride = 4 (mod 64): fragment reads (row = lane & 15, k = lane >> 4) hit 64 distinct banks
+#define SM_ROWS 32
+#define SM_V 8       // tile floats per lane: element i -> row sm_row(i, lane), column 16 * wave + (lane & 15)
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct SmTile { float v[SM_V]; };
+__device__ __forceinline__ int sm_row(int i, int lane) { return 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3); }
+
 
 // same SELU as mlp.hip (bitwise)
 __device__ __forceinline__ float selu_f(float x) {
@@ -388,176 +400,274 @@ __device__ __forceinline__ void sm_prestep(const SmState& st, const float* __res
     lands = (st.ckpt < n_t) && (flag || st.t + dt == tspan[st.ckpt]);
 }
 
-// one layer on the 64-row tile: out(C layout) = A[64 x K] * W_l[64 x K]^T
-__device__ __forceinline__ f32x16 sm_gemm(const float* __restrict__ Abuf, const float* __restrict__ Wl, int K,
-                                          int wm, int wn, int lane) {
-    f32x16 acc;
+// Workgroup barrier that orders LDS traffic only: global stores of the tile (trajectory rows) stay in
+// flight across it instead of being drained (s_waitcnt vmcnt(0)) the way __syncthreads() would
+__device__ __forceinline__ void sm_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// one layer on the 32-row tile: out(C layout) = A[32 x K] * W_l[64 x K]^T, this wave's 16 columns
+__device__ __forceinline__ void sm_gemm(const float* __restrict__ Abuf, const float* __restrict__ Wl, int K,
+                                        int wv, int lane, f32x4& c0, f32x4& c1) {
+    c0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = lane >> 4;
+    const float* ap = Abuf + fr * SM_LD + fk;
+    const float* bp = Wl + (wv * 16 + fr) * SM_LD + fk;
+    // every layer runs the full 16 k-steps (rows / columns beyond K are zero in both operands, and
+    // fma(0, 0, acc) leaves acc alone), fully unrolled: all 48 operand reads are in flight before the
+    // first MFMA issues, then the two accumulator chains run back to back in ascending k
+    (void)K;
+    float a0[SM_W / 4], a1[SM_W / 4], b[SM_W / 4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int fr = lane & 31, fk = lane >> 5;
-    const float* ap = Abuf + (wm * 32 + fr) * SM_LD + fk;
-    const float* bp = Wl + (wn * 32 + fr) * SM_LD + fk;
-    // software pipeline: the operands of k-step kk+2 are read from LDS while the MFMA of kk runs (the read
-    // past the last step stays inside the padded 65-float row)
-    const int Kp = (K + 1) & ~1;
-    float a = ap[0], b = bp[0];
-    for (int kk = 0; kk < Kp; kk += 2) {
-        const float an = ap[kk + 2], bn = bp[kk + 2];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        a = an; b = bn;
+    for (int j = 0; j < SM_W / 4; ++j) { a0[j] = ap[4 * j]; a1[j] = ap[16 * SM_LD + 4 * j]; b[j] = bp[4 * j]; }
+#pragma unroll
+    for (int j = 0; j < SM_W / 4; ++j) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[j], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b[j], c1, 0, 0, 0);
     }
-    return acc;
 }
 
 // f(t, y) for the tile; y arrives in C layout, the result leaves in C layout (columns >= d are 0)
-__device__ __forceinline__ f32x16 sm_field(const f32x16& y, float t, const SmArgs& A, int d, float* Abuf0,
+__device__ __forceinline__ SmTile sm_field(const SmTile& y, float t, const SmArgs& A, int d, float* Abuf0,
                                            float* Abuf1, const float* Wl, const float* bl, const float* wt,
-                                           int wm, int wn, int lane) {
-    const int col = wn * 32 + (lane & 31);
+                                           int wv, int lane) {
+    const int col = wv * 16 + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        Abuf0[row * SM_LD + col] = (col < d) ? y[r] : 0.f;
-    }
-    __syncthreads();
-    f32x16 acc;
+    for (int i = 0; i < SM_V; ++i) Abuf0[sm_row(i, lane) * SM_LD + col] = (col < d) ? y.v[i] : 0.f;
+    sm_lds_barrier();
+    SmTile acc;
     float* src = Abuf0; float* dst = Abuf1;
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
         const int K = (l == 0) ? d : A.dims[l];
         const int N = A.dims[l + 1];
-        acc = sm_gemm(src, Wl + l * SM_W * SM_LD, K, wm, wn, lane);
+        f32x4 c0, c1;
+        sm_gemm(src, Wl + l * SM_W * SM_LD, K, wv, lane, c0, c1);
         const float bv = (col < N) ? bl[l * SM_W + col] : 0.f;
         const float wtc = (l == 0 && col < N) ? wt[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[r] + bv;
+        for (int i = 0; i < SM_V; ++i) {
+            float v = ((i < 4) ? c0[i & 3] : c1[i & 3]) + bv;
             if (l == 0) v = fmaf(t, wtc, v);
             if (l < 3) v = selu_f(v);
-            acc[r] = (col < N) ? v : 0.f;
+            acc.v[i] = (col < N) ? v : 0.f;
         }
         if (l < 3) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                dst[row * SM_LD + col] = acc[r];
-            }
-            __syncthreads();
+            for (int i = 0; i < SM_V; ++i) dst[sm_row(i, lane) * SM_LD + col] = acc.v[i];
+            sm_lds_barrier();
             float* tmp = src; src = dst; dst = tmp;
         }
     }
     return acc;
 }
 
-__global__ __launch_bounds__(256) void ode_small_step(SmArgs A, int B, int d, const SmState* __restrict__ st_all,
-                                                   int attempt, float* __restrict__ xbuf, float* __restrict__ kbuf,
-                                                   const float* __restrict__ tspan, int n_t, float atol, float rtol,
-                                                   double* __restrict__ red) {
-    extern __shared__ __attribute__((aligned(16))) float small_lds[];
-    float* Wl = small_lds;                              // [4][64][65]
-    float* bl = Wl + 4 * SM_W * SM_LD;               // [4][64]
-    float* wt = bl + 4 * SM_W;                       // [64] time column of layer 0
-    float* Ab0 = wt + SM_W;                          // [64][65]
-    float* Ab1 = Ab0 + SM_W * SM_LD;
-    const SmState st = st_all[attempt & 1];
-    if (st.done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-    // weights -> LDS (zero padded)
+// weights -> LDS, zero padded to [4][64][SM_LD]; biases; the time column of layer 0
+__device__ __forceinline__ void sm_stage_weights(const SmArgs& A, int d, float* Wl, float* bl, float* wt, int tid) {
     for (int l = 0; l < 4; ++l) {
         const int in_l = A.dims[l], out_l = A.dims[l + 1];
         const int K = (l == 0) ? d : in_l;
-        for (int e = tid; e < SM_W * SM_W; e += 256) {
-            const int r = e / SM_W, k = e % SM_W;
-            Wl[(l * SM_W + r) * SM_LD + k] = (r < out_l && k < K) ? A.W[l][(size_t)r * in_l + k] : 0.f;
+        for (int e = tid; e < SM_W * SM_LD; e += 256) {
+            const int r = e / SM_LD, k = e % SM_LD;
+            Wl[l * SM_W * SM_LD + e] = (r < out_l && k < K) ? A.W[l][(size_t)r * in_l + k] : 0.f;
         }
         if (tid < SM_W) bl[l * SM_W + tid] = (tid < out_l) ? A.b[l][tid] : 0.f;
     }
     if (tid < SM_W) wt[tid] = (tid < A.dims[1]) ? A.W[0][(size_t)tid * A.dims[0] + d] : 0.f;
-
-    float dt, dt_old; bool flag, lands;
-    sm_prestep(st, tspan, n_t, dt, dt_old, flag, lands);
-    const size_t n = (size_t)B * d;
-    const float* x_in = xbuf + (size_t)st.par * n;
-    const float* k1_in = kbuf + (size_t)st.par * n;
-    float* x_out = xbuf + (size_t)(st.par ^ 1) * n;
-    float* k7_out = kbuf + (size_t)(st.par ^ 1) * n;
-    const int col = wn * 32 + (lane & 31);
-    double esum = 0.0;
-    for (int row0 = blockIdx.x * SM_W; row0 < B; row0 += gridDim.x * SM_W) {
-        f32x16 x, k0, k1, k2, k3, k4, k5, k6, y;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gr = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const bool ok = gr < B && col < d;
-            x[r] = ok ? x_in[(size_t)gr * d + col] : 0.f;
-            k0[r] = ok ? k1_in[(size_t)gr * d + col] : 0.f;
-        }
-        __syncthreads();                              // weights staged / previous tile done with the buffers
-        // stage S (a literal): y = x + dt * sum_{q<=S} a[S][q] k_q ; KOUT = f(t + c[S] dt, y)
-#define SM_STAGE(S, KOUT)                                                                            \
-        {                                                                                            \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
-                float acc = (float)DP_A_dev(S, 0) * k0[r];                                           \
-                if (S >= 1) acc = fmaf((float)DP_A_dev(S, 1), k1[r], acc);                           \
-                if (S >= 2) acc = fmaf((float)DP_A_dev(S, 2), k2[r], acc);                           \
-                if (S >= 3) acc = fmaf((float)DP_A_dev(S, 3), k3[r], acc);                           \
-                if (S >= 4) acc = fmaf((float)DP_A_dev(S, 4), k4[r], acc);                           \
-                if (S >= 5) acc = fmaf((float)DP_A_dev(S, 5), k5[r], acc);                           \
-                y[r] = fmaf(dt, acc, x[r]);                                                          \
-            }                                                                                        \
-            KOUT = sm_field(y, st.t + DP_C_dev(S) * dt, A, d, Ab0, Ab1, Wl, bl, wt, wm, wn, lane);  \
-        }
-        SM_STAGE(0, k1) SM_STAGE(1, k2) SM_STAGE(2, k3) SM_STAGE(3, k4) SM_STAGE(4, k5) SM_STAGE(5, k6)
-#undef SM_STAGE
-        // y is x_new (the 5th-order solution), k6 = f(t + dt, x_new): error + outputs
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gr = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (gr < B && col < d) {
-                float e = (float)DP_E_dev(0) * k0[r];
-                e = fmaf((float)DP_E_dev(1), k1[r], e);
-                e = fmaf((float)DP_E_dev(2), k2[r], e);
-                e = fmaf((float)DP_E_dev(3), k3[r], e);
-                e = fmaf((float)DP_E_dev(4), k4[r], e);
-                e = fmaf((float)DP_E_dev(5), k5[r], e);
-                e = fmaf((float)DP_E_dev(6), k6[r], e);
-                e *= dt;
-                const float sc = atol + rtol * fmaxf(fabsf(x[r]), fabsf(y[r]));
-                const float rr = e / sc;
-                esum += (double)rr * (double)rr;
-                x_out[(size_t)gr * d + col] = y[r];
-                k7_out[(size_t)gr * d + col] = k6[r];
-            }
-        }
-    }
-    esum = wave_sum_d(esum);
-    __shared__ double redw[4];
-    if (lane == 0) redw[wv] = esum;
-    __syncthreads();
-    if (tid == 0) atomicAdd(&red[attempt & 1], redw[0] + redw[1] + redw[2] + redw[3]);
 }
 
-// accept / reject, next step size, trajectory landing (every workgroup derives the same decision
-// from the same inputs; workgroup 0 publishes the next state)
-__global__ __launch_bounds__(256) void ode_small_ctrl(int B, int d, SmState* __restrict__ st_all, int attempt,
-                                                   const float* __restrict__ xbuf, const float* __restrict__ tspan,
-                                                   int n_t, float* __restrict__ traj, double* __restrict__ red) {
-    const SmState st = st_all[attempt & 1];
-    if (st.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) st_all[(attempt + 1) & 1] = st;
-        return;
+// Grid-wide rendezvous + all-reduce of a persistent launch (grid <= workgroups that are resident at
+// once).  There is no arrival counter: the fp64 partial sum a workgroup publishes IS its arrival.  Slots
+// hold a negative NaN until their owner stores its (non-negative) partial; wave 0 of every workgroup polls
+// all slots (L2 reads of distinct words, no same-address atomics to serialise) and, once none is NaN, has
+// the values in hand: it adds them in a fixed order, so the total is the same bit pattern in every
+// workgroup and in every run.  Three slot rows rotate (attempt % 3): at the start of attempt a the owner
+// re-arms its slot of row (a + 1) % 3, which held attempt a - 2 (everybody finished reading that before
+// publishing a - 1, which the owner saw at rendezvous a - 1), and its release store of attempt a orders
+// the re-arm before anything a reader of attempt a + 1 can see.  Measured on MI355X, 256 workgroups:
+// an arrival counter + polling cost 7-9 us per rendezvous, a two-level counter tree 15 us.
+// The wait is bounded (wall clock, ~4 s): a mis-sized launch turns into an error code, never a hung GPU.
+__device__ __forceinline__ bool sm_grid_allsum(double* __restrict__ row, double mine, int tid, int lane, int wv,
+                                               double* sh_total, int* sh_ok) {
+    if (wv == 0) {
+        if (lane == 0) __hip_atomic_store(&row[blockIdx.x], mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
+        double tsum;
+        for (;;) {
+            tsum = 0.0;
+            bool all = true;
+            for (int i = lane; i < (int)gridDim.x; i += 64) {
+                const double v = __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all = all && (v >= 0.0);
+                tsum += v;
+            }
+            if (__all(all)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0) {                  // the clock read is slow: look at it rarely
+                const unsigned long long now = wall_clock64();
+                if (!t0) t0 = now;
+                else if (now - t0 > 400000000ull) { ok = 0; break; }
+            }
+        }
+        tsum = wave_sum_d(tsum);
+        if (lane == 0) { *sh_total = tsum; *sh_ok = ok; }
     }
-    float dt, dt_old; bool flag, lands;
-    sm_prestep(st, tspan, n_t, dt, dt_old, flag, lands);
+    (void)tid;
+    sm_lds_barrier();
+    return *sh_ok != 0;
+}
+
+// The whole adaptive integration in ONE persistent launch.  A workgroup owns the row tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... for the entire solve.  RESIDENT (one tile per workgroup, B <=
+// 32 x resident workgroups = 8192 on MI355X): x and k1 live in registers from the first attempt to the
+// last, an accepted step is a register move, and the only global traffic of an attempt is the trajectory
+// row it lands on.  Otherwise x / k1 travel between a workgroup and its own rows of the (L2-resident)
+// parity buffers.  The only cross-workgroup value of a step attempt is the squared error norm: every
+// workgroup stores its fp64 partial, one grid rendezvous, and then every workgroup adds the partials up in
+// the same fixed order (so the solve is reproducible bit for bit), derives the same accept / reject
+// decision and next step size from that sum (the fp32 controller of the host loop above).  `lines` is only
+// touched by SM_PROF builds (phase stamps).
+template <bool RESIDENT>
+__global__ __launch_bounds__(256) void ode_small_dopri(SmArgs A, int B, int d, SmState* __restrict__ st_io,
+                                                    float* __restrict__ xbuf, float* __restrict__ kbuf,
+                                                    const float* __restrict__ tspan, int n_t, float atol, float rtol,
+                                                    float* __restrict__ traj, double* __restrict__ partial,
+                                                    unsigned long long* __restrict__ lines, int max_attempts) {
+    extern __shared__ __attribute__((aligned(16))) float small_lds[];
+    float* Wl = small_lds;                           // [4][64][SM_LD]
+    float* bl = Wl + 4 * SM_W * SM_LD;               // [4][64]
+    float* wt = bl + 4 * SM_W;                       // [64] time column of layer 0
+    float* Ab0 = wt + SM_W;                          // [32][SM_LD]
+    float* Ab1 = Ab0 + SM_ROWS * SM_LD;
+    __shared__ double redw[4];
+    __shared__ double sh_total;
+    __shared__ int sh_ok;
+    SmState st = st_io[0];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    sm_stage_weights(A, d, Wl, bl, wt, tid);
     const size_t n = (size_t)B * d;
-    const float ratio = (float)sqrt(red[attempt & 1] / (double)n);
-    const bool accept = ratio <= 1.f;
-    if (accept && lands) {
-        const float* xn = xbuf + (size_t)(st.par ^ 1) * n;
-        float* dst = traj + (size_t)st.ckpt * n;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = xn[i];
+    const int col = wv * 16 + (lane & 15);
+    const float T = tspan[n_t - 1];
+    SmTile x, k0, k1, k2, k3, k4, k5, k6, y;
+    if (RESIDENT) {
+#pragma unroll
+        for (int i = 0; i < SM_V; ++i) {
+            const int gr = blockIdx.x * SM_ROWS + sm_row(i, lane);
+            const bool ok = gr < B && col < d;
+            x.v[i] = ok ? xbuf[(size_t)gr * d + col] : 0.f;
+            k0.v[i] = ok ? kbuf[(size_t)gr * d + col] : 0.f;
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    __syncthreads();                                  // weights staged
+    int attempt = 0, err = 0;
+    for (; !st.done; ++attempt) {
+        if (attempt >= max_attempts) { err = 1; break; }
+#ifdef SM_PROF
+        unsigned long long* prof = lines + 16;
+        const int pslot = (blockIdx.x == 0) ? 0 : (blockIdx.x == gridDim.x - 1 ? 1 : (blockIdx.x == 100 ? 2 : -1));
+        const bool pon = tid == 0 && pslot >= 0 && attempt >= 20 && attempt < 38;
+        if (pon) prof[(pslot * 18 + attempt - 20) * 4 + 0] = wall_clock64();
+#endif
+        if (tid == 0)                                 // re-arm this workgroup's slot of the next attempt
+            __hip_atomic_store(&partial[(size_t)((attempt + 1) % 3) * SM_MAXGRID + blockIdx.x], __longlong_as_double(-1ll),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float dt, dt_old; bool flag, lands;
+        sm_prestep(st, tspan, n_t, dt, dt_old, flag, lands);
+        const float* x_in = xbuf + (size_t)st.par * n;
+        const float* k1_in = kbuf + (size_t)st.par * n;
+        float* x_out = xbuf + (size_t)(st.par ^ 1) * n;
+        float* k7_out = kbuf + (size_t)(st.par ^ 1) * n;
+        double esum = 0.0;
+        for (int row0 = blockIdx.x * SM_ROWS; row0 < B; row0 += gridDim.x * SM_ROWS) {
+            if (!RESIDENT) {
+#pragma unroll
+                for (int i = 0; i < SM_V; ++i) {
+                    const int gr = row0 + sm_row(i, lane);
+                    const bool ok = gr < B && col < d;
+                    x.v[i] = ok ? x_in[(size_t)gr * d + col] : 0.f;
+                    k0.v[i] = ok ? k1_in[(size_t)gr * d + col] : 0.f;
+                }
+                sm_lds_barrier();                     // previous tile done with the activation buffers
+            }
+            // stage S (a literal): y = x + dt * sum_{q<=S} a[S][q] k_q ; KOUT = f(t + c[S] dt, y)
+#define SM_STAGE(S, KOUT)                                                                            \
+            {                                                                                        \
+                _Pragma("unroll") for (int i = 0; i < SM_V; ++i) {                                   \
+                    float acc = (float)DP_A_dev(S, 0) * k0.v[i];                                     \
+                    if (S >= 1) acc = fmaf((float)DP_A_dev(S, 1), k1.v[i], acc);                     \
+                    if (S >= 2) acc = fmaf((float)DP_A_dev(S, 2), k2.v[i], acc);                     \
+                    if (S >= 3) acc = fmaf((float)DP_A_dev(S, 3), k3.v[i], acc);                     \
+                    if (S >= 4) acc = fmaf((float)DP_A_dev(S, 4), k4.v[i], acc);                     \
+                    if (S >= 5) acc = fmaf((float)DP_A_dev(S, 5), k5.v[i], acc);                     \
+                    y.v[i] = fmaf(dt, acc, x.v[i]);                                                  \
+                }                                                                                    \
+                KOUT = sm_field(y, st.t + DP_C_dev(S) * dt, A, d, Ab0, Ab1, Wl, bl, wt, wv, lane);   \
+            }
+            SM_STAGE(0, k1) SM_STAGE(1, k2) SM_STAGE(2, k3) SM_STAGE(3, k4) SM_STAGE(4, k5) SM_STAGE(5, k6)
+#undef SM_STAGE
+            // y is x_new (the 5th-order solution), k6 = f(t + dt, x_new): error + outputs
+#pragma unroll
+            for (int i = 0; i < SM_V; ++i) {
+                const int gr = row0 + sm_row(i, lane);
+                if (gr < B && col < d) {
+                    float e = (float)DP_E_dev(0) * k0.v[i];
+                    e = fmaf((float)DP_E_dev(1), k1.v[i], e);
+                    e = fmaf((float)DP_E_dev(2), k2.v[i], e);
+                    e = fmaf((float)DP_E_dev(3), k3.v[i], e);
+                    e = fmaf((float)DP_E_dev(4), k4.v[i], e);
+                    e = fmaf((float)DP_E_dev(5), k5.v[i], e);
+                    e = fmaf((float)DP_E_dev(6), k6.v[i], e);
+                    e *= dt;
+                    const float sc = atol + rtol * fmaxf(fabsf(x.v[i]), fabsf(y.v[i]));
+                    const float rr = e / sc;
+                    esum += (double)rr * (double)rr;
+                    if (!RESIDENT) {
+                        x_out[(size_t)gr * d + col] = y.v[i];
+                        k7_out[(size_t)gr * d + col] = k6.v[i];
+                    }
+                }
+            }
+        }
+        esum = wave_sum_d(esum);
+        if (lane == 0) redw[wv] = esum;
+        if (RESIDENT) sm_lds_barrier(); else __syncthreads();   // (the streamed path re-reads its rows below)
+#ifdef SM_PROF
+        if (pon) prof[(pslot * 18 + attempt - 20) * 4 + 1] = wall_clock64();
+#endif
+        if (!sm_grid_allsum(partial + (size_t)(attempt % 3) * SM_MAXGRID, redw[0] + redw[1] + redw[2] + redw[3], tid, lane,
+                            wv, &sh_total, &sh_ok)) { err = 2; break; }
+#ifdef SM_PROF
+        if (pon) prof[(pslot * 18 + attempt - 20) * 4 + 2] = wall_clock64();
+#endif
+        // accept / reject, next step size (identical in every workgroup and lane)
+        const float ratio = (float)sqrt(sh_total / (double)n);
+        const bool accept = ratio <= 1.f;
+        if (RESIDENT) {
+            if (accept) {
+                if (lands) {
+                    float* dst = traj + (size_t)st.ckpt * n;
+#pragma unroll
+                    for (int i = 0; i < SM_V; ++i) {
+                        const int gr = blockIdx.x * SM_ROWS + sm_row(i, lane);
+                        if (gr < B && col < d) dst[(size_t)gr * d + col] = y.v[i];
+                    }
+                }
+                x = y; k0 = k6;                       // FSAL
+            }
+        } else if (accept && lands) {
+            const float* xn = xbuf + (size_t)(st.par ^ 1) * n;
+            float* dst = traj + (size_t)st.ckpt * n;
+            for (int row0 = blockIdx.x * SM_ROWS; row0 < B; row0 += gridDim.x * SM_ROWS) {
+                const int rows = (B - row0 < SM_ROWS) ? B - row0 : SM_ROWS;
+                const size_t base = (size_t)row0 * d;
+                for (int e = tid; e < rows * d; e += 256) dst[base + e] = xn[base + e];   // own rows, written above
+            }
+        }
         SmState nx = st;
         nx.steps = st.steps + 1; nx.evals = st.evals + 6;
         if (accept) {
@@ -576,24 +686,34 @@ __global__ __launch_bounds__(256) void ode_small_ctrl(int B, int d, SmState* __r
         ndt = ndt * factor;
         if (!(ndt > 1e-12f)) ndt = 1e-12f;
         nx.dt = ndt;
-        nx.done = (nx.t < tspan[n_t - 1]) ? 0 : 1;
-        st_all[(attempt + 1) & 1] = nx;
-        red[(attempt + 1) & 1] = 0.0;
+        nx.done = (nx.t < T) ? 0 : 1;
+        st = nx;
     }
+    if (blockIdx.x == 0 && tid == 0) { st.pad = err; st_io[1] = st; }
 }
 
 static int ode_dopri5_small(const float* const* W, const float* const* b, const int* dims, int B, int d,
                             const float* t_span, int n_t, float atol, float rtol, float* traj,
                             int* n_steps, int* nfe, float* xbuf, float* kbuf, float* tspan_dev,
-                            void* state_dev, double* red_dev, float t0, float dt0, int evals0, hipStream_t s) {
+                            void* state_dev, char* sync_dev, float t0, float dt0, int evals0, hipStream_t s) {
     SmArgs A;
     for (int l = 0; l < 4; ++l) { A.W[l] = W[l]; A.b[l] = b[l]; }
     for (int l = 0; l < 5; ++l) A.dims[l] = dims[l];
-    const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_W * SM_LD);
-    static int raised = 0;
+    const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_ROWS * SM_LD);
+    static int raised = 0, resident = 0;
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)ode_small_step, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        raised = (e == hipSuccess) ? 1 : -1;
+        hipError_t e = hipFuncSetAttribute((const void*)ode_small_dopri<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e2 = hipFuncSetAttribute((const void*)ode_small_dopri<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        raised = (e == hipSuccess && e2 == hipSuccess) ? 1 : -1;
+        // workgroups that can be resident at once: the grid rendezvous needs grid <= this
+        int dev = 0, cus = 0, per_cu = 0;
+        if (raised > 0 && hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ode_small_dopri<false>, 256, lds) == hipSuccess &&
+            cus > 0 && per_cu > 0)
+            resident = cus * per_cu;
+        else
+            raised = -1;
         (void)hipGetLastError();
     }
     if (raised < 0) return CFM_EINVAL;
@@ -604,35 +724,31 @@ static int ode_dopri5_small(const float* const* W, const float* const* b, const 
     h[0].t = t0; h[0].dt = dt0; h[0].ckpt = 1; h[0].steps = 0; h[0].evals = evals0; h[0].par = 0; h[0].done = 0;
     rc = cfm_hip(hipMemcpyAsync(state_dev, h, sizeof(h), hipMemcpyHostToDevice, s));
     if (rc) return rc;
-    rc = cfm_hip(hipMemsetAsync(red_dev, 0, 2 * sizeof(double), s));
+    double* partial = (double*)sync_dev;
+    unsigned long long* lines = (unsigned long long*)(sync_dev + 3 * SM_MAXGRID * 8);
+    rc = cfm_hip(hipMemsetAsync(partial, 0xFF, 3 * SM_MAXGRID * 8, s));   // every slot: negative NaN = not arrived
     if (rc) return rc;
     SmState* st = (SmState*)state_dev;
-    int tiles = (B + SM_W - 1) / SM_W;
-    const int grid = tiles < 1024 ? tiles : 1024;
-    int copy_grid = (int)(((size_t)B * d + 255) / 256); if (copy_grid > 128) copy_grid = 128; if (copy_grid < 1) copy_grid = 1;
-    int attempt = 0;
-    const int max_attempts = 1000000;
+    const int tiles = (B + SM_ROWS - 1) / SM_ROWS;
+    int grid = tiles < resident ? tiles : resident;
+    if (grid > SM_MAXGRID) grid = SM_MAXGRID;
+    if (tiles <= grid)
+        hipLaunchKernelGGL(ode_small_dopri<true>, dim3(grid), dim3(256), lds, s, A, B, d, st, xbuf, kbuf, tspan_dev, n_t, atol,
+                           rtol, traj, partial, lines, 1000000);
+    else
+        hipLaunchKernelGGL(ode_small_dopri<false>, dim3(grid), dim3(256), lds, s, A, B, d, st, xbuf, kbuf, tspan_dev, n_t, atol,
+                           rtol, traj, partial, lines, 1000000);
+    rc = cfm_status();
+    if (rc) return rc;
     SmState cur;
-    for (;;) {
-        const int chunk = (attempt == 0) ? (n_t - 1) + 4 : 8;
-        for (int c = 0; c < chunk; ++c, ++attempt) {
-            hipLaunchKernelGGL(ode_small_step, dim3(grid), dim3(256), lds, s, A, B, d, st, attempt, xbuf, kbuf, tspan_dev,
-                               n_t, atol, rtol, red_dev);
-            hipLaunchKernelGGL(ode_small_ctrl, dim3(copy_grid), dim3(256), 0, s, B, d, st, attempt, xbuf, tspan_dev, n_t,
-                               traj, red_dev);
-        }
-        rc = cfm_status();
-        if (rc) return rc;
-        rc = cfm_hip(hipMemcpyAsync(&cur, st + (attempt & 1), sizeof(SmState), hipMemcpyDeviceToHost, s));
-        if (rc) return rc;
-        rc = cfm_hip(hipStreamSynchronize(s));
-        if (rc) return rc;
-        if (cur.done) break;
-        if (attempt >= max_attempts) return CFM_ENOCONV;
-    }
+    rc = cfm_hip(hipMemcpyAsync(&cur, st + 1, sizeof(SmState), hipMemcpyDeviceToHost, s));
+    if (rc) return rc;
+    rc = cfm_hip(hipStreamSynchronize(s));
+    if (rc) return rc;
     if (n_steps) *n_steps = cur.steps;
     if (nfe) *nfe = cur.evals;
-    return 0;
+    if (cur.pad == 2) return CFM_ETIMEOUT;
+    return cur.done && cur.pad == 0 ? 0 : CFM_ENOCONV;
 }
 
 // Fixed-step Euler for the same small fields: x_{k+1} = x_k + dt_k f(t_k, x_k), every step of the
@@ -644,36 +760,27 @@ __global__ __launch_bounds__(256) void ode_small_euler(SmArgs A, int B, int d, c
     float* bl = Wl + 4 * SM_W * SM_LD;
     float* wt = bl + 4 * SM_W;
     float* Ab0 = wt + SM_W;
-    float* Ab1 = Ab0 + SM_W * SM_LD;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-    for (int l = 0; l < 4; ++l) {
-        const int in_l = A.dims[l], out_l = A.dims[l + 1];
-        const int K = (l == 0) ? d : in_l;
-        for (int e = tid; e < SM_W * SM_W; e += 256) {
-            const int r = e / SM_W, k = e % SM_W;
-            Wl[(l * SM_W + r) * SM_LD + k] = (r < out_l && k < K) ? A.W[l][(size_t)r * in_l + k] : 0.f;
-        }
-        if (tid < SM_W) bl[l * SM_W + tid] = (tid < out_l) ? A.b[l][tid] : 0.f;
-    }
-    if (tid < SM_W) wt[tid] = (tid < A.dims[1]) ? A.W[0][(size_t)tid * A.dims[0] + d] : 0.f;
+    float* Ab1 = Ab0 + SM_ROWS * SM_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    sm_stage_weights(A, d, Wl, bl, wt, tid);
     const size_t n = (size_t)B * d;
-    const int col = wn * 32 + (lane & 31);
-    for (int row0 = blockIdx.x * SM_W; row0 < B; row0 += gridDim.x * SM_W) {
-        f32x16 x;
+    const int col = wv * 16 + (lane & 15);
+    for (int row0 = blockIdx.x * SM_ROWS; row0 < B; row0 += gridDim.x * SM_ROWS) {
+        SmTile x;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gr = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            x[r] = (gr < B && col < d) ? traj[(size_t)gr * d + col] : 0.f;
+        for (int i = 0; i < SM_V; ++i) {
+            const int gr = row0 + sm_row(i, lane);
+            x.v[i] = (gr < B && col < d) ? traj[(size_t)gr * d + col] : 0.f;
         }
         __syncthreads();
         for (int k = 0; k + 1 < n_t; ++k) {
             const float t = tspan[k], dt = tspan[k + 1] - tspan[k];
-            const f32x16 f = sm_field(x, t, A, d, Ab0, Ab1, Wl, bl, wt, wm, wn, lane);
+            const SmTile f = sm_field(x, t, A, d, Ab0, Ab1, Wl, bl, wt, wv, lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                x[r] = fmaf(dt, 1.f * f[r], x[r]);
-                const int gr = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (gr < B && col < d) traj[(size_t)(k + 1) * n + (size_t)gr * d + col] = x[r];
+            for (int i = 0; i < SM_V; ++i) {
+                x.v[i] = fmaf(dt, 1.f * f.v[i], x.v[i]);
+                const int gr = row0 + sm_row(i, lane);
+                if (gr < B && col < d) traj[(size_t)(k + 1) * n + (size_t)gr * d + col] = x.v[i];
             }
         }
     }
@@ -684,7 +791,7 @@ static int ode_euler_small(const float* const* W, const float* const* b, const i
     SmArgs A;
     for (int l = 0; l < 4; ++l) { A.W[l] = W[l]; A.b[l] = b[l]; }
     for (int l = 0; l < 5; ++l) A.dims[l] = dims[l];
-    const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_W * SM_LD);
+    const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_ROWS * SM_LD);
     static int raised = 0;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)ode_small_euler, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -694,7 +801,7 @@ static int ode_euler_small(const float* const* W, const float* const* b, const i
     if (raised < 0) return CFM_EINVAL;
     int rc = cfm_hip(hipMemcpyAsync(tspan_dev, t_span, sizeof(float) * n_t, hipMemcpyHostToDevice, s));
     if (rc) return rc;
-    const int tiles = (B + SM_W - 1) / SM_W;
-    hipLaunchKernelGGL(ode_small_euler, dim3(tiles < 2048 ? tiles : 2048), dim3(256), lds, s, A, B, d, tspan_dev, n_t, traj);
+    const int tiles = (B + SM_ROWS - 1) / SM_ROWS;
+    hipLaunchKernelGGL(ode_small_euler, dim3(tiles < 4096 ? tiles : 4096), dim3(256), lds, s, A, B, d, tspan_dev, n_t, traj);
     return cfm_status();
 }

@@ -417,11 +417,14 @@ def test_ode_euler_and_dopri5_vs_golden(dev, golden_dir):
     np.testing.assert_array_equal(tr[0], d["x"])
 
 
-@pytest.mark.parametrize("B,d,w,n_t", [(300, 2, 64, 25), (257, 50, 64, 12), (64, 63, 33, 4)])
+@pytest.mark.parametrize("B,d,w,n_t", [(300, 2, 64, 25), (257, 50, 64, 12), (64, 63, 33, 4), (8192, 50, 64, 6),
+                                        (8231, 3, 48, 5), (20000, 2, 64, 4)])
 def test_ode_fused_small_field_equals_layer_path(dev, B, d, w, n_t):
-    """Small vector fields (every width <= 64) take the fused drivers (one kernel per dopri5 step
-    attempt with the controller on the device; the whole t_span in one launch for euler).  Same MFMA
-    instruction, k order and epilogues as the layer-per-kernel path: the trajectories are bit-equal."""
+    """Small vector fields (every width <= 64) take the fused drivers (the whole adaptive dopri5 solve
+    in one persistent launch with the controller on the device -- x / k1 resident in registers up to
+    B = 8192, streamed through the parity buffers above (the last two cases); the whole t_span in one
+    launch for euler).  Same ascending-k fp32 fma chain and epilogues as the layer-per-kernel path:
+    the trajectories are bit-equal."""
     import cfm_amd
     from cfm_amd import _lib
     from cfm_amd.ode import NeuralODE
