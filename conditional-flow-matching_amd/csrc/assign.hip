@@ -90,13 +90,14 @@ struct AsgParams {
     int handoff;           // ... once at most this many free rows are left
     double stop_early;     // stop_frac of every epsilon phase but the last (0 = same as stop_frac)
     int wide_blocks_cap;   // upper bound on the grid of the wide kernels (0 = none)
-    int bulk;              // asg_step launches enqueued before the first poll (n >= 1024)
+    int bulk;              // asg_step launches enqueued before the first poll (n >= bulk_min_n)
+    int bulk_min_n;
 };
 
 // Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
 // called from another thread never tear a running solve.
 static std::mutex g_params_mu;
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 10, 800000, 1, 6, 0.0, 0, 160};
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 10, 800000, 1, 6, 0.0, 0, 160, 1024};
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
@@ -117,9 +118,10 @@ extern "C" void cfm_assign_set_wide_blocks(int cap) { std::lock_guard<std::mutex
 extern "C" void cfm_assign_set_handoff(int handoff) { std::lock_guard<std::mutex> lk(g_params_mu); if (handoff >= 0) g_params.handoff = handoff; }
 extern "C" void cfm_assign_set_stop_early(double f) { std::lock_guard<std::mutex> lk(g_params_mu); if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
 extern "C" void cfm_assign_set_ms_quantile(double) {}   // kept for old tuning scripts: the radius is the largest free-column label
-extern "C" void cfm_assign_set_bulk(int bulk, int) {
+extern "C" void cfm_assign_set_bulk(int bulk, int min_n) {
     std::lock_guard<std::mutex> lk(g_params_mu);
     if (bulk >= 0) g_params.bulk = bulk;
+    if (min_n > 0) g_params.bulk_min_n = min_n;
 }
 
 // 512 bytes at the head of the workspace.  Line 0 is read-mostly inside a launch (its first 64 bytes
@@ -1409,7 +1411,7 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     if (rc) return rc;
 
     const int chunk = P.chunk > 0 ? P.chunk : 10;
-    const int bulk = (n >= 1024) ? P.bulk : 0;
+    const int bulk = (n >= P.bulk_min_n) ? P.bulk : 0;
     AsgGraph& G = g_graph;
     bool use_graph = asg_graph_enabled() && !G.disabled && n >= 256;
     if (use_graph && !(G.exec[0] && G.ws == ws && G.n == n && G.chunk == chunk && G.bulk == bulk &&
