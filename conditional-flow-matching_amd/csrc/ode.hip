@@ -338,22 +338,25 @@ extern "C" int cfm_ode_dopri5_mlp_f32(const float* const* W, const float* const*
 //
 // The layer-per-kernel driver above spends ~31 launches and one host read-back per step
 // attempt: 266 us per step at B = 8192, d = 50, w = 64 where the arithmetic is ~20 us.
-// Rows are independent inside a step (only the error norm couples them), so here ONE
-// kernel does the whole attempt: a workgroup keeps the four weight matrices in LDS
-// (68 KB), owns 32 rows (B = 8192 -> 256 workgroups, one per CU), holds x and k1..k7 of its
-// tile in MFMA accumulator layout in registers (8 floats per variable and lane), and runs the
-// six stage evaluations back to back.  Wave w owns output columns 16w..16w+15 of all 32 rows:
-// two independent v_mfma_f32_16x16x4_f32 accumulator chains per wave (rows 0-15 / 16-31), the
-// same ascending-k fp32 fma chain and epilogue as mlp_layer: bitwise the same field values.
-// A second small kernel turns the summed error into the accept / reject decision and the
-// next step size ON THE DEVICE (same fp32 controller as the host loop above) and copies
-// accepted t_span landings into the trajectory; the host only pumps (step, control) pairs
-// and polls a 32-byte state block.
+// Rows are independent inside a step (only the error norm couples them), so here ONE persistent
+// kernel does the whole adaptive solve: a workgroup keeps the four weight matrices in LDS (68 KB)
+// and owns a 16-row tile (SM_MB = 1: B = 8192 -> 512 workgroups, two per CU, so one workgroup's
+// MFMA phase overlaps the other's SELU epilogue; measured 3.46 ms against 3.87 ms for 32-row tiles
+// with two accumulator chains per wave and one workgroup per CU), holds x and k1..k7 of its tile
+// in MFMA accumulator layout in registers, and runs the six stage evaluations back to back.  Wave w
+// owns output columns 16w..16w+15: a v_mfma_f32_16x16x4_f32 accumulator chain with the same
+// ascending-k fp32 fma chain and epilogue as mlp_layer: bitwise the same field values.  The
+// accept / reject decision and the next step size are taken ON THE DEVICE by every workgroup from
+// the same all-reduced error norm (same fp32 controller as the host loop above); the host launches
+// once and reads the step counters back.
 // =====================================================================================
 #define SM_W 64
 #define SM_LD 68     // row stride = 4 (mod 64): fragment reads (row = lane & 15, k = lane >> 4) hit 64 distinct banks
-#define SM_ROWS 32
-#define SM_V 8       // tile floats per lane: element i -> row sm_row(i, lane), column 16 * wave + (lane & 15)
+#ifndef SM_MB
+#define SM_MB 1      // 16-row blocks per tile = independent MFMA accumulator chains per wave
+#endif
+#define SM_ROWS (16 * SM_MB)
+#define SM_V (4 * SM_MB)   // tile floats per lane: element i -> row sm_row(i, lane), column 16 * wave + (lane & 15)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct SmTile { float v[SM_V]; };
@@ -408,25 +411,29 @@ __device__ __forceinline__ void sm_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// one layer on the 32-row tile: out(C layout) = A[32 x K] * W_l[64 x K]^T, this wave's 16 columns
+// one layer on the tile: out(C layout) = A[SM_ROWS x K] * W_l[64 x K]^T, this wave's 16 columns
 __device__ __forceinline__ void sm_gemm(const float* __restrict__ Abuf, const float* __restrict__ Wl, int K,
-                                        int wv, int lane, f32x4& c0, f32x4& c1) {
-    c0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                                        int wv, int lane, f32x4 (&c)[SM_MB]) {
+#pragma unroll
+    for (int m = 0; m < SM_MB; ++m) c[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = lane >> 4;
     const float* ap = Abuf + fr * SM_LD + fk;
     const float* bp = Wl + (wv * 16 + fr) * SM_LD + fk;
     // every layer runs the full 16 k-steps (rows / columns beyond K are zero in both operands, and
-    // fma(0, 0, acc) leaves acc alone), fully unrolled: all 48 operand reads are in flight before the
-    // first MFMA issues, then the two accumulator chains run back to back in ascending k
+    // fma(0, 0, acc) leaves acc alone), fully unrolled: all operand reads are in flight before the
+    // first MFMA issues, then the accumulator chain(s) run back to back in ascending k
     (void)K;
-    float a0[SM_W / 4], a1[SM_W / 4], b[SM_W / 4];
-#pragma unroll
-    for (int j = 0; j < SM_W / 4; ++j) { a0[j] = ap[4 * j]; a1[j] = ap[16 * SM_LD + 4 * j]; b[j] = bp[4 * j]; }
+    float a[SM_MB][SM_W / 4], b[SM_W / 4];
 #pragma unroll
     for (int j = 0; j < SM_W / 4; ++j) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[j], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b[j], c1, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < SM_MB; ++m) a[m][j] = ap[16 * m * SM_LD + 4 * j];
+        b[j] = bp[4 * j];
+    }
+#pragma unroll
+    for (int j = 0; j < SM_W / 4; ++j) {
+#pragma unroll
+        for (int m = 0; m < SM_MB; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][j], b[j], c[m], 0, 0, 0);
     }
 }
 
@@ -444,13 +451,13 @@ __device__ __forceinline__ SmTile sm_field(const SmTile& y, float t, const SmArg
     for (int l = 0; l < 4; ++l) {
         const int K = (l == 0) ? d : A.dims[l];
         const int N = A.dims[l + 1];
-        f32x4 c0, c1;
-        sm_gemm(src, Wl + l * SM_W * SM_LD, K, wv, lane, c0, c1);
+        f32x4 c[SM_MB];
+        sm_gemm(src, Wl + l * SM_W * SM_LD, K, wv, lane, c);
         const float bv = (col < N) ? bl[l * SM_W + col] : 0.f;
         const float wtc = (l == 0 && col < N) ? wt[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < SM_V; ++i) {
-            float v = ((i < 4) ? c0[i & 3] : c1[i & 3]) + bv;
+            float v = c[i >> 2][i & 3] + bv;
             if (l == 0) v = fmaf(t, wtc, v);
             if (l < 3) v = selu_f(v);
             acc.v[i] = (col < N) ? v : 0.f;
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(256) void ode_small_dopri(SmArgs A, int B, int d, S
     float* Wl = small_lds;                           // [4][64][SM_LD]
     float* bl = Wl + 4 * SM_W * SM_LD;               // [4][64]
     float* wt = bl + 4 * SM_W;                       // [64] time column of layer 0
-    float* Ab0 = wt + SM_W;                          // [32][SM_LD]
+    float* Ab0 = wt + SM_W;                          // [SM_ROWS][SM_LD]
     float* Ab1 = Ab0 + SM_ROWS * SM_LD;
     __shared__ double redw[4];
     __shared__ double sh_total;
