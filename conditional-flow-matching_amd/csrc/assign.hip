@@ -92,12 +92,13 @@ struct AsgParams {
     int wide_blocks_cap;   // upper bound on the grid of the wide kernels (0 = none)
     int bulk;              // asg_step launches enqueued before the first poll (n >= bulk_min_n)
     int bulk_min_n;
+    int small;             // 1: problems of 2 <= n <= 256 take the one-workgroup solver (assign_small.h)
 };
 
 // Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
 // called from another thread never tear a running solve.
 static std::mutex g_params_mu;
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 10, 800000, 1, 6, 0.0, 0, 160, 1024};
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 10, 800000, 1, 6, 0.0, 0, 160, 1024, 1};
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
@@ -118,6 +119,7 @@ extern "C" void cfm_assign_set_wide_blocks(int cap) { std::lock_guard<std::mutex
 extern "C" void cfm_assign_set_handoff(int handoff) { std::lock_guard<std::mutex> lk(g_params_mu); if (handoff >= 0) g_params.handoff = handoff; }
 extern "C" void cfm_assign_set_stop_early(double f) { std::lock_guard<std::mutex> lk(g_params_mu); if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
 extern "C" void cfm_assign_set_ms_quantile(double) {}   // kept for old tuning scripts: the radius is the largest free-column label
+extern "C" void cfm_assign_set_small(int on) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.small = on ? 1 : 0; }
 extern "C" void cfm_assign_set_bulk(int bulk, int min_n) {
     std::lock_guard<std::mutex> lk(g_params_mu);
     if (bulk >= 0) g_params.bulk = bulk;
@@ -862,6 +864,7 @@ __device__ __forceinline__ void wide_cert(gfp M, const AsgWs& w, AsgState* st, i
 }
 
 #include "assign_sparse.h"
+#include "assign_small.h"
 
 // ------------------------------------------------- one-workgroup helpers -----
 #define CT WT
@@ -1342,6 +1345,8 @@ static int asg_raise_lds() {
 // poll buffer (pinned host memory): one per host thread, concurrent solves on different streams
 // must not share it
 static thread_local int* g_pinned = nullptr;
+static thread_local int g_small_last[16];      // status block of this thread's last one-workgroup solve (phase times)
+extern "C" void cfm_assign_debug_small(int* out16) { for (int q = 0; q < 16; ++q) out16[q] = g_small_last[q]; }
 
 struct AsgLaunch {
     AsgWs w; int n, blocks; size_t lds_step, lds_build, lds_solve; int sparse; hipStream_t s;
@@ -1483,6 +1488,33 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
                                     double* total_cost, int* stats, void* ws, void* stream) {
     const AsgParams P = asg_params_snapshot();
     int cert = 1;
+    if (P.small && B >= 2 && B <= SMA_N) {
+        // one workgroup, one launch; a solve that hits its round caps or fails its certificate reports it and
+        // the chip-wide state machine below takes over
+        if (!M || !perm || !ws) return CFM_EINVAL;
+        if (((uintptr_t)ws & 15) != 0) return CFM_EALIGN;
+        hipStream_t s = (hipStream_t)stream;
+        if (!g_pinned) {
+            int rc0 = cfm_hip(hipHostMalloc((void**)&g_pinned, 256, hipHostMallocDefault));
+            if (rc0) return rc0;
+        }
+        SmaParams Q;
+        Q.theta = P.theta; Q.eps0_frac = P.eps0_frac; Q.eps_last_frac = P.eps_last_frac; Q.stop_frac = P.stop_frac;
+        Q.round_cap = P.round_cap; Q.arr_cap = P.arr_cap; Q.total_cap = 20000;
+        int* status = (int*)ws;
+        int rc0 = cfm_hip(hipMemsetAsync(status, 0, 64, s));
+        if (rc0) return rc0;
+        if (certified) { rc0 = cfm_hip(hipMemsetAsync(certified, 0, sizeof(int), s)); if (rc0) return rc0; }
+        hipLaunchKernelGGL(asg_small, dim3(1), dim3(SMA_T), 0, s, M, B, Q, perm, certified, total_cost, stats, status);
+        rc0 = cfm_status();
+        if (rc0) return rc0;
+        rc0 = cfm_hip(hipMemcpyAsync(g_pinned, status, 64, hipMemcpyDeviceToHost, s));
+        if (rc0) return rc0;
+        rc0 = cfm_hip(hipStreamSynchronize(s));
+        if (rc0) return rc0;
+        for (int q = 0; q < 16; ++q) g_small_last[q] = g_pinned[q];
+        if (g_pinned[0] == 1) return 0;
+    }
     int rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, P, P.sparse, &cert);
     // The candidate-list path is exact by construction; should its certificate ever fail
     // (or its solver report an inconsistency) the dense state machine decides.

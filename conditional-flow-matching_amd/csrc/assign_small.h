@@ -1,0 +1,498 @@
+// assign_small.h — exact optimal assignment for SMALL problems (2 <= n <= 256) in ONE launch of ONE workgroup.
+//
+// Replaces pot.emd(a, b, M) (torchcfm/optimal_transport.py:49,87) at the batch sizes of the reference's
+// tutorials (B = 128 / 256: examples/2D_tutorials/Flow_matching_tutorial.ipynb cell 16, conditional MNIST).
+// The chip-wide state machine of assign.hip pays ~6.5 us per step whatever the grid (a step is a chain of
+// dependent L2 round trips) and ~200 steps per solve: 2-3 ms at n = 256.  Here the whole problem lives in
+// one workgroup: the cost matrix in REGISTERS (wave w owns rows w, w + 16, ...; a lane holds 4 adjacent
+// columns of each of the wave's 16 rows: 64 VGPRs), prices / matches / search labels in 12 KB of LDS, a
+// workgroup barrier (~0.1 us) where the state machine has a kernel boundary.
+//
+// Same algorithm as assign.hip, phase by phase, in fp64 on exactly the fp32 costs the caller passed.  Costs are
+// used as C = (c - cmin) * S with S a power of two that puts the cost range just below 2^44 (an exact
+// rescaling); auction prices live on the integer grid of that scale (a bid is rounded DOWN onto it, so the
+// bidder's new object is its strict minimum and epsilon = 0 rounds leave every kept pair exactly tight);
+// every sum is formed the same way by whichever thread evaluates it, so equality tests are reproducible.
+//   init     Jonker-Volgenant column reduction: p_j = max_i (min_k C_ik - C_ij).
+//   phase A  epsilon-scaling forward auction, Jacobi rounds, no award step: the state of an object is one
+//            64-bit LDS word  price << 14 | round << 8 | row ; prices only rise, ds_max_u64 is the award;
+//            a row is matched iff the object it bid for last still carries its id.  A wave bids for its own
+//            unmatched rows (top-2 over the wave: two DPP min reductions).  Phases are cut at <= 2 % unmatched.
+//   phase B  the same rounds with epsilon = 0 (JV augmenting row reduction): a kept pair is exactly tight.
+//   phase C  rows that are not tight are released; one Dijkstra search per free row (the wave that owns the
+//            row being scanned relaxes all columns and picks the next one; hand-over through LDS + barrier),
+//            JV dual update, augmentation.
+//   phase D  the same fp64 certificate as assign.hip (dual feasibility + complementary slackness on the
+//            ORIGINAL fp32 costs, tolerance 1e-10 of the cost scale) + total cost.
+// A solve that exceeds its round caps (adversarial ties) reports it in `status` and the host falls back to
+// the chip-wide solver; nothing is ever returned uncertified.
+#pragma once
+
+#define SMA_T 1024
+#define SMA_NW (SMA_T / 64)
+#define SMA_N 256
+#define SMA_RB 8            // row id bits of an object word
+#define SMA_QB 6            // round bits (epsilon = 0 rounds)
+#define SMA_SHIFT (SMA_RB + SMA_QB)
+
+struct SmaParams {
+    double theta, eps0_frac, eps_last_frac, stop_frac;
+    int round_cap, arr_cap, total_cap;
+};
+
+struct SmaShared {
+    unsigned long long key[SMA_N];      // price << 14 | round << 8 | row
+    double pd[SMA_N];                   // price of the round's snapshot (integer valued)
+    double u[SMA_N];                    // row duals (phase C)
+    double dist[SMA_N];                 // search labels
+    short arow[SMA_N];                  // row -> column or -1
+    short bidcol[SMA_N];                // row -> column it bid for in this round or -1
+    short colrow[SMA_N];                // column -> row or -1 (phase C)
+    short pred[SMA_N];                  // column -> row that labelled it
+    short freelist[SMA_N];
+    unsigned char done[SMA_N];
+    unsigned fm[2][SMA_NW];             // per wave: bit r = row (wave + 16 r) is unmatched
+    int nfree[2];
+    int ctl[8];                         // search hand-over: [0] next row or -1, [1] found column, [2] error
+    double ctld[4];                     // [0] label of the next row, [1] shortest path length
+    unsigned long long red[SMA_NW + 2];
+    double redd[2 * SMA_NW + 2];
+};
+
+// bits of an integer-valued double 0 <= x < 2^51 as an unsigned integer (x + 2^52 has x in its mantissa)
+__device__ __forceinline__ unsigned long long sma_u64(double x) {
+    return (unsigned long long)__double_as_longlong(x + 4503599627370496.0) & 0x000fffffffffffffull;
+}
+__device__ __forceinline__ double sma_f64(unsigned long long k) {      // the inverse, k < 2^52
+    return __longlong_as_double((long long)(k | 0x4330000000000000ull)) - 4503599627370496.0;
+}
+__device__ __forceinline__ void sma_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// scaled cost (c - cmin) * S as ONE fma: mcs = -cmin * S is exact (S is a power of two); INFINITY for a padded
+// column.  (The empty asm keeps the compiler from hoisting the 64 conversions of a lane out of the round
+// loop: as loop invariants they would need 128 more registers than the 128 a 1024-thread workgroup has.)
+__device__ __forceinline__ double sma_c(float c, double mcs, double S) {
+    asm volatile("" : "+v"(c));
+    return fma((double)c, S, mcs);
+}
+
+// top-2 of the lane-local (best, second) pairs over the wave in ONE DPP reduction (row_shr 1, 2, 4, 8 inside the
+// 16-lane rows, then row_bcast 15 / 31); uniform results
+__device__ __forceinline__ void sma_wave_top2(double b1, double b2, double& w1, double& w2) {
+#define SMA_STAGE(CTRL, MASK)                                                              \
+    {                                                                                      \
+        const double o1 = asg_dpp_d<CTRL, MASK>(INFINITY, b1), o2 = asg_dpp_d<CTRL, MASK>(INFINITY, b2); \
+        b2 = fmin(fmax(b1, o1), fmin(b2, o2));                                             \
+        b1 = fmin(b1, o1);                                                                 \
+    }
+    SMA_STAGE(0x111, 0xf) SMA_STAGE(0x112, 0xf) SMA_STAGE(0x114, 0xf) SMA_STAGE(0x118, 0xf)
+    SMA_STAGE(0x142, 0xa) SMA_STAGE(0x143, 0xc)
+#undef SMA_STAGE
+    w1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b1), 63), __builtin_amdgcn_readlane(__double2loint(b1), 63));
+    w2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b2), 63), __builtin_amdgcn_readlane(__double2loint(b2), 63));
+}
+
+// the 4 entries of row slot r (0..15) of this wave: r is wave uniform, the registers are selected with
+// constant indices (a dynamically indexed register array would go to scratch)
+__device__ __forceinline__ float4 sma_pick(const float4 (&m)[16], int r) {
+    float4 v = m[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+        float4 t = m[q];
+        asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));   // opaque: a select of array elements would be folded into m[r]
+        if (r == q) v = t;
+    }
+    return v;
+}
+
+struct SmaTop { double w1, w2; int j1; double pold; };
+
+// top-2 of C_ij + p_j over the whole row (a wave, 4 columns per lane); everything in the result is uniform
+__device__ __forceinline__ SmaTop sma_top2(const float4& c, const double (&p)[4], double mcs, double S, int lane) {
+    const double v0 = sma_c(c.x, mcs, S) + p[0], v1 = sma_c(c.y, mcs, S) + p[1];
+    const double v2 = sma_c(c.z, mcs, S) + p[2], v3 = sma_c(c.w, mcs, S) + p[3];
+    double b1 = v0, b2 = INFINITY; int k1 = 0;
+    b2 = fmin(b2, fmax(b1, v1)); k1 = v1 < b1 ? 1 : k1; b1 = fmin(b1, v1);
+    b2 = fmin(b2, fmax(b1, v2)); k1 = v2 < b1 ? 2 : k1; b1 = fmin(b1, v2);
+    b2 = fmin(b2, fmax(b1, v3)); k1 = v3 < b1 ? 3 : k1; b1 = fmin(b1, v3);
+    SmaTop t;
+    sma_wave_top2(b1, b2, t.w1, t.w2);
+    const unsigned long long ball = __ballot(b1 == t.w1);
+    const int win = __builtin_amdgcn_readfirstlane(__ffsll((long long)ball) - 1);
+    t.j1 = __builtin_amdgcn_readlane(4 * lane + k1, win);
+    const double ps = k1 == 0 ? p[0] : k1 == 1 ? p[1] : k1 == 2 ? p[2] : p[3];
+    t.pold = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ps), win),
+                              __builtin_amdgcn_readlane(__double2loint(ps), win));
+    return t;
+}
+
+// C_ij of a wave-uniform column j of a row this wave holds (uniform result)
+__device__ __forceinline__ float sma_entry(const float4& c, int j, int lane) {
+    const int k = j & 3;
+    const float v = k == 0 ? c.x : k == 1 ? c.y : k == 2 ? c.z : c.w;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j >> 2));
+}
+
+// One Dijkstra scan: the wave that holds `row` relaxes every open column through it, closes the nearest open
+// column and hands the search to the row matched to it (or reports the free column it reached).
+__device__ __forceinline__ void sma_scan(SmaShared& sh, const float4& c, int row, double mcs, double S, int lane) {
+    const double base = sh.ctld[0], ur = sh.u[row];
+    const double2 pa = *reinterpret_cast<const double2*>(&sh.pd[4 * lane]);
+    const double2 pb = *reinterpret_cast<const double2*>(&sh.pd[4 * lane + 2]);
+    const double2 da = *reinterpret_cast<const double2*>(&sh.dist[4 * lane]);
+    const double2 db = *reinterpret_cast<const double2*>(&sh.dist[4 * lane + 2]);
+    const unsigned dn = *reinterpret_cast<const unsigned*>(&sh.done[4 * lane]);
+    double d[4] = {da.x, da.y, db.x, db.y};
+    const double nd[4] = {base + ((sma_c(c.x, mcs, S) + pa.x) - ur), base + ((sma_c(c.y, mcs, S) + pa.y) - ur),
+                          base + ((sma_c(c.z, mcs, S) + pb.x) - ur), base + ((sma_c(c.w, mcs, S) + pb.y) - ur)};
+    double b1 = INFINITY; int k1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool open = ((dn >> (8 * k)) & 0xffu) == 0u;
+        if (open && nd[k] < d[k]) { d[k] = nd[k]; sh.dist[4 * lane + k] = nd[k]; sh.pred[4 * lane + k] = (short)row; }
+        if (open && d[k] < b1) { b1 = d[k]; k1 = k; }
+    }
+    const double w1 = asg_wave_min_d(b1);
+    const unsigned long long ball = __ballot(b1 == w1);
+    const int win = __builtin_amdgcn_readfirstlane(__ffsll((long long)ball) - 1);
+    const int js = __builtin_amdgcn_readlane(4 * lane + k1, win);
+    if (lane == 0) {
+        if (!(w1 < INFINITY)) { sh.ctl[0] = -1; sh.ctl[2] = 1; }
+        else {
+            sh.done[js] = 1;
+            const int nr = sh.colrow[js];
+            if (nr < 0) { sh.ctl[0] = -1; sh.ctl[1] = js; sh.ctld[1] = w1; }
+            else { sh.ctl[0] = nr; sh.ctld[0] = w1; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mraw, int n, SmaParams P, int* __restrict__ perm,
+                                                  int* __restrict__ certified, double* __restrict__ total_cost,
+                                                  int* __restrict__ stats, int* __restrict__ status) {
+    __shared__ SmaShared sh;
+    gfp M = ASG_GLOBAL(Mraw);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned long long tk0 = wall_clock64();
+    // ---- the matrix -> registers; cost range
+    float4 m[16];
+    float lmin = INFINITY, lmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = wv + 16 * r;
+        float e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = 4 * lane + k;
+            const bool ok = i < n && j < n;
+            e[k] = ok ? M[(size_t)i * n + j] : INFINITY;
+            if (ok) { lmin = fminf(lmin, e[k]); lmax = fmaxf(lmax, e[k]); }
+        }
+        m[r] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    if (tid < SMA_N) {
+        sh.key[tid] = 0ull; sh.arow[tid] = -1; sh.bidcol[tid] = -1; sh.colrow[tid] = -1;
+    }
+    if (tid < 2 * SMA_NW) (&sh.fm[0][0])[tid] = 0u;
+    if (tid < 2) sh.nfree[tid] = 0;
+    {
+        const double a = asg_wave_min_d((double)lmin), b = -asg_wave_min_d(-(double)lmax);
+        if (lane == 0) { sh.redd[wv] = a; sh.redd[SMA_NW + wv] = b; }
+    }
+    sma_sync();
+    double cmin = sh.redd[0], cmax = sh.redd[SMA_NW];
+#pragma unroll
+    for (int q = 1; q < SMA_NW; ++q) { cmin = fmin(cmin, sh.redd[q]); cmax = fmax(cmax, sh.redd[SMA_NW + q]); }
+    const double range = cmax - cmin;
+    const double CM = 17592186044416.0;                      // 2^44: upper bound of the scaled cost range
+    double S = 1.0;
+    if (range > 0.0 && range < INFINITY) { int e; (void)frexp(range, &e); S = ldexp(1.0, 44 - e); }   // range * S in [2^43, 2^44)
+    const double mcs = -cmin * S;
+    const bool finite = cmin > -INFINITY && cmax < INFINITY && cmin == cmin && cmax == cmax;
+    // ---- init: column reduction  p_j = max_i (min_k C_ik - C_ij) + 2^44  (>= 0)
+    {
+        double best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (wv + 16 * r < n) {
+                const double c0 = sma_c(m[r].x, mcs, S), c1 = sma_c(m[r].y, mcs, S), c2 = sma_c(m[r].z, mcs, S), c3 = sma_c(m[r].w, mcs, S);
+                const double rmin = asg_wave_min_d(fmin(fmin(c0, c1), fmin(c2, c3)));
+                best[0] = fmax(best[0], rmin - c0); best[1] = fmax(best[1], rmin - c1);
+                best[2] = fmax(best[2], rmin - c2); best[3] = fmax(best[3], rmin - c3);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = 4 * lane + k;
+            if (j < n && best[k] > -INFINITY)
+                atomicMax(&sh.key[j], sma_u64(floor(best[k] + CM)) << SMA_SHIFT);
+        }
+    }
+    // every row unmatched
+    if (tid < SMA_NW) {
+        unsigned mk = 0u;
+        for (int r = 0; r < 16; ++r) if (tid + 16 * r < n) mk |= 1u << r;
+        sh.fm[0][tid] = mk;
+    }
+    if (tid == 0) sh.nfree[0] = n;
+    sma_sync();
+    if (tid < SMA_N) sh.pd[tid] = sma_f64(sh.key[tid] >> SMA_SHIFT);
+    sma_sync();
+
+    const unsigned long long tk1 = wall_clock64();
+    // ---- phases A, B: bid rounds (control variables are replicated: every thread takes the same decisions)
+    double eps = fmax(1.0, __builtin_rint(P.eps0_frac * CM));
+    const double eps_last = P.eps_last_frac * CM;
+    int stop = (int)(P.stop_frac * n);
+    int mode = 0;                     // 0 auction, 1 epsilon = 0 rounds
+    int cur = 0, round = 0, arr_round = 0, rounds_total = 0, st_auction = 0, st_arr = 0, st_scans = 0, err = 0;
+    if (!finite) err = 3;
+    while (!err) {
+        const int nxt = cur ^ 1;
+        const int cnt = sh.nfree[cur];
+        {
+            const unsigned mk = sh.fm[cur][wv];
+            if (mk) {
+                double p[4];
+                {
+                    const double2 pa = *reinterpret_cast<const double2*>(&sh.pd[4 * lane]);
+                    const double2 pb = *reinterpret_cast<const double2*>(&sh.pd[4 * lane + 2]);
+                    p[0] = pa.x; p[1] = pa.y; p[2] = pb.x; p[3] = pb.y;
+                }
+                const unsigned rnd = mode ? (unsigned)(arr_round + 1) : 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if ((mk >> r) & 1u) {
+                        const int i = wv + 16 * r;
+                        const SmaTop t = sma_top2(m[r], p, mcs, S, lane);
+                        if (lane == 0) {
+                            const double pnew = floor(t.pold + ((t.w2 - t.w1) + eps));     // DOWN onto the price grid
+                            if (pnew < 1.0e15) {
+                                atomicMax(&sh.key[t.j1], (sma_u64(pnew) << SMA_SHIFT) | (unsigned long long)((rnd << SMA_RB) | (unsigned)i));
+                                sh.bidcol[i] = (short)t.j1;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        sma_sync();
+        if (tid < SMA_N) {
+            const int cand = sh.bidcol[tid];
+            const int c = cand >= 0 ? cand : sh.arow[tid];
+            const bool won = c >= 0 && (int)(sh.key[c] & 0xffull) == tid;
+            sh.arow[tid] = won ? (short)c : (short)-1;
+            sh.bidcol[tid] = -1;
+            if (tid < n && !won) { atomicOr(&sh.fm[nxt][tid & 15], 1u << (tid >> 4)); atomicAdd(&sh.nfree[nxt], 1); }
+            sh.pd[tid] = sma_f64(sh.key[tid] >> SMA_SHIFT);
+        } else if (tid < SMA_N + SMA_NW) sh.fm[cur][tid - SMA_N] = 0u;
+        else if (tid == SMA_N + SMA_NW) sh.nfree[cur] = 0;
+        sma_sync();
+        cur = nxt;
+        st_scans += cnt;
+        if (++rounds_total > P.total_cap) { err = 1; break; }
+        bool restart = false;
+        if (mode == 0) {
+            ++st_auction; ++round;
+            if (cnt <= stop || round >= P.round_cap) {
+                const double e2 = eps / P.theta;
+                if (e2 < eps_last) { mode = 1; eps = 0.0; arr_round = 0; }
+                else {
+                    eps = fmax(1.0, __builtin_rint(e2));
+                    stop = (int)(P.stop_frac * n);
+                }
+                round = 0; restart = true;
+            }
+        } else {
+            ++st_arr; ++arr_round;
+            if (cnt == 0 || arr_round >= P.arr_cap) break;
+        }
+        if (restart) {                 // every row is unmatched again, the prices stay
+            if (tid < SMA_N) sh.arow[tid] = -1;
+            if (tid < SMA_NW) {
+                unsigned mk = 0u;
+                for (int r = 0; r < 16; ++r) if (tid + 16 * r < n) mk |= 1u << r;
+                sh.fm[cur][tid] = mk;
+            }
+            if (tid == 0) sh.nfree[cur] = n;
+            sma_sync();
+        }
+    }
+
+    const unsigned long long tk2 = wall_clock64();
+    // ---- phase C entry: duals u_i = min_k (C_ik + p_k); a matched row keeps its column iff that pair is tight
+    int st_free = 0, st_searches = 0;
+    if (!err) {
+        double p[4];
+        {
+            const double2 pa = *reinterpret_cast<const double2*>(&sh.pd[4 * lane]);
+            const double2 pb = *reinterpret_cast<const double2*>(&sh.pd[4 * lane + 2]);
+            p[0] = pa.x; p[1] = pa.y; p[2] = pb.x; p[3] = pb.y;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = wv + 16 * r;
+            if (i < n) {
+                const double c0 = sma_c(m[r].x, mcs, S) + p[0], c1 = sma_c(m[r].y, mcs, S) + p[1];
+                const double c2 = sma_c(m[r].z, mcs, S) + p[2], c3 = sma_c(m[r].w, mcs, S) + p[3];
+                const double ui = asg_wave_min_d(fmin(fmin(c0, c1), fmin(c2, c3)));
+                const int a = sh.arow[i];
+                bool keep = false;
+                if (a >= 0) {
+                    const int k = a & 3;
+                    const double mine = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                    const double own = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), a >> 2),
+                                                        __builtin_amdgcn_readlane(__double2loint(mine), a >> 2));
+                    keep = (own == ui);
+                }
+                if (lane == 0) {
+                    sh.u[i] = ui;
+                    if (keep) sh.colrow[a] = (short)i; else sh.arow[i] = -1;
+                }
+            }
+        }
+        sma_sync();
+        if (wv == 0) {                 // compact list of the free rows
+            int base = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                const bool fr = i < n && sh.arow[i] < 0;
+                const unsigned long long b = __ballot(fr);
+                if (fr) sh.freelist[base + __popcll(b & ((1ull << lane) - 1ull))] = (short)i;
+                base += __popcll(b);
+            }
+            if (lane == 0) sh.ctl[3] = base;
+        }
+        sma_sync();
+        st_free = sh.ctl[3];
+    }
+
+    const unsigned long long tk3 = wall_clock64();
+    // ---- phase C: one shortest augmenting path per free row
+    for (int f = 0; f < st_free && !err; ++f) {
+        const int root = sh.freelist[f];
+        if (tid < SMA_N) { sh.dist[tid] = INFINITY; sh.done[tid] = 0; }
+        if (tid == 0) { sh.ctl[0] = root; sh.ctl[1] = -1; sh.ctl[2] = 0; sh.ctld[0] = 0.0; }
+        sma_sync();
+        if (wv == (root & 15)) {       // the root's dual from the current prices
+            const float4 c = sma_pick(m, root >> 4);
+            const double2 pa = *reinterpret_cast<const double2*>(&sh.pd[4 * lane]);
+            const double2 pb = *reinterpret_cast<const double2*>(&sh.pd[4 * lane + 2]);
+            const double ui = asg_wave_min_d(fmin(fmin(sma_c(c.x, mcs, S) + pa.x, sma_c(c.y, mcs, S) + pa.y),
+                                                  fmin(sma_c(c.z, mcs, S) + pb.x, sma_c(c.w, mcs, S) + pb.y)));
+            if (lane == 0) sh.u[root] = ui;
+        }
+        sma_sync();
+        ++st_searches;
+        int guard = 0;
+        for (;;) {
+            const int row = sh.ctl[0];
+            if (row < 0) break;
+            if (++guard > n + 2) { err = 2; break; }
+            if (wv == (row & 15)) {
+                // one code copy per row slot (static register indices; a select chain over the 16 slots costs 60
+                // instructions per scan)
+                switch (row >> 4) {
+#define SMA_CASE(R) case R: sma_scan(sh, m[R], row, mcs, S, lane); break;
+                    SMA_CASE(0) SMA_CASE(1) SMA_CASE(2) SMA_CASE(3) SMA_CASE(4) SMA_CASE(5) SMA_CASE(6) SMA_CASE(7)
+                    SMA_CASE(8) SMA_CASE(9) SMA_CASE(10) SMA_CASE(11) SMA_CASE(12) SMA_CASE(13) SMA_CASE(14)
+                    default: sma_scan(sh, m[15], row, mcs, S, lane); break;
+#undef SMA_CASE
+                }
+            }
+            ++st_scans;
+            sma_sync();
+        }
+        if (err) break;
+        if (sh.ctl[2] || sh.ctl[1] < 0) { err = 2; break; }
+        const int jfree = sh.ctl[1];
+        const double dfin = sh.ctld[1];
+        // dual update of the scanned columns, then the augmentation (one thread: the path is a chain)
+        if (tid < SMA_N && sh.done[tid] && tid != jfree) {
+            const double np = sh.pd[tid] + (dfin - sh.dist[tid]);
+            sh.pd[tid] = np;
+        }
+        if (tid == 0) {
+            int j = jfree, hops = 0;
+            for (;;) {
+                const int i = sh.pred[j];
+                const int jn = sh.arow[i];
+                sh.arow[i] = (short)j; sh.colrow[j] = (short)i;
+                if (i == root || ++hops > n) break;
+                j = jn;
+            }
+        }
+        sma_sync();
+        // duals of the matched rows from the new prices: u_i = C_{i a_i} + p_{a_i}
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = wv + 16 * r;
+            if (i < n) {
+                const int a = sh.arow[i];
+                if (a >= 0) {
+                    const double ci = sma_c(sma_entry(m[r], a, lane), mcs, S);
+                    if (lane == 0) sh.u[i] = ci + sh.pd[a];
+                }
+            }
+        }
+        sma_sync();
+    }
+
+    const unsigned long long tk4 = wall_clock64();
+    // ---- phase D: certificate on the original costs, total cost, export
+    if (!err) {
+        const double q = 1.0 / S;
+        const double2 pa = *reinterpret_cast<const double2*>(&sh.pd[4 * lane]);
+        const double2 pb = *reinterpret_cast<const double2*>(&sh.pd[4 * lane + 2]);
+        const double p[4] = {pa.x * q, pa.y * q, pb.x * q, pb.y * q};
+        double wmin = INFINITY, csum = 0.0; int bad = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = wv + 16 * r;
+            if (i < n) {
+                const int a = sh.arow[i];
+                if (a < 0 || a >= n || sh.colrow[a] != i) { bad = 1; continue; }
+                const double ca = (double)sma_entry(m[r], a, lane);
+                const double ui = ca + sh.pd[a] * q;
+                double s = INFINITY;
+                if (4 * lane + 0 < n) s = fmin(s, ((double)m[r].x + p[0]) - ui);
+                if (4 * lane + 1 < n) s = fmin(s, ((double)m[r].y + p[1]) - ui);
+                if (4 * lane + 2 < n) s = fmin(s, ((double)m[r].z + p[2]) - ui);
+                if (4 * lane + 3 < n) s = fmin(s, ((double)m[r].w + p[3]) - ui);
+                wmin = fmin(wmin, s);
+                csum += ca;
+            }
+        }
+        wmin = asg_wave_min_d(wmin);
+        if (lane == 0) { sh.redd[wv] = wmin; sh.redd[SMA_NW + wv] = csum; sh.red[wv] = (unsigned long long)bad; }
+        sma_sync();
+        if (tid == 0) {
+            double ms = sh.redd[0], tot = sh.redd[SMA_NW]; unsigned long long b = sh.red[0];
+            for (int qq = 1; qq < SMA_NW; ++qq) { ms = fmin(ms, sh.redd[qq]); tot += sh.redd[SMA_NW + qq]; b |= sh.red[qq]; }
+            const double scale = fmax(fabs(cmax), fabs(cmin));
+            const double tol = 1e-10 * fmax(scale, 1e-30);
+            const int ok = (!b) && (ms >= -tol);
+            if (!ok) err = 4;
+            sh.ctl[4] = ok;
+            if (ok) {
+                if (certified) *certified = 1;
+                if (total_cost) *total_cost = tot;
+            }
+        }
+        sma_sync();
+        if (sh.ctl[4]) { if (tid < n) perm[tid] = sh.arow[tid]; }
+        else err = 4;
+    }
+    if (tid == 0) {
+        if (stats) {
+            stats[0] = st_auction; stats[1] = st_arr; stats[2] = st_free; stats[3] = st_searches;
+            stats[4] = st_scans; stats[5] = st_scans; stats[6] = 1; stats[7] = 0x40000000;     // bit 30: the one-workgroup path
+        }
+        status[1] = st_auction; status[2] = st_free; status[3] = st_scans;
+        // phase times in 10 ns ticks: load + init, bid rounds, convert, searches, certificate
+        status[4] = (int)(tk1 - tk0); status[5] = (int)(tk2 - tk1); status[6] = (int)(tk3 - tk2); status[7] = (int)(tk4 - tk3);
+        status[8] = (int)(wall_clock64() - tk4);
+        __threadfence_system();
+        status[0] = err ? -err : 1;
+    }
+}

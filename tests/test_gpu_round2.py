@@ -404,3 +404,68 @@ def test_sampler_takes_points_variant_for_low_dimension(dev):
     i, j = oracle.sample_map_reference(pi, 256)
     assert torch.equal(a, x0[i]) and torch.equal(b, x1[j])
     np.testing.assert_allclose(pi.sum(0), 1.0 / 256, rtol=1e-6)
+
+
+# ------------------------------------------------------------- one-workgroup exact assignment
+def _small_instances():
+    rng = np.random.RandomState(11)
+    out = []
+    for n in (2, 3, 7, 16, 17, 64, 65, 100, 128, 255, 256):
+        out.append((f"uniform{n}", (rng.rand(n, n) * 10).astype(np.float32), True))
+    for n, d in ((256, 2), (200, 2), (128, 3), (256, 50), (77, 1)):
+        x = rng.randn(n, d); y = rng.randn(n, d) + 0.5
+        out.append((f"geo{n}x{d}", ((x[:, None, :] - y[None]) ** 2).sum(-1).astype(np.float32), True))
+    out.append(("ties", rng.randint(0, 5, size=(200, 200)).astype(np.float32), False))
+    out.append(("allequal", np.zeros((65, 65), dtype=np.float32), False))
+    out.append(("negative", (-rng.rand(90, 90) * 1e4).astype(np.float32), True))
+    out.append(("dupcols", np.repeat(rng.rand(128, 64).astype(np.float32), 2, axis=1), False))
+    out.append(("offset1e6", (rng.rand(100, 100) + 1e6).astype(np.float32), False))
+    out.append(("tiny", (rng.rand(100, 100) * 1e-20).astype(np.float32), True))
+    return out
+
+
+@pytest.mark.parametrize("name,Mnp,unique", _small_instances(), ids=[t[0] for t in _small_instances()])
+def test_small_assignment_one_workgroup_vs_scipy(dev, name, Mnp, unique):
+    """n <= 256 takes the one-launch, one-workgroup solver (assign_small.h; stats[7] bit 30 says so): optimal
+    cost equal to SciPy's on the same fp32 matrix, the permutation itself where the optimum is unique, the
+    certificate set, and the same total as the chip-wide state machine on the same input."""
+    from cfm_amd import _lib
+    ot = _ot()
+    lib = _lib.load()
+    M = torch.from_numpy(np.ascontiguousarray(Mnp)).to(dev)
+    perm, info = ot.assign_exact(M, return_info=True)
+    assert info["certified"] and (info["stats"][7] & 0x40000000), info
+    p = perm.cpu().numpy().astype(np.int64)
+    n = len(p)
+    assert sorted(p.tolist()) == list(range(n))
+    ref = oracle.exact_perm(Mnp)
+    c, cr = oracle.assignment_cost(Mnp, p), oracle.assignment_cost(Mnp, ref)
+    assert c <= cr + 1e-9 * max(1.0, abs(cr)), (c, cr)
+    if unique:
+        np.testing.assert_array_equal(p, ref)
+    assert info["total_cost"] == pytest.approx(c, rel=1e-12, abs=1e-30)
+    try:
+        lib.cfm_assign_set_small(0)
+        perm2, info2 = ot.assign_exact(M, return_info=True)
+    finally:
+        lib.cfm_assign_set_small(1)
+    assert not (info2["stats"][7] & 0x40000000)
+    c2 = oracle.assignment_cost(Mnp, perm2.cpu().numpy().astype(np.int64))
+    assert c2 == pytest.approx(c, rel=1e-12, abs=1e-30)
+
+
+def test_small_assignment_tutorial_batch_through_the_sampler(dev):
+    """C1 (B = 256, d = 2, the reference's tutorial batch): OTPlanSampler(method='exact') end to end picks the
+    pairs of the SciPy-optimal permutation (same np.random stream as the reference's sample_map)."""
+    ot = _ot()
+    x0, x1 = oracle.config_inputs("C1")
+    Mh = ot.cost_matrix(x0.to(dev), x1.to(dev), matrix_cores=False).cpu().numpy()   # the matrix the sampler solves on
+    ref = oracle.exact_perm(Mh)
+    samp = ot.OTPlanSampler(method="exact")
+    np.random.seed(5)
+    a, b = samp.sample_plan(x0.to(dev), x1.to(dev))
+    np.random.seed(5)
+    u = np.random.random_sample(x0.shape[0])
+    i = np.minimum((u * x0.shape[0]).astype(np.int64), x0.shape[0] - 1)
+    np.testing.assert_array_equal(a.cpu().numpy(), x0.numpy()[i])
+    np.testing.assert_array_equal(b.cpu().numpy(), x1.numpy()[ref[i]])
