@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
 int cfm_mlp_forward_impl(const float* x, const float* t, float tval, int has_t, int t_per_row,
                          const float* const* W, const float* const* b, const int* dims,
@@ -708,21 +709,24 @@ static int ode_dopri5_small(const float* const* W, const float* const* b, const 
     for (int l = 0; l < 5; ++l) A.dims[l] = dims[l];
     const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_ROWS * SM_LD);
     static int raised = 0, resident = 0;
-    if (!raised) {
+    static std::once_flag once;
+    std::call_once(once, [lds] {
         hipError_t e = hipFuncSetAttribute((const void*)ode_small_dopri<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipError_t e2 = hipFuncSetAttribute((const void*)ode_small_dopri<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        raised = (e == hipSuccess && e2 == hipSuccess) ? 1 : -1;
+        int ok = (e == hipSuccess && e2 == hipSuccess) ? 1 : -1;
         // workgroups that can be resident at once: the grid rendezvous needs grid <= this
-        int dev = 0, cus = 0, per_cu = 0;
-        if (raised > 0 && hipGetDevice(&dev) == hipSuccess &&
+        int dev = 0, cus = 0, pa = 0, pb = 0;
+        if (ok > 0 && hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ode_small_dopri<false>, 256, lds) == hipSuccess &&
-            cus > 0 && per_cu > 0)
-            resident = cus * per_cu;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&pa, (const void*)ode_small_dopri<true>, 256, lds) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, (const void*)ode_small_dopri<false>, 256, lds) == hipSuccess &&
+            cus > 0 && pa > 0 && pb > 0)
+            resident = cus * (pa < pb ? pa : pb);
         else
-            raised = -1;
+            ok = -1;
         (void)hipGetLastError();
-    }
+        raised = ok;
+    });
     if (raised < 0) return CFM_EINVAL;
     int rc = cfm_hip(hipMemcpyAsync(tspan_dev, t_span, sizeof(float) * n_t, hipMemcpyHostToDevice, s));
     if (rc) return rc;
@@ -800,11 +804,12 @@ static int ode_euler_small(const float* const* W, const float* const* b, const i
     for (int l = 0; l < 5; ++l) A.dims[l] = dims[l];
     const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_ROWS * SM_LD);
     static int raised = 0;
-    if (!raised) {
+    static std::once_flag once;
+    std::call_once(once, [] {
         hipError_t e = hipFuncSetAttribute((const void*)ode_small_euler, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        raised = (e == hipSuccess) ? 1 : -1;
         (void)hipGetLastError();
-    }
+        raised = (e == hipSuccess) ? 1 : -1;
+    });
     if (raised < 0) return CFM_EINVAL;
     int rc = cfm_hip(hipMemcpyAsync(tspan_dev, t_span, sizeof(float) * n_t, hipMemcpyHostToDevice, s));
     if (rc) return rc;

@@ -24,6 +24,7 @@
 // Convergence is decided on the device (no host sync): every kernel of the
 // pre-enqueued sequence reads the state block and exits if `done` is set.
 #include "cfm_common.h"
+#include <mutex>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -657,14 +658,15 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, 
     int v_in_lds = ((size_t)B1 * 8 <= 128 * 1024) ? 1 : 0;
     if (v_in_lds && (size_t)B1 * 8 > 48 * 1024) {
         static int raised = 0;   // dynamic LDS above the 64 KiB default needs the attribute
-        if (!raised) {
+        static std::once_flag once;
+        std::call_once(once, [] {
             hipError_t e = hipFuncSetAttribute((const void*)sk_row_pass<true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             hipError_t e2 = hipFuncSetAttribute((const void*)sk_row_pass<false>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            raised = (e == hipSuccess && e2 == hipSuccess) ? 1 : -1;
             (void)hipGetLastError();
-        }
+            raised = (e == hipSuccess && e2 == hipSuccess) ? 1 : -1;
+        });
         if (raised < 0) v_in_lds = 0;
     }
     const size_t lds = v_in_lds ? (size_t)B1 * 8 : 0;
@@ -672,20 +674,21 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, 
     int stream_grid = 0, stream_nf4 = 0;
     if (row_fast && v_in_lds) {
         static int per_cu = -1, cus = 0;
-        if (per_cu < 0) {
+        static std::once_flag once_stream;
+        std::call_once(once_stream, [] {
             const char* e = getenv("CFM_SK_STREAM");       // workgroups per CU; 0 = one-shot row pass
-            per_cu = e ? atoi(e) : 1;
-            int dev = 0; hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                cus = prop.multiProcessorCount;
-            if (cus <= 0) cus = 256;
+            int pc = e ? atoi(e) : 1;
+            int dev = 0, c = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
             const void* fns[4] = {(const void*)sk_row_stream<4>, (const void*)sk_row_stream<8>,
                                   (const void*)sk_row_stream<12>, (const void*)sk_row_stream<16>};
             for (int q = 0; q < 4; ++q)
                 if (hipFuncSetAttribute(fns[q], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-                    per_cu = 0;
+                    pc = 0;
             (void)hipGetLastError();
-        }
+            cus = c; per_cu = pc < 0 ? 0 : pc;
+        });
         // units of 256 * nf4 columns: the largest of 4, 8, 12, 16 float4 per lane that divides the row
         for (int q = 4; q <= SK_STREAM_UNIT; q += 4)
             if ((B1 / 256) % q == 0) stream_nf4 = q;

@@ -157,7 +157,12 @@ class MLP(torch.nn.Module):
                     params += [l.weight, l.bias]
                 return _MLPTrainFunction.apply(x, *params)
             return self.net(x)
-        return self.forward_hip(x)
+        # no-grad inference: any leading shape (the reference's nn.Sequential accepts [..., dim]) and the
+        # caller's dtype back
+        if x.dim() != 2:
+            lead = x.shape[:-1]
+            return self.forward_hip(x.reshape(-1, x.shape[-1])).reshape(*lead, -1).to(x.dtype)
+        return self.forward_hip(x).to(x.dtype)
 
 
 class GradModel(torch.nn.Module):

@@ -97,7 +97,10 @@ def assign_exact(M, return_info=False):
     return (perm, info) if return_info else perm
 
 
-_RECT_EXACT_MAX = 8192   # largest lcm(B0, B1) the rectangular exact path expands to
+# largest lcm(B0, B1) the rectangular exact path expands to.  The expanded problem repeats every row L/B0 and every
+# column L/B1 times: it is massively tied, which is the slow regime of every assignment solver (127 x 128 -> L = 16256
+# was measured at ~200 s on MI355X), so the bound is a usability bound, not a memory bound.
+_RECT_EXACT_MAX = 8192
 
 
 def exact_plan_rect(M):
@@ -427,14 +430,15 @@ class OTPlanSampler:
                 return flat // M.shape[1], flat % M.shape[1]
             return sample_pi(sol, u)
         if kind == "dense":
-            # NaN guard of get_map (ref:88-96): a non-finite potential -> uniform plan
             fin = bool(torch.isfinite(sol.f).all() and torch.isfinite(sol.g).all())
-            u = _u01_to_device(np.random.random_sample(n), dev)
             if not fin:
-                if self.warn:
-                    warnings.warn("Numerical errors in OT plan, reverting to uniform plan.")
-                flat = torch.clamp((u * (M.shape[0] * M.shape[1])).floor().long(), max=M.numel() - 1)
-                return flat // M.shape[1], flat % M.shape[1]
+                # what the reference does with a non-finite plan (ref:88-96, 118): the diagnostics, no uniform
+                # revert (|NaN| < 1e-8 is False), and np.random.choice raises
+                print("ERROR: p is not finite")
+                print("Cost mean, max", M.mean(), M.max())
+                print(x0, x1)
+                raise ValueError("probabilities contain NaN")   # (before the draw: the NumPy stream is not consumed)
+            u = _u01_to_device(np.random.random_sample(n), dev)
             return sample_dense(sol, u)
         u = _u01_to_device(np.random.random_sample(n), dev)
         return sample_perm(sol, u, M.shape[0])
@@ -457,7 +461,18 @@ class OTPlanSampler:
         dev = _lib.require_gpu()
         a, b = _lib.to_dev_f32(x0f, dev), _lib.to_dev_f32(x1f, dev)
         M = cost_matrix(a, b, squared=True, normalize=self.normalize_cost, matrix_cores=False)
-        perm = assign_exact(M).long()
+        B0, B1 = M.shape
+        if B0 == B1:
+            perm = assign_exact(M).long()
+        else:
+            # scipy.optimize.linear_sum_assignment on a rectangular matrix pairs min(B0, B1) rows / columns at
+            # minimum total cost and returns the column indices in row order (ref:179: `_, j = ...`).  Zero-cost
+            # dummy rows / columns make it a square problem with the same optimum on the real entries.
+            n = max(B0, B1)
+            Mx = torch.zeros((n, n), dtype=torch.float32, device=dev)
+            Mx[:B0, :B1] = M
+            full = assign_exact(Mx).long()[:B0]
+            perm = full[full < B1]
         return x0f, gather_rows(x1f.detach().to(dev), perm).to(x1.device)
 
     def sample_plan_with_labels(self, x0, x1, y0=None, y1=None, replace=True):

@@ -469,3 +469,37 @@ def test_small_assignment_tutorial_batch_through_the_sampler(dev):
     i = np.minimum((u * x0.shape[0]).astype(np.int64), x0.shape[0] - 1)
     np.testing.assert_array_equal(a.cpu().numpy(), x0.numpy()[i])
     np.testing.assert_array_equal(b.cpu().numpy(), x1.numpy()[ref[i]])
+
+
+# ------------------------------------------------------------------------ API gaps closed
+@pytest.mark.parametrize("B0,B1", [(100, 160), (160, 100)])
+def test_sample_plan_with_scipy_rectangular(dev, B0, B1):
+    """ref:179 `_, j = scipy.optimize.linear_sum_assignment(M)` on a rectangular matrix: min(B0, B1) pairs at
+    minimum total cost, column indices in row order; x0 is returned whole (reference behaviour)."""
+    import scipy.optimize
+    ot = _ot()
+    rng = np.random.RandomState(3)
+    x0 = torch.from_numpy(rng.randn(B0, 3).astype(np.float32))
+    x1 = torch.from_numpy((rng.randn(B1, 3) + 0.3).astype(np.float32))
+    M = ot.cost_matrix(x0.to(dev), x1.to(dev), matrix_cores=False).cpu().numpy()
+    _, j = scipy.optimize.linear_sum_assignment(M.astype(np.float64))
+    a, b = ot.OTPlanSampler(method="exact").sample_plan_with_scipy(x0.to(dev), x1.to(dev))
+    assert a.shape[0] == B0 and b.shape[0] == min(B0, B1)
+    np.testing.assert_array_equal(a.cpu().numpy(), x0.numpy())
+    np.testing.assert_array_equal(b.cpu().numpy(), x1.numpy()[j])
+
+
+def test_mlp_inference_accepts_leading_dims_and_keeps_dtype(dev):
+    """The reference's nn.Sequential takes [..., dim]; so does the no-grad HIP path (and float64 comes back float64)."""
+    import cfm_amd
+    torch.manual_seed(0)
+    m = cfm_amd.MLP(dim=3, time_varying=True, w=32).to(dev)
+    x = torch.randn(5, 7, 4, device=dev)
+    with torch.no_grad():
+        y3 = m(x)
+        y2 = m(x.reshape(35, 4))
+        yd = m(x.double())
+    assert y3.shape == (5, 7, 3) and yd.dtype == torch.float64
+    assert torch.equal(y3.reshape(35, 3), y2)
+    ref = m.net(x)          # the plain module graph (PyTorch-ROCm)
+    torch.testing.assert_close(y3, ref, rtol=1e-5, atol=1e-6)

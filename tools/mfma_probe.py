@@ -1,6 +1,6 @@
 """Run the MFMA-bearing kernels of the path a few times each (for rocprofv3 --pmc / --kernel-trace):
-mlp_* (C3 field forward, B=4096), cost_gemm (C3 cost matrix), ode_small_step (C5 dopri5),
-the layer-per-kernel ODE on the C3 field.  Measurement infrastructure; not part of the product path."""
+mlp_* (C3 field forward, B=4096), cost_gemm (C3 cost matrix), ode_small_dopri (C5 dopri5), the
+layer-per-kernel ODE on the C3 field, gemm_f32_mfma (C3 model step: forward, backward, Adam).  Measurement infrastructure; not part of the product path."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -29,4 +29,13 @@ with torch.no_grad():
     nodes = NeuralODE(torch_wrapper(ms), solver="dopri5", atol=1e-4, rtol=1e-4)
     for _ in range(2):
         nodes.trajectory(c0.to(dev), torch.linspace(0, 1, 100))
+# the training step of the C3 model on the library's kernels (forward with saved pre-activations, backward GEMMs, Adam)
+mt = cfm_amd.MLP(dim=784, time_varying=True, w=512).to(dev)
+opt = cfm_amd.FusedAdam(mt.parameters(), lr=1e-4)
+xt = torch.cat([a, t[:, None]], -1)
+for _ in range(5):
+    opt.zero_grad(set_to_none=True)
+    loss = ((mt(xt) - b) ** 2).mean()
+    loss.backward()
+    opt.step()
 torch.cuda.synchronize()

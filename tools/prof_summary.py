@@ -1,6 +1,10 @@
 """Summarise rocprofv3 output directories into the small files kept under profiles/.
     python tools/prof_summary.py stats  <dir> <out.csv>        per-kernel calls / total / avg / min / max (kernel trace)
     python tools/prof_summary.py pmc    <dir> <out.csv>        per-kernel per-counter mean per call
+    python tools/prof_summary.py util   <pmc.csv> <out.csv>    MFMA-busy per kernel from a pmc summary that holds
+                                                               SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE
+    python tools/prof_summary.py asgjson <fetch.csv> <write.csv> <out.json>   HBM bytes per launch of the assignment
+                                                               kernels (FETCH_SIZE x 2 + WRITE_SIZE; bench.py reads it)
 Measurement infrastructure."""
 import collections, csv, glob, os, sys
 
@@ -35,5 +39,45 @@ def pmc(d, out):
                 fh.write(f"\"{k}\",{c},{calls[(k, c)]},{v / calls[(k, c)]:.3f}\n")
 
 
+def util(pmc_csv, out):
+    # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs: busy fraction of the
+    # MFMA pipes = busy / (gui_active / 8 * 1024) = busy / (gui_active * 128)
+    rows = collections.defaultdict(dict)
+    with open(pmc_csv) as fh:
+        for r in csv.DictReader(fh):
+            rows[r["kernel"]][r["counter"]] = float(r["mean_per_call"])
+    with open(out, "w") as fh:
+        fh.write("kernel,SQ_VALU_MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE_sum_over_8_XCDs,MfmaUtil_percent\n")
+        for k, d in sorted(rows.items()):
+            b, g = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), d.get("GRBM_GUI_ACTIVE", 0.0)
+            if b > 0 and g > 0:
+                fh.write(f"\"{k}\",{b:.0f},{g:.0f},{100 * b / (g * 128):.1f}\n")
+
+
+def asgjson(fetch_csv, write_csv, out):
+    import json
+    def load(f, counter):
+        d = {}
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["counter"] == counter:
+                    d[r["kernel"]] = float(r["mean_per_call"])
+        return d
+    fe, wr = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    res = {}
+    for k in ("asg_step", "asg_build", "asg_solve", "asg_small"):
+        if k in fe:
+            res[f"{k}_FETCH_SIZE_KiB_per_launch"] = round(fe[k], 3)
+            res[f"{k}_WRITE_SIZE_KiB_per_launch"] = round(wr.get(k, 0.0), 3)
+    if "asg_step" in fe:
+        res["asg_step_hbm_bytes_per_launch"] = round((2.0 * fe["asg_step"] + wr.get("asg_step", 0.0)) * 1024.0, 3)
+    res["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/asg_trace.py (8 C3 solves); FETCH_SIZE x2 "
+                   "(gfx950 reports half the bytes of wide coalesced reads: calibrated on cost_tiled, which writes its 64 MiB output = "
+                   "65536 KiB of WRITE_SIZE), WRITE_SIZE x1; means include no-op launches")
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    fn = {"stats": stats, "pmc": pmc, "util": util, "asgjson": asgjson}[sys.argv[1]]
+    fn(*sys.argv[2:])

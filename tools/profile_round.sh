@@ -10,6 +10,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/raw/asg_$C -- python tools/asg_trace.py run > $O/asg_$C.log 2>&1
   python tools/prof_summary.py pmc $O/raw/asg_$C $O/asg_pmc_$C.csv
 done
+python tools/prof_summary.py asgjson $O/asg_pmc_FETCH_SIZE.csv $O/asg_pmc_WRITE_SIZE.csv $O/asg_pmc_summary.json
 rocprofv3 --kernel-trace --output-format csv -d $O/raw/asg_trace -- python tools/asg_trace.py run > /dev/null 2>&1
 python tools/asg_trace.py summary $O/raw/asg_trace > $O/asg_trace_summary.txt 2>&1
 python tools/prof_summary.py stats $O/raw/asg_trace $O/asg_kernel_stats.csv
@@ -17,6 +18,7 @@ rocprofv3 --kernel-trace --output-format csv -d $O/raw/mfma_trace -- python tool
 python tools/prof_summary.py stats $O/raw/mfma_trace $O/mfma_kernel_stats.csv
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/raw/mfma_pmc -- python tools/mfma_probe.py > $O/mfma_pmc.log 2>&1
 python tools/prof_summary.py pmc $O/raw/mfma_pmc $O/mfma_pmc.csv
+python tools/prof_summary.py util $O/mfma_pmc.csv $O/mfma_util.csv
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/raw/mfma_pmc2 -- python tools/mfma_probe.py > $O/mfma_pmc2.log 2>&1
 python tools/prof_summary.py pmc $O/raw/mfma_pmc2 $O/mfma_pmc2.csv
 rocprofv3 -L 2>/dev/null | grep -i -E "mfma|FETCH_SIZE|WRITE_SIZE|MfmaUtil" | head -40 > $O/counters_available.txt
