@@ -214,7 +214,22 @@ def cpu_baseline(B, d, budget_s=25.0):
     torch.set_num_threads(threads_max)
     med = np.median(runs, axis=0)
     total = float(med.sum())
-    return {"value": B / total, "unit": "samples/s", "cores": 1, "kind": "port",
+    # CPU Sinkhorn iterations/s: the C restatement of POT's log-domain loop (oracle/sinkhorn_oracle.c,
+    # float64, OpenMP), a fixed 10 iterations on the C2 matrix (B = 4096, d = 2, eps = 0.05)
+    sk_cpu = None
+    try:
+        import sinkhorn_c
+        a0, a1 = oracle.config_inputs("C2")
+        Mc = oracle.ref_cost_f32(a0, a1)
+        sinkhorn_c.sinkhorn_log(Mc, 0.05, numItermax=1, stopThr=0.0)          # warm-up (loads / builds the library)
+        t0 = time.perf_counter(); sinkhorn_c.sinkhorn_log(Mc, 0.05, numItermax=10, stopThr=0.0); dt = time.perf_counter() - t0
+        nth = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+        sk_cpu = {"config": "C2: B=4096, d=2, eps=0.05", "iters_per_s": 10.0 / dt, "cores": nth, "kind": "port",
+                  "sample": f"10 iterations of the float64 log-domain loop in C (oracle/sinkhorn_oracle.c), OpenMP over rows / "
+                            f"columns, {nth} threads"}
+    except Exception as e:                                                        # noqa: BLE001  (no C compiler on the box)
+        sk_cpu = {"error": str(e)[:120]}
+    return {"value": B / total, "unit": "samples/s", "cores": 1, "kind": "port", "sinkhorn_cpu": sk_cpu,
             "s_per_step_median": total, "s_per_step_min": float(runs.sum(1).min()), "runs": int(nrun),
             "breakdown_s": {"cdist2": float(med[0]), "exact_solve_scipy_lsap": float(med[1]),
                             "sample_map_dense_choice": float(med[2]), "gather_xt_ut": float(med[3])},
