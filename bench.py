@@ -174,7 +174,7 @@ def c1_latency(dev, reps=20):
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter(); samp.sample_plan(a, b); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    M = ot.cost_matrix(a, b, matrix_cores=False)
+    M = ot.cost_matrix(a, b)
     tsolve = []
     for _ in range(reps):
         torch.cuda.synchronize(); t0 = time.perf_counter(); ot.assign_exact(M); tsolve.append(time.perf_counter() - t0)
@@ -245,7 +245,7 @@ def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
     Un-overlapped solves on one stream.  Algorithmic bytes per SURVEY §8d: 4 B per row scan (the fp32 cost
     row) + 8 B prices per sweep (= per launch).  Launch durations: the device books the time of every
     step on its own 100 MHz clock (cfm_assign_debug_times); HIP events bracket each solve on its stream."""
-    Ms = [ot.cost_matrix(x0, x1, matrix_cores=False) for (x0, x1) in pool[:nsolves]]
+    Ms = [ot.cost_matrix(x0, x1) for (x0, x1) in pool[:nsolves]]
     ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
     for M in Ms[:2]:
         ot.assign_exact(M)
@@ -335,7 +335,7 @@ def main():
     def couple(x0, x1, drawn):
         """cost -> exact assignment -> sampling -> fused gather + xt/ut, on the CURRENT stream."""
         u_host, t_host = drawn
-        M = ot.cost_matrix(x0, x1, matrix_cores=False)     # as OTPlanSampler(method="exact") does
+        M = ot.cost_matrix(x0, x1)     # as OTPlanSampler(method="exact") does
         perm = ot.assign_exact(M)
         u = torch.from_numpy(u_host).to(dev)
         i, j = ot.sample_perm(perm, u, B)

@@ -71,7 +71,7 @@ def timing(dev, seeds, B=4096, d=784, label=""):
     Ms = []
     for seed in range(1000, 1000 + 1000 * seeds, 1000):
         for (x0, x1) in bench.synth_batches(B, d, 8, seed, dev):
-            Ms.append(ot.cost_matrix(x0, x1, matrix_cores=False))
+            Ms.append(ot.cost_matrix(x0, x1))
     ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
     acc = np.zeros(32); evs = []; stats = []
     chk = 0

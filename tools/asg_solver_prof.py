@@ -15,7 +15,7 @@ B = 4096
 names = ["init/search", "fast batches", "collect", "a-posteriori", "augment", "dense batches", "#fast", "#batches", "-",
          "fb: entries+lists issue", "fb: gathers+lower", "fb: barrier1", "fb: dfree", "fb: phase W", "fb: barrier2", "pending seen"]
 with torch.cuda.stream(torch.cuda.Stream()):
-    Ms = [ot.cost_matrix(x0, x1, matrix_cores=False) for (x0, x1) in bench.synth_batches(B, 784, 8, 1000, dev)]
+    Ms = [ot.cost_matrix(x0, x1) for (x0, x1) in bench.synth_batches(B, 784, 8, 1000, dev)]
     ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
     acc = np.zeros(16)
     for M in Ms:

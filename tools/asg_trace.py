@@ -23,7 +23,7 @@ def run():
     import bench
     _lib.load(); dev = _lib.require_gpu()
     with torch.cuda.stream(torch.cuda.Stream()):
-        Ms = [ot.cost_matrix(x0, x1, matrix_cores=False) for (x0, x1) in bench.synth_batches(4096, 784, 4, 1000, dev)]
+        Ms = [ot.cost_matrix(x0, x1) for (x0, x1) in bench.synth_batches(4096, 784, 4, 1000, dev)]
         for rep in range(2):
             for M in Ms:
                 ot.assign_exact(M)
