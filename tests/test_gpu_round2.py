@@ -503,3 +503,38 @@ def test_mlp_inference_accepts_leading_dims_and_keeps_dtype(dev):
     assert torch.equal(y3.reshape(35, 3), y2)
     ref = m.net(x)          # the plain module graph (PyTorch-ROCm)
     torch.testing.assert_close(y3, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_small_assignment_randomized_families(dev):
+    """160 random instances, n = 2..256, eight cost families (uniform, geometric d = 1..50, small integers, Monge-like,
+    18 orders of magnitude, large offsets, 1-D chains, duplicated columns): always a permutation, always SciPy's
+    optimal cost (tools/asg_small_stress.py runs 600 + three concurrent streams)."""
+    ot = _ot()
+    rng = np.random.RandomState(321)
+    for k in range(160):
+        n = int(rng.randint(2, 257))
+        fam = k % 8
+        if fam == 0:
+            M = rng.rand(n, n) * 10
+        elif fam == 1:
+            d = int(rng.choice([1, 2, 3, 8, 50])); x = rng.randn(n, d); y = rng.randn(n, d) + rng.rand()
+            M = ((x[:, None, :] - y[None]) ** 2).sum(-1)
+        elif fam == 2:
+            M = rng.randint(0, int(rng.choice([2, 5, 50])), size=(n, n)).astype(float)
+        elif fam == 3:
+            M = -np.sort(rng.rand(n))[:, None] * np.sort(rng.rand(n))[None, :]
+        elif fam == 4:
+            M = rng.rand(n, n) ** 8 * 1e4
+        elif fam == 5:
+            M = rng.randn(n, n) * 1e3 + 1e5
+        elif fam == 6:
+            M = np.abs(np.subtract.outer(np.sort(rng.rand(n)), np.sort(rng.rand(n))))
+        else:
+            M = np.repeat(rng.rand(n, (n + 1) // 2), 2, axis=1)[:, :n]
+        Mnp = np.ascontiguousarray(M, dtype=np.float32)
+        perm, info = ot.assign_exact(torch.from_numpy(Mnp).to(dev), return_info=True)
+        p = perm.cpu().numpy().astype(np.int64)
+        assert sorted(p.tolist()) == list(range(n)), (k, n)
+        assert info["stats"][7] & 0x40000000
+        c, cr = oracle.assignment_cost(Mnp, p), oracle.assignment_cost(Mnp, oracle.exact_perm(Mnp))
+        assert c <= cr + 1e-9 * max(1.0, abs(cr), float(np.abs(Mnp).max())), (k, n, fam, c, cr)
