@@ -166,6 +166,10 @@ int cfm_partial_entropic_f64(const float* M, int B0, int B1, double reg, double 
  * stats (device int32[8], may be NULL): {auction_rounds, arr_rounds,
  *  free_rows_after_arr, sap_batches, sap_row_scans, total_row_scans, steps,
  *  eps_phases | multi_source_phases << 8 | dense_fallback_row_scans << 16}.
+ * 2 <= B <= 256 (the reference's tutorial batches) is solved by ONE launch of ONE workgroup
+ * (cost matrix in registers); stats[7] then has bit 30 set and stats[6] = 1.  A solve that hits
+ * that path's round caps is redone by the chip-wide state machine; the call never returns 0
+ * with an uncertified permutation (CFM_ENOCONV instead).
  * ws: cfm_workspace_bytes(CFM_OP_ASSIGN,B,B,0) bytes. */
 int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,
                          double* total_cost, int* stats, void* ws, void* stream);
