@@ -1499,7 +1499,8 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
             if (rc0) return rc0;
         }
         SmaParams Q;
-        Q.theta = P.theta; Q.eps0_frac = P.eps0_frac; Q.eps_last_frac = P.eps_last_frac; Q.stop_frac = P.stop_frac;
+        Q.theta = P.theta; Q.eps0_frac = P.eps0_frac; Q.eps_last_frac = P.eps_last_frac;
+        Q.stop_frac = 0.5 * P.stop_frac;      // a search for a left-over row costs ~100 us here: cut the phases later (measured)
         Q.round_cap = P.round_cap; Q.arr_cap = P.arr_cap; Q.total_cap = 20000;
         int* status = (int*)ws;
         int rc0 = cfm_hip(hipMemsetAsync(status, 0, 64, s));
