@@ -35,14 +35,34 @@ def shard_seed(base, rank):
     return int(base) + int(rank)
 
 
-def all_gather_samples(x):
-    """[B,d] per rank -> [world*B, d] on every rank (single collective; identity at world=1)."""
+def all_gather_samples(x, direct=None):
+    """[B,d] per rank -> [world*B, d] on every rank (identity at world=1).
+
+    Default: one RCCL all-gather.  ``direct=True`` (or CFM_ALLGATHER=direct): the fully connected exchange SURVEY
+    8(e) describes — every rank posts world-1 sends of its block and world-1 receives into the output in one
+    batch, so each of the 7 xGMI links of an MI355X carries exactly one block each way instead of a ring relaying
+    every block over one link.  Which one is faster on an 8-GPU node is not measured here (one GPU per box);
+    both give the same bytes (tests/test_distributed_gloo.py runs both over gloo)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return x
+    world, rank = dist.get_world_size(), dist.get_rank()
     x = x.contiguous()
-    out = torch.empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
-                      device=x.device)
-    dist.all_gather_into_tensor(out, x)
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if direct is None:
+        direct = os.environ.get("CFM_ALLGATHER", "") == "direct"
+    if not direct:
+        dist.all_gather_into_tensor(out, x)
+        return out
+    B = x.shape[0]
+    out[rank * B:(rank + 1) * B].copy_(x)
+    ops = []
+    for k in range(1, world):                      # peer order staggered by rank: no two ranks start on the same link
+        peer = (rank + k) % world
+        src = (rank - k) % world
+        ops.append(dist.P2POp(dist.isend, x, peer))
+        ops.append(dist.P2POp(dist.irecv, out[src * B:(src + 1) * B], src))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
     return out
 
 

@@ -28,6 +28,7 @@ def _worker(rank, world, port, out):
     perm = oracle.exact_perm(oracle.ref_cost_f32(x0, x1))
     local = x1[perm]
     gathered = D.all_gather_samples(local)
+    assert torch.equal(gathered, D.all_gather_samples(local, direct=True))      # the point-to-point form: same bytes
     assert gathered.shape == (world * 32, 2)
     assert torch.equal(gathered[rank * 32:(rank + 1) * 32], local)
     other = 1 - rank
@@ -128,3 +129,28 @@ def test_bench_loop_world_size_2_gloo():
     assert len(out) == 2
     assert out[0][0] == out[1][0] > 0.0          # max-over-ranks time is the same number on both ranks
     assert out[0][1] == out[1][1]                # both hold the same gathered samples
+
+
+def _direct_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from cfm_amd import distributed as D
+    x = torch.full((5, 3), float(rank)) + torch.arange(15.0).reshape(5, 3) / 100
+    a = D.all_gather_samples(x)
+    b = D.all_gather_samples(x, direct=True)
+    assert torch.equal(a, b)
+    for r in range(world):
+        assert torch.equal(b[5 * r:5 * r + 5], torch.full((5, 3), float(r)) + torch.arange(15.0).reshape(5, 3) / 100)
+    out[rank] = float(b.sum())
+    dist.destroy_process_group()
+
+
+def test_direct_all_gather_world_size_3_gloo():
+    """The fully connected point-to-point all-gather with an odd world size: every rank ends up with every
+    block in rank order, identical to the collective."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_direct_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert len(out) == 3 and out[0] == out[1] == out[2]
