@@ -119,7 +119,7 @@ extern "C" void cfm_assign_set_wide_blocks(int cap) { std::lock_guard<std::mutex
 extern "C" void cfm_assign_set_handoff(int handoff) { std::lock_guard<std::mutex> lk(g_params_mu); if (handoff >= 0) g_params.handoff = handoff; }
 extern "C" void cfm_assign_set_stop_early(double f) { std::lock_guard<std::mutex> lk(g_params_mu); if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
 extern "C" void cfm_assign_set_ms_quantile(double) {}   // kept for old tuning scripts: the radius is the largest free-column label
-extern "C" void cfm_assign_set_small(int on) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.small = on ? 1 : 0; }
+extern "C" void cfm_assign_set_small(int on) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.small = on > 0 ? on : 0; }
 extern "C" void cfm_assign_set_bulk(int bulk, int min_n) {
     std::lock_guard<std::mutex> lk(g_params_mu);
     if (bulk >= 0) g_params.bulk = bulk;
@@ -1500,8 +1500,9 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
         }
         SmaParams Q;
         Q.theta = P.theta; Q.eps0_frac = P.eps0_frac; Q.eps_last_frac = P.eps_last_frac;
-        Q.stop_frac = 0.5 * P.stop_frac;      // a search for a left-over row costs ~100 us here: cut the phases later (measured)
+        Q.stop_frac = P.stop_frac;
         Q.round_cap = P.round_cap; Q.arr_cap = P.arr_cap; Q.total_cap = 20000;
+        Q.bid_cap = P.small >= 2 ? P.small - 1 : 1;      // cfm_assign_set_small(k >= 2): k - 1 bids per wave and round
         int* status = (int*)ws;
         int rc0 = cfm_hip(hipMemsetAsync(status, 0, 64, s));
         if (rc0) return rc0;

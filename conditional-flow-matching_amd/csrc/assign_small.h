@@ -17,10 +17,9 @@
 //   phase A  epsilon-scaling forward auction, no award step: the state of an object is one 64-bit LDS word
 //            price << 14 | round << 8 | row ; prices only rise, ds_max_u64 is the award; a row is matched iff the
 //            object it bid for last still carries its id.  A wave bids for its own unmatched rows (top-2 over the
-//            wave in one DPP reduction of (best, second) pairs).  The epsilon > 0 phases run WITHOUT round
-//            barriers (an asynchronous auction: every wave bids with the prices as they are; stale prices only
-//            make a bid smaller, epsilon-CS holds for every accepted bid): a round is as long as its most loaded
-//            wave, and 27 bidders over 16 waves put 4-5 on one of them.  Phases are cut at <= 1 % unmatched.
+//            wave in one DPP reduction of (best, second) pairs).  In the epsilon > 0 phases a wave places ONE bid
+//            per round (a round is as long as its most loaded wave, and 27 bidders over 16 waves put 4-5 on one
+//            of them); Jacobi rounds on a price snapshot: deterministic.  Phases are cut at <= 2 % unmatched.
 //   phase B  the same rounds with epsilon = 0 (JV augmenting row reduction): a kept pair is exactly tight.
 //   phase C  rows that are not tight are released; one Dijkstra search per free row (the wave that owns the
 //            row being scanned relaxes all columns and picks the next one; hand-over through LDS + barrier),
@@ -41,6 +40,7 @@
 struct SmaParams {
     double theta, eps0_frac, eps_last_frac, stop_frac;
     int round_cap, arr_cap, total_cap;
+    int bid_cap;        // bids per wave and round in the epsilon > 0 phases (16 = every unmatched row)
 };
 
 struct SmaShared {
@@ -57,8 +57,6 @@ struct SmaShared {
     unsigned fm[2][SMA_NW];             // per wave: bit r = row (wave + 16 r) is unmatched
     int nfree[2];
     int ctl[8];                         // search hand-over: [0] next row or -1, [1] found column, [2] error
-    int wcnt[SMA_NW];                   // barrier-free auction phases: unmatched rows per wave (as last seen by it)
-    int actl[4];                        // ... [0] phase over, [1] bids of the phase, [2] longest wave loop, [3] cap hit
     double ctld[4];                     // [0] label of the next row, [1] shortest path length
     unsigned long long red[SMA_NW + 2];
     double redd[2 * SMA_NW + 2];
@@ -131,21 +129,15 @@ __device__ __forceinline__ SmaTop sma_top2(const float4& c, const double (&p)[4]
     return t;
 }
 
-// One bid of the barrier-free auction phases: the prices are read from the object words as they are NOW (another
-// wave may have raised some since this wave last looked).  Stale-low prices only make the bid smaller: with
-// p_true >= p_seen for every column, c_ij1 + bid = second_seen + eps <= second_true + eps, so epsilon-CS holds for
-// an accepted bid, and a bid below the current word is simply not accepted by the ds_max.  The row's match is
-// written unconditionally: it counts only while the object word carries the row id.
-__device__ __forceinline__ void sma_bid_async(SmaShared& sh, const float4& c, int i, double eps, double mcs, double S, int lane) {
-    const ulonglong2 ka = *reinterpret_cast<const ulonglong2*>(&sh.key[4 * lane]);
-    const ulonglong2 kb = *reinterpret_cast<const ulonglong2*>(&sh.key[4 * lane + 2]);
-    const double p[4] = {sma_f64(ka.x >> SMA_SHIFT), sma_f64(ka.y >> SMA_SHIFT), sma_f64(kb.x >> SMA_SHIFT), sma_f64(kb.y >> SMA_SHIFT)};
+// one bid (prices = the round's snapshot p): wave top-2, then lane 0 raises the object word
+__device__ __forceinline__ void sma_bid(SmaShared& sh, const float4& c, const double (&p)[4], int i, double eps, unsigned rnd,
+                                        double mcs, double S, int lane) {
     const SmaTop t = sma_top2(c, p, mcs, S, lane);
     if (lane == 0) {
         const double pnew = floor(t.pold + ((t.w2 - t.w1) + eps));     // DOWN onto the price grid
         if (pnew < 1.0e15) {
-            atomicMax(&sh.key[t.j1], (sma_u64(pnew) << SMA_SHIFT) | (unsigned long long)(unsigned)i);
-            sh.arow[i] = (short)t.j1;
+            atomicMax(&sh.key[t.j1], (sma_u64(pnew) << SMA_SHIFT) | (unsigned long long)((rnd << SMA_RB) | (unsigned)i));
+            sh.bidcol[i] = (short)t.j1;
         }
     }
 }
@@ -271,74 +263,13 @@ __global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mra
     const double eps_last = P.eps_last_frac * CM;
     const int stop = (int)(P.stop_frac * n);
     int mode = 0;                     // 0 auction, 1 epsilon = 0 rounds
-    int cur = 0, arr_round = 0, rounds_total = 0, st_auction = 0, st_arr = 0, st_scans = 0, err = 0;
+    int cur = 0, round = 0, arr_round = 0, rounds_total = 0, st_auction = 0, st_arr = 0, st_scans = 0, err = 0;
     if (!finite) err = 3;
     while (!err) {
-        if (mode == 0) {
-            // ---- an epsilon > 0 phase WITHOUT round barriers: every wave keeps bidding for its own unmatched rows
-            // (one at a time, prices as they are) until <= stop rows are unmatched chip... workgroup-wide.  A round
-            // structure makes every round as long as its most loaded wave (27 bidders over 16 waves: 4-5 on one of
-            // them) plus two barriers; measured 0.92 ms for the rounds of C1, this loop: see DESIGN.md.
-            if (tid < SMA_NW) { int k = 0; for (int r = 0; r < 16; ++r) k += (tid + 16 * r < n) ? 1 : 0; sh.wcnt[tid] = k; }
-            if (tid < 4) sh.actl[tid] = 0;
-            sma_sync();
-            {
-                int it = 0, nb = 0;
-                for (;;) {
-                    const int i = wv + 16 * (lane & 15);
-                    bool fr = false;
-                    if (lane < 16 && i < n) {
-                        const int a = sh.arow[i];
-                        fr = a < 0 || (int)(sh.key[a] & 0xffull) != i;
-                    }
-                    const unsigned mk = (unsigned)(__ballot(fr) & 0xffffull);
-                    const int nf = __popc(mk);
-                    if (lane == 0) sh.wcnt[wv] = nf;
-                    if ((it & 3) == 0 || nf == 0) {
-                        int c = (lane < SMA_NW) ? sh.wcnt[lane] : 0;
-                        c = wave_sum_i(c);
-                        if (c <= stop && lane == 0) sh.actl[0] = 1;
-                    }
-                    if (++it > P.round_cap * 4) { if (lane == 0) { sh.actl[3] = 1; sh.actl[0] = 1; } }
-                    if (__builtin_amdgcn_readfirstlane(sh.actl[0])) break;
-                    if (nf == 0) { __builtin_amdgcn_s_sleep(8); continue; }
-                    const int r = __builtin_amdgcn_readfirstlane(__ffs((int)mk) - 1);
-                    const int ib = wv + 16 * r;
-                    ++nb;
-                    switch (r) {
-#define SMA_CASE(R) case R: sma_bid_async(sh, m[R], ib, eps, mcs, S, lane); break;
-                        SMA_CASE(0) SMA_CASE(1) SMA_CASE(2) SMA_CASE(3) SMA_CASE(4) SMA_CASE(5) SMA_CASE(6) SMA_CASE(7)
-                        SMA_CASE(8) SMA_CASE(9) SMA_CASE(10) SMA_CASE(11) SMA_CASE(12) SMA_CASE(13) SMA_CASE(14)
-                        default: sma_bid_async(sh, m[15], ib, eps, mcs, S, lane); break;
-#undef SMA_CASE
-                    }
-                }
-                if (lane == 0) { atomicAdd(&sh.actl[1], nb); atomicMax(&sh.actl[2], it); }
-            }
-            sma_sync();
-            st_scans += sh.actl[1]; st_auction += sh.actl[2];
-            if (sh.actl[3]) { err = 1; break; }
-            {
-                const double e2 = eps / P.theta;
-                if (e2 < eps_last) { mode = 1; eps = 0.0; arr_round = 0; }
-                else eps = fmax(1.0, __builtin_rint(e2));
-            }
-            // every row is unmatched again, the prices stay (and the round-based epsilon = 0 rounds get their snapshot)
-            sma_sync();
-            if (tid < SMA_N) { sh.arow[tid] = -1; sh.bidcol[tid] = -1; sh.pd[tid] = sma_f64(sh.key[tid] >> SMA_SHIFT); }
-            if (tid < SMA_NW) {
-                unsigned mk2 = 0u;
-                for (int r = 0; r < 16; ++r) if (tid + 16 * r < n) mk2 |= 1u << r;
-                sh.fm[cur][tid] = mk2; sh.fm[cur ^ 1][tid] = 0u;
-            }
-            if (tid == 0) { sh.nfree[cur] = n; sh.nfree[cur ^ 1] = 0; }
-            sma_sync();
-            continue;
-        }
         const int nxt = cur ^ 1;
         const int cnt = sh.nfree[cur];
         {
-            const unsigned mk = sh.fm[cur][wv];
+            const unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)sh.fm[cur][wv]);
             if (mk) {
                 double p[4];
                 {
@@ -346,20 +277,31 @@ __global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mra
                     const double2 pb = *reinterpret_cast<const double2*>(&sh.pd[4 * lane + 2]);
                     p[0] = pa.x; p[1] = pa.y; p[2] = pb.x; p[3] = pb.y;
                 }
-                const unsigned rnd = (unsigned)(arr_round + 1);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if ((mk >> r) & 1u) {
-                        const int i = wv + 16 * r;
-                        const SmaTop t = sma_top2(m[r], p, mcs, S, lane);
-                        if (lane == 0) {
-                            const double pnew = floor(t.pold + ((t.w2 - t.w1) + eps));     // DOWN onto the price grid
-                            if (pnew < 1.0e15) {
-                                atomicMax(&sh.key[t.j1], (sma_u64(pnew) << SMA_SHIFT) | (unsigned long long)((rnd << SMA_RB) | (unsigned)i));
-                                sh.bidcol[i] = (short)t.j1;
-                            }
+                if (mode == 0) {
+                    // epsilon > 0: ONE bid per wave and round (P.bid_cap; its other unmatched rows wait a round).
+                    // Uncapped, a round is as long as its most loaded wave, and 27 bidders over 16 waves put 4-5 on
+                    // one of them.  Measured over 7 instances (n = 64 .. 256): cap 1: 4.88 ms in total, cap 3: 4.91,
+                    // uncapped: 5.64; the fair share ceil(unmatched / 16): 6.4; a barrier-free asynchronous auction
+                    // (same critical path, emulated in tools/proto/asg_small_async_sim.py) was as fast as cap 1 but
+                    // not deterministic on tied costs.  Jacobi rounds on a price snapshot: the same result every run.
+                    const int cap = P.bid_cap;
+                    unsigned left = mk;
+                    for (int k = 0; k < cap && left; ++k) {
+                        const int r = __ffs((int)left) - 1;
+                        left &= left - 1u;
+                        switch (r) {
+#define SMA_CASE(R) case R: sma_bid(sh, m[R], p, wv + 16 * R, eps, 0u, mcs, S, lane); break;
+                            SMA_CASE(0) SMA_CASE(1) SMA_CASE(2) SMA_CASE(3) SMA_CASE(4) SMA_CASE(5) SMA_CASE(6) SMA_CASE(7)
+                            SMA_CASE(8) SMA_CASE(9) SMA_CASE(10) SMA_CASE(11) SMA_CASE(12) SMA_CASE(13) SMA_CASE(14)
+                            default: sma_bid(sh, m[15], p, wv + 240, eps, 0u, mcs, S, lane); break;
+#undef SMA_CASE
                         }
                     }
+                } else {
+                    const unsigned rnd = (unsigned)(arr_round + 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((mk >> r) & 1u) sma_bid(sh, m[r], p, wv + 16 * r, eps, rnd, mcs, S, lane);
                 }
             }
         }
@@ -378,8 +320,27 @@ __global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mra
         cur = nxt;
         st_scans += cnt;
         if (++rounds_total > P.total_cap) { err = 1; break; }
-        ++st_arr; ++arr_round;                                  // (only the epsilon = 0 rounds come through here)
-        if (cnt == 0 || arr_round >= P.arr_cap) break;
+        if (mode == 0) {
+            ++st_auction; ++round;
+            if (cnt <= stop || round >= P.round_cap) {
+                const double e2 = eps / P.theta;
+                if (e2 < eps_last) { mode = 1; eps = 0.0; arr_round = 0; }
+                else eps = fmax(1.0, __builtin_rint(e2));
+                round = 0;
+                // every row is unmatched again, the prices stay
+                if (tid < SMA_N) sh.arow[tid] = -1;
+                if (tid < SMA_NW) {
+                    unsigned mk2 = 0u;
+                    for (int r = 0; r < 16; ++r) if (tid + 16 * r < n) mk2 |= 1u << r;
+                    sh.fm[cur][tid] = mk2;
+                }
+                if (tid == 0) sh.nfree[cur] = n;
+                sma_sync();
+            }
+        } else {
+            ++st_arr; ++arr_round;
+            if (cnt == 0 || arr_round >= P.arr_cap) break;
+        }
     }
 
     const unsigned long long tk2 = wall_clock64();

@@ -18,11 +18,12 @@ def colred(C):
     u = C.min(1)
     return (u[:, None] - C).max(0)
 
+rounds_box = [0]
 def run(C, mode, theta=5.0, eps0=8e-3, epsl=1e-6, stop_frac=0.02, NW=16):
     n = C.shape[0]; rng = C.max() - C.min()
     P = colred(C); P = P - P.min()
     eps = eps0 * rng; eps_last = epsl * rng; stop = int(stop_frac * n)
-    bids = 0; timeu = 0
+    bids = 0; timeu = 0; rounds_box[0] = 0
     while True:
         owner = -np.ones(n, int); arow = -np.ones(n, int)
         if mode == "jacobi":
@@ -37,6 +38,28 @@ def run(C, mode, theta=5.0, eps0=8e-3, epsl=1e-6, stop_frac=0.02, NW=16):
                 best = {}
                 for k in range(len(free)):
                     key = (newP[k], free[k])
+                    if j1[k] not in best or key > best[j1[k]]: best[j1[k]] = key
+                for j, (p, i) in best.items():
+                    if p > P[j]:
+                        if owner[j] >= 0: arow[owner[j]] = -1
+                        P[j] = p; owner[j] = i; arow[i] = j
+        elif mode.startswith("cap"):
+            cap = int(mode[3:])
+            while True:
+                free = np.nonzero(arow < 0)[0]
+                if len(free) <= stop: break
+                # Jacobi round in which every wave bids for at most `cap` of its unmatched rows (snapshot prices)
+                sel = []; cntw = np.zeros(NW, int)
+                for i in free:
+                    if cntw[i % NW] < cap: sel.append(i); cntw[i % NW] += 1
+                sel = np.array(sel); timeu += cntw.max(); bids += len(sel); rounds_box[0] += 1
+                W = C[sel] + P[None, :]
+                j1 = W.argmin(1); w1 = W[np.arange(len(sel)), j1]
+                W[np.arange(len(sel)), j1] = np.inf; w2 = W.min(1)
+                newP = P[j1] + (w2 - w1) + eps
+                best = {}
+                for k in range(len(sel)):
+                    key = (newP[k], sel[k])
                     if j1[k] not in best or key > best[j1[k]]: best[j1[k]] = key
                 for j, (p, i) in best.items():
                     if p > P[j]:
@@ -68,4 +91,6 @@ if __name__ == "__main__":
     for kind, n in (("g2", 256), ("g2", 256), ("g2", 128), ("g784", 256), ("u", 256)):
         C = instance(kind, n, rs)
         bj, tj = run(C, "jacobi"); ba, ta = run(C, "async")
-        print(f"{kind} n={n}: jacobi bids {bj} critical path {tj} | async bids {ba} critical path {ta}")
+        b1, t1 = run(C, "cap1"); r1 = rounds_box[0]; b2, t2 = run(C, "cap2"); r2 = rounds_box[0]
+        print(f"{kind} n={n}: jacobi bids {bj} critical path {tj} | async bids {ba} critical path {ta} | "
+              f"capped rounds: cap 1 {r1} rounds ({b1} bids), cap 2 {r2} rounds, path {t2} ({b2} bids)")
