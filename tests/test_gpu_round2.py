@@ -434,7 +434,9 @@ def test_small_assignment_one_workgroup_vs_scipy(dev, name, Mnp, unique):
     lib = _lib.load()
     M = torch.from_numpy(np.ascontiguousarray(Mnp)).to(dev)
     perm, info = ot.assign_exact(M, return_info=True)
-    assert info["certified"] and (info["stats"][7] & 0x40000000), info
+    assert info["certified"], info
+    # (heavily tied costs — most rows not exactly tight after the auction — are handed to the chip-wide machine)
+    assert (info["stats"][7] & 0x40000000) or not unique, info
     p = perm.cpu().numpy().astype(np.int64)
     n = len(p)
     assert sorted(p.tolist()) == list(range(n))
@@ -511,6 +513,7 @@ def test_small_assignment_randomized_families(dev):
     optimal cost (tools/asg_small_stress.py runs 600 + three concurrent streams)."""
     ot = _ot()
     rng = np.random.RandomState(321)
+    on_small = 0
     for k in range(160):
         n = int(rng.randint(2, 257))
         fam = k % 8
@@ -535,6 +538,7 @@ def test_small_assignment_randomized_families(dev):
         perm, info = ot.assign_exact(torch.from_numpy(Mnp).to(dev), return_info=True)
         p = perm.cpu().numpy().astype(np.int64)
         assert sorted(p.tolist()) == list(range(n)), (k, n)
-        assert info["stats"][7] & 0x40000000
+        on_small += bool(info["stats"][7] & 0x40000000)
         c, cr = oracle.assignment_cost(Mnp, p), oracle.assignment_cost(Mnp, oracle.exact_perm(Mnp))
         assert c <= cr + 1e-9 * max(1.0, abs(cr), float(np.abs(Mnp).max())), (k, n, fam, c, cr)
+    assert on_small >= 100, on_small        # the generic families stay on the one-workgroup path
