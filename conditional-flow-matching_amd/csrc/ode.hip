@@ -743,6 +743,11 @@ static int ode_dopri5_small(const float* const* W, const float* const* b, const 
     const int tiles = (B + SM_ROWS - 1) / SM_ROWS;
     int grid = tiles < resident ? tiles : resident;
     if (grid > SM_MAXGRID) grid = SM_MAXGRID;
+    // One persistent solve at a time per process: two of them launched from two streams could each get only part
+    // of their workgroups resident and wait for the rest forever (the bounded wait would turn that into
+    // CFM_ETIMEOUT after 4 s).  The call is synchronous anyway: the lock is held until the solve has finished.
+    static std::mutex persistent_mu;
+    std::lock_guard<std::mutex> persistent_lock(persistent_mu);
     if (tiles <= grid)
         hipLaunchKernelGGL(ode_small_dopri<true>, dim3(grid), dim3(256), lds, s, A, B, d, st, xbuf, kbuf, tspan_dev, n_t, atol,
                            rtol, traj, partial, lines, 1000000);

@@ -542,3 +542,35 @@ def test_small_assignment_randomized_families(dev):
         c, cr = oracle.assignment_cost(Mnp, p), oracle.assignment_cost(Mnp, oracle.exact_perm(Mnp))
         assert c <= cr + 1e-9 * max(1.0, abs(cr), float(np.abs(Mnp).max())), (k, n, fam, c, cr)
     assert on_small >= 100, on_small        # the generic families stay on the one-workgroup path
+
+
+def test_two_threads_sampling_concurrently_with_persistent_dopri5(dev):
+    """Two host threads, two streams, both integrating with the persistent dopri5 kernel at a batch that fills the
+    chip (each launch needs all its workgroups resident): the library serialises the solves instead of letting the
+    two grids starve each other; both results equal the single-threaded one bit for bit."""
+    import threading
+    import cfm_amd
+    from cfm_amd.ode import NeuralODE
+    from cfm_amd.utils import torch_wrapper
+    torch.manual_seed(1)
+    model = cfm_amd.MLP(dim=6, time_varying=True, w=64).to(dev)
+    x = torch.randn(8192, 6).to(dev)
+    ts = torch.linspace(0, 1, 12)
+    with torch.no_grad():
+        ref = NeuralODE(torch_wrapper(model), solver="dopri5", atol=1e-4, rtol=1e-4).trajectory(x, ts).cpu()
+    out, errs = {}, []
+
+    def work(k):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()), torch.no_grad():
+                node = NeuralODE(torch_wrapper(model), solver="dopri5", atol=1e-4, rtol=1e-4)
+                for _ in range(4):
+                    out[k] = node.trajectory(x, ts).cpu()
+        except Exception as e:       # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert torch.equal(out[0], ref) and torch.equal(out[1], ref)
