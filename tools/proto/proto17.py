@@ -2,7 +2,7 @@
 # does) vs multi-source forest phases (what the wide phases do, here carried to the end).
 # Counts label-correcting rounds and row relaxations ("scans": one list entry of a solver batch).
 import numpy as np, sys, copy
-sys.path.insert(0,'scratch')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
 from proto import auction_phase
 from proto5 import bench_batch, cost32
 from proto7 import col_reduce

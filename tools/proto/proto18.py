@@ -3,7 +3,7 @@
 # last rows: a reference for moving the multi-source phases of phase C into the one-workgroup solver.
 # Validated against SciPy's optimum; counts batches (<= 64 list entries each).
 import numpy as np, sys
-sys.path.insert(0,'scratch')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
 from proto import auction_phase
 from proto4 import build_lists, sap_sparse
 from proto5 import bench_batch, cost32
