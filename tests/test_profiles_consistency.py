@@ -1,0 +1,56 @@
+"""The committed measurement artefacts are self-consistent: the `roofline` object of the committed bench line can be
+re-derived from its own fields, its `traffic` is the figure of the committed PMC passes, and the rocprofv3 kernel
+statistics of the same command carry the kernels the line talks about."""
+import csv
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+
+
+def _bench():
+    with open(os.path.join(PROF, "r2_bench_default.json")) as fh:
+        return json.loads(fh.read().strip().splitlines()[-1])
+
+
+def test_bench_line_contract_fields():
+    d = _bench()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = samples of all timed steps / wall time
+    assert d["value"] == pytest.approx(d["config"]["batch_per_gpu"] / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_roofline_rederivable_from_its_fields_and_the_pmc_passes():
+    r = _bench()["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    # achieved = algorithmic bytes per launch / average launch duration
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9, rel=1e-6)
+    with open(os.path.join(PROF, "r2_asg_pmc_summary.json")) as fh:
+        pmc = json.load(fh)
+    assert r["traffic"] == pytest.approx(pmc["asg_step_hbm_bytes_per_launch"], rel=1e-9)
+    assert pmc["asg_step_hbm_bytes_per_launch"] == pytest.approx(
+        (2.0 * pmc["asg_step_FETCH_SIZE_KiB_per_launch"] + pmc["asg_step_WRITE_SIZE_KiB_per_launch"]) * 1024.0, rel=1e-9)
+    # traffic well above the algorithmic bytes would mean wasted re-reads: it is within 25 % of them
+    assert r["traffic"] <= 1.25 * r["algorithmic_bytes_per_launch"]
+
+
+def test_kernel_statistics_of_the_same_command_are_committed():
+    with open(os.path.join(PROF, "r2_bench_kernel_stats.csv")) as fh:
+        rows = {row["kernel"]: row for row in csv.DictReader(fh)}
+    for k in ("asg_step", "asg_solve", "asg_small"):
+        assert k in rows and int(rows[k]["calls"]) > 0, k
+    assert any(k.startswith("void gemm_f32_mfma") for k in rows)          # the model step runs on this library's kernels
+    assert any(k.startswith("void ode_small_dopri") for k in rows)
+    with open(os.path.join(PROF, "r2_mfma_util.csv")) as fh:
+        util = {row["kernel"]: float(row["MfmaUtil_percent"]) for row in csv.DictReader(fh)}
+    assert all(0.0 < v <= 100.0 for v in util.values()) and len(util) >= 4
