@@ -246,6 +246,40 @@ def cpu_baseline(B, d, budget_s=25.0):
                       f"reference's dense-plan np.random.choice sampling + eager xt/ut; host has {os.cpu_count()} cores"}
 
 
+def parity_leg(dev, ot, budget_s=60.0):
+    """Results parity of the product path against the REFERENCE path on the same inputs, reported in the line
+    (VERDICT r2 Next #1): exact-OT plan indices of cost kernel + HIP solver vs LSAP on the reference's own fp32
+    matrix torch.cdist(x0, x1) ** 2 (optimal_transport.py:84-87; SciPy LSAP in float64 = the support of pot.emd
+    with uniform equal marginals, and the reference's own solver at :179).  The oracle is the checker here, never
+    the thing measured.  c3: BASELINE configs[2] (B = 4096, d = 784).  c2: the d = 2 clouds of configs[1] used
+    with the exact method, where SURVEY 0.5 found the optimum to be decided below fp32 cost rounding (18 of 4096
+    indices differed between two fp32 roundings of the same matrix): the index agreement is reported together with
+    the cost gap of the two optima priced on the reference's matrix."""
+    import cfm_oracle as oracle
+    out = {}
+
+    def one(cfg, B):
+        x0, x1 = oracle.config_inputs(cfg, B=B)
+        Mref = oracle.ref_cost_f32(x0, x1)
+        t0 = time.perf_counter(); ref = oracle.exact_perm(Mref); t_cpu = time.perf_counter() - t0
+        perm = ot.assign_exact(ot.cost_matrix(x0.to(dev), x1.to(dev))).cpu().numpy()
+        M64 = Mref.astype(np.float64); ar = np.arange(B)
+        c_ref, c_gpu = float(M64[ar, ref].sum()), float(M64[ar, perm].sum())
+        return float((perm == ref).mean()), (c_gpu - c_ref) / abs(c_ref), t_cpu
+
+    agree, gap, t3 = one("C3", 4096)
+    out.update({"c3_index_agreement": agree, "c3_cost_gap_rel": gap, "c3_B": 4096})
+    agree, gap, t2 = one("C2", 2048)
+    Bc2 = 2048
+    if 10.0 * t2 + t3 < budget_s:                       # LSAP on d = 2 clouds: ~8x per doubling
+        agree, gap, _ = one("C2", 4096); Bc2 = 4096
+    out.update({"c2_index_agreement": agree, "c2_cost_gap_rel": gap, "c2_B": Bc2,
+                "note": "index agreement = fraction of rows whose plan index equals LSAP (float64) on the reference's "
+                        "torch.cdist**2 fp32 matrix; cost gap = (cost of the product path's permutation - optimum) / "
+                        "optimum, both priced on the reference's matrix"})
+    return out
+
+
 def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
     """Dominant kernel of the step: asg_step (every chip-wide step of the exact-assignment state machine).
     Un-overlapped solves on one stream.  Algorithmic bytes per SURVEY §8d: 4 B per row scan (the fp32 cost
@@ -488,6 +522,7 @@ def main():
                            "traffic": None, "note": "reported at N = 1 only"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, d)
+        out["parity"] = parity_leg(dev, ot)
     print(json.dumps(out))
 
 

@@ -98,7 +98,7 @@ struct AsgParams {
 // Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
 // called from another thread never tear a running solve.
 static std::mutex g_params_mu;
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 10, 800000, 1, 6, 0.0, 0, 160, 1024, 1};
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 15, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1};
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
@@ -116,7 +116,10 @@ extern "C" void cfm_assign_set_mode(int sparse) { std::lock_guard<std::mutex> lk
 // Upper bound on the workgroups of the wide kernels (0 = none): with several couplings in flight on
 // different streams a smaller grid lets their kernels run side by side.
 extern "C" void cfm_assign_set_wide_blocks(int cap) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.wide_blocks_cap = cap > 0 ? cap : 0; }
-extern "C" void cfm_assign_set_handoff(int handoff) { std::lock_guard<std::mutex> lk(g_params_mu); if (handoff >= 0) g_params.handoff = handoff; }
+extern "C" void cfm_assign_set_handoff(int handoff) {      // at most 64 free rows: one root slot each in the list solver
+    std::lock_guard<std::mutex> lk(g_params_mu);
+    if (handoff >= 0) g_params.handoff = handoff > 64 ? 64 : handoff;
+}
 extern "C" void cfm_assign_set_stop_early(double f) { std::lock_guard<std::mutex> lk(g_params_mu); if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
 extern "C" void cfm_assign_set_ms_quantile(double) {}   // kept for old tuning scripts: the radius is the largest free-column label
 extern "C" void cfm_assign_set_small(int on) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.small = on > 0 ? on : 0; }
@@ -865,6 +868,7 @@ __device__ __forceinline__ void wide_cert(gfp M, const AsgWs& w, AsgState* st, i
 
 #include "assign_sparse.h"
 #include "assign_small.h"
+static_assert(SP_ROOTS == 64, "the hand-off threshold (cfm_assign_set_handoff) is capped at the solver's root slots");
 
 // ------------------------------------------------- one-workgroup helpers -----
 #define CT WT

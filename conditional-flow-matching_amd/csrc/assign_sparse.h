@@ -29,10 +29,14 @@
 #define SP_NMAX 4096
 #define SP_NOCOL 0xffffu
 #define SP_DENSE 0x8000u      // list entry: relax over the full matrix row
-#define SP_ROOT 0x4000u       // list entry: the free root row of the search
+#define SP_ROOT 0x4000u       // list entry: a free root row of the phase (low bits: its root slot, not a column)
 #define SP_COLMASK 0x0fffu
 #define SP_STALE 0x80000000u  // pred[k]: not improved in the current batch
 #define SP_MARK 0x7fffffffu   // pred[k]: improved in this batch, winner not chosen yet
+#define SP_ROOTS 64           // a phase grows one tree per free row, at most this many (= the hand-off threshold)
+#define SP_ROWMASK 0x0fffu    // pred[k] = root slot << 12 | predecessor row  (| SP_STALE)
+#define SP_SLOT(pr) (((pr) >> 12) & 63u)
+#define SP_TNONE 0x7fffffff   // tcol[slot]: the tree accepted no free column
 
 #define SP_BUILD_WAVES 8   // waves per workgroup that build lists
 #define SP_CAP 64          // list entries per batch (16 waves x 4 entries kept in registers)
@@ -58,6 +62,12 @@ struct SpL {
     unsigned short* lcol;    // scan list: column | flags
     double* rd;              // 64 doubles of scratch
     int* ri;                 // 128 ints of scratch
+    // multi-source phase: one tree per free row ("root slot" s)
+    double* ru;                  // [SP_ROOTS] u of the root row = min_k (c + p)
+    unsigned long long* tmin;    // [SP_ROOTS] smallest free-column label of the tree (bit pattern; ~0: none)
+    int* tcol;                   // [SP_ROOTS] accepted free column
+    unsigned short* rrow;        // [SP_ROOTS] root row of the slot (compacted free-row list)
+    unsigned char* rdn;          // [SP_ROOTS] root row already relaxed over its full matrix row
 };
 // scratch slots
 #define SP_RI_NPL 64     // pending-list length (atomic append counter)
@@ -65,6 +75,10 @@ struct SpL {
 #define SP_RI_FLAG 66
 #define SP_RD_DFREE 48   // best free-column label
 #define SP_RD_FAR 49     // labels above this are only flagged (inl = 2), not listed, until the near list is empty
+#define SP_RI_RBAD 120   // 2 ints: mask of the root slots that failed the a-posteriori test
+#define SP_RI_NFC 122    // free columns / free rows left after a phase
+#define SP_RI_NFR 123
+#define SP_RI_ANYD 124   // some root of the phase starts dense
 
 __device__ __forceinline__ SpL sp_carve(char* lds, int n) {
     SpL L; char* q = lds; const size_t N = (size_t)n;
@@ -73,6 +87,11 @@ __device__ __forceinline__ SpL sp_carve(char* lds, int n) {
     L.ri = (int*)q; q += 128 * 4;
     L.lcol = (unsigned short*)q; q += SP_CAP * 2;
     q += 128;   // 512 + 512 + 512 + 128 + 128 = 1792: keeps the arrays below 16-byte aligned
+    L.ru = (double*)q; q += SP_ROOTS * 8;
+    L.tmin = (unsigned long long*)q; q += SP_ROOTS * 8;
+    L.tcol = (int*)q; q += SP_ROOTS * 4;
+    L.rrow = (unsigned short*)q; q += SP_ROOTS * 2;
+    L.rdn = (unsigned char*)q; q += SP_ROOTS;          // + 1472 = 3264 (a multiple of 16) of the 4096 reserved
     L.p = (double*)q; q += 8 * N;
     L.dist = (double*)q; q += 8 * N;
     L.pred = (unsigned*)q; q += 4 * N;
@@ -316,15 +335,18 @@ __device__ __forceinline__ double sp_cand(double pk, float c, double rj, double 
     return base + rc;
 }
 
-// generic entry (dense entries allowed); recomputed in phase W
+// generic entry (dense entries allowed); recomputed in phase W.  A root entry carries its root slot, a
+// column entry inherits the slot of the tree that gave the column its label (pred[j]).
 template <bool PHASE_W>
 __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, int n,
-                                         unsigned e, double base, int i0, double u0, int lane, int plcur,
+                                         unsigned e, double base, int lane, int plcur,
                                          double dfree, double far_thr) {
     const bool dense = (e & SP_DENSE) != 0, root = (e & SP_ROOT) != 0;
     const int j = root ? -1 : (int)(e & SP_COLMASK);
-    const int i = root ? i0 : (int)L.owner[j];
-    double rj = u0;
+    const unsigned slot = root ? (e & 63u) : SP_SLOT(L.pred[j]);
+    const int i = root ? (int)L.rrow[slot] : (int)L.owner[j];
+    const unsigned claim = (slot << 12) | (unsigned)i;
+    double rj = root ? L.ru[slot] : 0.0;
     if (!dense) {
         const uint2 cl = w.cl[(size_t)i * SP_K + lane];
         const unsigned col = cl.x; const float c = __uint_as_float(cl.y);
@@ -338,7 +360,7 @@ __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, in
         }
         if (valid && (int)col != j) {
             const double cand = sp_cand(L.p[col], c, rj, base);
-            if (PHASE_W) sp_claim(L, (int)col, cand, (unsigned)i, L.dist[col], L.pred[col], plcur, far_thr);
+            if (PHASE_W) sp_claim(L, (int)col, cand, claim, L.dist[col], L.pred[col], plcur, far_thr);
             else if (cand < dfree) sp_lower(L, (int)col, cand, L.dist[col]);
         }
     } else {
@@ -353,7 +375,7 @@ __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, in
                 const int k = k0 + q * 64 + lane;
                 if (k < n && k != j) {
                     const double cand = sp_cand(L.p[k], c[q], rj, base);
-                    if (PHASE_W) sp_claim(L, k, cand, (unsigned)i, L.dist[k], L.pred[k], plcur, far_thr);
+                    if (PHASE_W) sp_claim(L, k, cand, claim, L.dist[k], L.pred[k], plcur, far_thr);
                     else if (cand < dfree) sp_lower(L, k, cand, L.dist[k]);
                 }
             }
@@ -361,11 +383,27 @@ __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, in
     }
 }
 
-// best free column label (one wave)
-__device__ __forceinline__ double sp_dfree(const SpL& L, int nFC, int lane) {
-    double lm = INFINITY;
-    for (int t = lane; t < nFC; t += 64) lm = fmin(lm, L.dist[L.fcol[t]]);
-    return sp_wave_min(lm);
+// Radius of the phase (one wave; at most SP_ROOTS free columns, lane <-> free column).  Every tree that has reached
+// a free column will accept its nearest one, so nothing at or above
+//     R = max over those trees of (smallest free-column label of the tree)
+// can matter any more.  The radius only ever shrinks (min with the current one): an entry skipped once is never
+// needed later, whatever happens to the trees afterwards — the finish accepts labels <= the final radius only, and
+// every label below it is final.  The tree of a column is the root slot in its predecessor word; a column lowered
+// in the batch that is still being claimed (SP_MARK) has no tree yet: the radius then stays as it is for one batch.
+__device__ __forceinline__ double sp_radius(const SpL& L, int nFC, int lane, double dfree) {
+    L.tmin[lane] = ~0ull;
+    double d = INFINITY; unsigned pr = SP_MARK;
+    if (lane < nFC) { const int k = L.fcol[lane]; d = L.dist[k]; pr = L.pred[k] & 0x7fffffffu; }
+    const bool have = d < INFINITY;
+    const bool unknown = have && pr == SP_MARK;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reset before the minima (same wave: LDS is in order)
+    if (have && !unknown) atomicMin(&L.tmin[SP_SLOT(pr)], (unsigned long long)__double_as_longlong(d));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long tm = L.tmin[lane];
+    const double mine = (tm == ~0ull) ? -INFINITY : __longlong_as_double((long long)tm);
+    double R = sp_wave_max(mine);
+    if (!(R > -INFINITY) || __ballot(unknown)) R = INFINITY;
+    return fmin(dfree, R);
 }
 
 #ifdef SP_PROFILE
@@ -381,11 +419,11 @@ __device__ __forceinline__ double sp_rfl_d(double v) {
 
 // One batch of <= SP_CAP sparse entries.  Written in stages over the (at most SP_E) entries
 // of this wave so that the LDS / global round trips of different entries overlap; everything
-// that is uniform over the wave (entry, row, base label, the lane holding the matched edge)
+// that is uniform over the wave (entry, row, tree, base label, the lane holding the matched edge)
 // is moved to scalar registers so the control flow is scalar.  Candidates stay in registers
-// between the two phases.  The last wave also refreshes dfree (published through LDS).
+// between the two phases.  The last wave also refreshes the radius (published through LDS).
 __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& L,
-                                              int n, int nS, int nFC, double dfree, int i0, double u0,
+                                              int n, int nS, int nFC, double dfree,
                                               int lane, int wv, int plcur, double far_thr, long long* fb) {
 #ifdef SP_PROFILE
     long long tl = clock64();
@@ -394,6 +432,7 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
     int nq = 0;
     if (nS > swv) { nq = (nS - swv + SP_NW - 1) / SP_NW; if (nq > SP_E) nq = SP_E; }
     int jj[SP_E], ii[SP_E], kk[SP_E]; bool root[SP_E], on[SP_E], use[SP_E];
+    unsigned claim[SP_E];
     double bs[SP_E], cd[SP_E], pj[SP_E], pk[SP_E], dc[SP_E];
     uint2 cl[SP_E];
     // stage 1: entries (uniform LDS reads)
@@ -406,17 +445,27 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
 #pragma unroll
     for (int q = 0; q < SP_E; ++q) {
         const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)ev[q]);
+        ev[q] = e;
         bs[q] = sp_rfl_d(bs[q]);
         root[q] = (e & SP_ROOT) != 0;
         jj[q] = root[q] ? -1 : (int)(e & SP_COLMASK);
         on[q] = (q < nq) && bs[q] < dfree;
     }
-    // stage 2: rows
-    unsigned ov[SP_E];
+    // stage 2: rows and trees (a root entry: its slot's row; a column entry: the owner and the slot of its label)
+    unsigned ov[SP_E], sv[SP_E];
 #pragma unroll
-    for (int q = 0; q < SP_E; ++q) { ov[q] = (unsigned)i0; if (on[q] && !root[q]) ov[q] = L.owner[jj[q]]; }
+    for (int q = 0; q < SP_E; ++q) {
+        ov[q] = 0u; sv[q] = ev[q] << 12;
+        if (on[q]) {
+            if (root[q]) ov[q] = L.rrow[ev[q] & 63u];
+            else { ov[q] = L.owner[jj[q]]; sv[q] = L.pred[jj[q]]; }
+        }
+    }
 #pragma unroll
-    for (int q = 0; q < SP_E; ++q) ii[q] = __builtin_amdgcn_readfirstlane((int)ov[q]);
+    for (int q = 0; q < SP_E; ++q) {
+        ii[q] = __builtin_amdgcn_readfirstlane((int)ov[q]);
+        claim[q] = (SP_SLOT((unsigned)__builtin_amdgcn_readfirstlane((int)sv[q])) << 12) | (unsigned)ii[q];
+    }
     // stage 3: candidate lists (one 8-byte load per lane and entry, all in flight together)
 #pragma unroll
     for (int q = 0; q < SP_E; ++q) {
@@ -424,7 +473,7 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
         if (on[q]) cl[q] = w.cl[(size_t)ii[q] * SP_K + lane];
     }
     FB_TICK(0);
-    // stage 4: prices / labels of the candidates, price of the matched column
+    // stage 4: prices / labels of the candidates; price of the matched column, or the root's u
 #pragma unroll
     for (int q = 0; q < SP_E; ++q) {
         pj[q] = 0.0; pk[q] = 0.0; dc[q] = 0.0; use[q] = false; kk[q] = 0;
@@ -434,7 +483,7 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
             kk[q] = use[q] ? (int)col : 0;
             pk[q] = L.p[kk[q]];
             dc[q] = L.dist[kk[q]];
-            if (!root[q]) pj[q] = L.p[jj[q]];
+            pj[q] = root[q] ? L.ru[claim[q] >> 12] : L.p[jj[q]];
         }
     }
     // stage 5: candidates
@@ -442,13 +491,13 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
     for (int q = 0; q < SP_E; ++q) {
         cd[q] = 0.0;
         if (on[q]) {
-            double rj = u0;
+            double rj = sp_rfl_d(pj[q]);
             if (!root[q]) {
                 const unsigned long long hit = __ballot((int)cl[q].x == jj[q]);
                 float cij;
                 if (hit) cij = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)cl[q].y, __ffsll((long long)hit) - 1));
                 else cij = M[(size_t)ii[q] * n + jj[q]];
-                rj = (double)cij + sp_rfl_d(pj[q]);            // = u_i: the matched edge is tight
+                rj = (double)cij + rj;                          // = u_i: the matched edge is tight
             }
             cd[q] = sp_cand(pk[q], __uint_as_float(cl[q].y), rj, bs[q]);
         }
@@ -469,11 +518,6 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
     FB_TICK(1);
     sp_sync();
     FB_TICK(2);
-    if (swv == SP_NW - 1) {
-        const double dnew = sp_dfree(L, nFC, lane);
-        if (lane == 0) L.rd[SP_RD_DFREE] = dnew;
-    }
-    FB_TICK(3);
     // phase W, staged the same way
     unsigned pc[SP_E], oldp[SP_E], ow[SP_E]; unsigned char il[SP_E]; bool won[SP_E];
 #pragma unroll
@@ -483,7 +527,7 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
         oldp[q] = 0u; won[q] = false;
         if (on[q]) {
             won[q] = use[q] && cd[q] == dc[q] && !(pc[q] & SP_STALE);
-            if (won[q]) oldp[q] = atomicMin(&L.pred[kk[q]], (unsigned)ii[q]);
+            if (won[q]) oldp[q] = atomicMin(&L.pred[kk[q]], claim[q]);
         }
     }
 #pragma unroll
@@ -497,8 +541,15 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
             if (won[q] && ow[q] != SP_NOCOL) sp_file(L, kk[q], cd[q], il[q], plcur, far_thr);
         }
     }
-    FB_TICK(4);
+    FB_TICK(3);
     sp_sync();
+    FB_TICK(4);
+    // the radius from the claimed state (every tree tag of this batch is in place), by the last wave, while the
+    // others start the bookkeeping: it is published for the NEXT batch (a stale, larger radius is always valid)
+    if (swv == SP_NW - 1) {
+        const double dnew = sp_radius(L, nFC, lane, dfree);
+        if (lane == 0) L.rd[SP_RD_DFREE] = dnew;
+    }
     FB_TICK(5);
 }
 
@@ -659,6 +710,15 @@ __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double
 #define SP_TICK(slot) do { } while (0)
 #endif
 
+// The searches, as MULTI-SOURCE phases (a shortest-path forest, one tree per free row, grown by the batches below;
+// a column belongs to the tree that gave it its label).  When the forest has converged below the radius every tree
+// that reached a free column accepts its nearest one (the trees are vertex disjoint, so all of these paths are
+// augmented), the duals move by D = the largest accepted label:
+//     p_k += D - d_k  for every column with d_k < D   (u follows through the tight matched edges)
+// which keeps them feasible and makes every accepted path tight.  One phase costs the depth of one search and
+// retires several rows: at n = 4096 the 25 - 30 rows left by the auction go in about five phases / 280 batches,
+// against 65 chip-wide relax rounds + 370 batches when the forest ran on the dense matrix and only the last six
+// rows came here one by one (tools/proto/proto18.py).
 __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, char* lds) {
 #ifdef SP_PROFILE
     long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -669,83 +729,92 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
 #else
     long long* fb = nullptr;
 #endif
-    const int n = st->n, nF = st->nF;
+    const int n = st->n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SpL L = sp_carve(lds, n);
-    int nFC = st->nFC;
+    int nFC = st->nFC, nFree = st->nF;
+    int err = (nFree > SP_ROOTS || nFC != nFree) ? 9 : 0;
     for (int k = tid; k < n; k += SP_T) {
         L.p[k] = w.p[k];
         const int o = w.owner[k]; L.owner[k] = (o < 0) ? (unsigned short)SP_NOCOL : (unsigned short)o;
         const int ak = w.a[k]; L.a[k] = (ak < 0) ? (unsigned short)SP_NOCOL : (unsigned short)ak;
     }
-    for (int t = tid; t < nFC; t += SP_T) L.fcol[t] = (unsigned short)w.listFC[t];
-    if (tid == 0) { L.ri[126] = 0; L.ri[125] = 0; }
+    if (!err) {
+        for (int t = tid; t < nFC; t += SP_T) L.fcol[t] = (unsigned short)w.listFC[t];
+        for (int t = tid; t < nFree; t += SP_T) L.rrow[t] = (unsigned short)w.listF[t];
+    }
+    if (tid == 0) { L.ri[126] = 0; L.ri[125] = 0; L.ri[SP_RI_FLAG] = 0; }
     sp_sync();
 
-    int batches = 0, scans = 0, dense_scans = 0, err = 0;
-    for (int f = 0; f < nF && !err; ++f) {
-        const int i0 = w.listF[f];
+    int batches = 0, scans = 0, dense_scans = 0, phases = 0;
+    while (nFree > 0 && !err) {
+        const int nR = nFree;                 // every free row is a root of this phase (slot s <-> rrow[s])
+        ++phases;
         for (int k = tid; k < n; k += SP_T) {
             L.dist[k] = INFINITY; L.pred[k] = SP_STALE | SP_MARK; L.ddone[k] = 0; L.inl[k] = 0;
         }
-        // root: u0 = min_k (c_i0k + p_k).  The candidate minimum is the row minimum iff it does
-        // not exceed the bound T_i0 of the dropped columns; otherwise take it over the full row
-        // and start with a dense root entry.
-        double u0;
-        {
+        // roots: u_r = min_k (c_rk + p_k), one wave per root.  The candidate minimum is the row minimum iff it does
+        // not exceed the bound T_r of the dropped columns; otherwise take it over the full row and start the root
+        // with a dense entry.
+        if (tid == 0) L.ri[SP_RI_ANYD] = 0;
+        sp_sync();
+        for (int s0 = wv; s0 < nR; s0 += SP_NW) {
+            const int i0 = L.rrow[s0];
             const uint2 cl = w.cl[(size_t)i0 * SP_K + lane];
             const double val = (cl.x != SP_NOCOL) ? (double)__uint_as_float(cl.y) + L.p[cl.x] : INFINITY;
-            u0 = sp_wave_min(val);                // every wave computes the same value
+            double u0 = sp_wave_min(val);
+            const bool rdense = !(u0 <= w.cT[i0]);
+            if (rdense) {
+                double mm = INFINITY;
+                for (int k = lane; k < n; k += 64) mm = fmin(mm, (double)M[(size_t)i0 * n + k] + L.p[k]);
+                u0 = sp_wave_min(mm);
+            }
+            if (lane == 0) {
+                L.ru[s0] = u0; L.rdn[s0] = rdense ? 1 : 0;
+                L.lcol[s0] = (unsigned short)(SP_ROOT | (rdense ? SP_DENSE : 0u) | (unsigned)s0); L.lbase[s0] = 0.0;
+                if (rdense) L.ri[SP_RI_ANYD] = 1;
+            }
         }
-        bool root_dense = false;
-        if (!(u0 <= w.cT[i0])) {
-            double mm = INFINITY;
-            for (int k = tid; k < n; k += SP_T) mm = fmin(mm, (double)M[(size_t)i0 * n + k] + L.p[k]);
-            u0 = sp_block_min(mm, L);
-            root_dense = true;
-        }
-        const double bound0 = w.cT[i0] - u0;
-        if (tid == 0) {
-            L.lcol[0] = (unsigned short)(root_dense ? (SP_ROOT | SP_DENSE) : SP_ROOT); L.lbase[0] = 0.0;
-            L.ri[SP_RI_NPL] = 0; L.rd[SP_RD_DFREE] = INFINITY; L.rd[SP_RD_FAR] = INFINITY;
-        }
-        int nS = 1, plcur = 0;
-        bool any_dense = root_dense;
-        double dfree = INFINITY;
+        if (tid == 0) { L.ri[SP_RI_NPL] = 0; L.rd[SP_RD_DFREE] = INFINITY; L.rd[SP_RD_FAR] = INFINITY; }
+        sp_sync();
+        int nS = nR, plcur = 0;
+        bool any_dense = L.ri[SP_RI_ANYD] != 0;
+        double dfree = INFINITY;      // radius of the phase
         double delta = INFINITY;      // label window of a batch above the smallest pending label
         double far_thr = INFINITY;    // near / far split of the pending columns
-        sp_sync();
         SP_TICK(0);
 
         for (int guard = 0;; ++guard) {
             if (guard > 8 * n + 64) { err = 6; break; }
             if (nS > 0) {
                 if (!any_dense) {
-                    sp_fast_batch(M, w, L, n, nS, nFC, dfree, i0, u0, lane, wv, plcur, far_thr, fb);
+                    sp_fast_batch(M, w, L, n, nS, nFC, dfree, lane, wv, plcur, far_thr, fb);
                 } else {
                     for (int t = wv; t < nS; t += SP_NW) {
                         const double b = L.lbase[t];
-                        if (b < dfree) sp_entry<false>(M, w, L, n, L.lcol[t], b, i0, u0, lane, plcur, dfree, far_thr);
+                        if (b < dfree) sp_entry<false>(M, w, L, n, L.lcol[t], b, lane, plcur, dfree, far_thr);
+                    }
+                    sp_sync();
+                    for (int t = wv; t < nS; t += SP_NW) {
+                        const double b = L.lbase[t];
+                        if (b < dfree) sp_entry<true>(M, w, L, n, L.lcol[t], b, lane, plcur, dfree, far_thr);
                     }
                     sp_sync();
                     if (wv == SP_NW - 1) {
-                        const double dnew = sp_dfree(L, nFC, lane);
+                        const double dnew = sp_radius(L, nFC, lane, dfree);
                         if (lane == 0) L.rd[SP_RD_DFREE] = dnew;
                     }
-                    for (int t = wv; t < nS; t += SP_NW) {
-                        const double b = L.lbase[t];
-                        if (b < dfree) sp_entry<true>(M, w, L, n, L.lcol[t], b, i0, u0, lane, plcur, dfree, far_thr);
-                    }
-                    sp_sync();
                 }
                 ++batches; scans += nS;
 #ifdef SP_PROFILE
                 if (!any_dense) { SP_TICK(1); ++nfast; } else { SP_TICK(5); }
 #endif
             }
-            dfree = L.rd[SP_RD_DFREE];
+            // (the batch's radius is published by the last wave after the batch's final barrier: it is read below,
+            //  behind the barriers of the bookkeeping, which itself still works with the previous, larger one)
             delta = sp_collect_all(L, plcur, dfree, delta, far_thr);
             sp_sync();
+            dfree = L.rd[SP_RD_DFREE];
             nS = L.ri[SP_RI_NS]; far_thr = L.rd[SP_RD_FAR]; plcur ^= 1; any_dense = false;
             SP_TICK(2);
             if (nS > 0) continue;
@@ -794,7 +863,13 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 }
             }
 
-            // ---- converged on the lists: a-posteriori pruning test for every tree row
+            // ---- converged on the lists: a-posteriori pruning test for every root and every tree row
+            if (wv == 0) {
+                bool c = false;
+                if (lane < nR && !L.rdn[lane]) c = !(w.cT[L.rrow[lane]] - L.ru[lane] >= dfree);
+                const unsigned long long m = __ballot(c);
+                if (lane == 0) { L.ri[SP_RI_RBAD] = (int)(unsigned)m; L.ri[SP_RI_RBAD + 1] = (int)(unsigned)(m >> 32); }
+            }
             int cnt = 0; bool sel[SP_IPT]; double dk[SP_IPT];
 #pragma unroll
             for (int e = 0; e < SP_IPT; ++e) {
@@ -820,22 +895,26 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 nsel = __builtin_amdgcn_readlane(wscan, 63);
                 off = __shfl(wscan - wsum, wv, 64) + (winc - cnt);
             }
+            const unsigned long long rbad = (unsigned long long)(unsigned)L.ri[SP_RI_RBAD] |
+                                            ((unsigned long long)(unsigned)L.ri[SP_RI_RBAD + 1] << 32);
+            const int nrb = __popcll(rbad);
+            const int ccap = SP_CAP - nrb;               // list slots left for tree rows (the rest wait for the next test)
 #pragma unroll
             for (int e = 0; e < SP_IPT; ++e) {
                 const int k = e * SP_T + tid;
                 if (sel[e]) {
-                    if (off < SP_CAP - 1) {
+                    if (off < ccap) {
                         L.lcol[off] = (unsigned short)(k | SP_DENSE); L.lbase[off] = dk[e]; L.ddone[k] = 1;
                     }
                     ++off;
                 }
             }
-            nS = nsel < SP_CAP - 1 ? nsel : SP_CAP - 1;
-            if (!root_dense && !(bound0 >= dfree)) {
-                root_dense = true;
-                if (tid == 0) { L.lcol[nS] = (unsigned short)(SP_ROOT | SP_DENSE); L.lbase[nS] = 0.0; }
-                ++nS;
+            nS = nsel < ccap ? nsel : ccap;
+            if (tid < SP_ROOTS && ((rbad >> tid) & 1ull)) {
+                const int pos = nS + __popcll(rbad & ((1ull << tid) - 1ull));
+                L.lcol[pos] = (unsigned short)(SP_ROOT | SP_DENSE | (unsigned)tid); L.lbase[pos] = 0.0; L.rdn[tid] = 1;
             }
+            nS += nrb;
             any_dense = nS > 0;
             dense_scans += nS;
             sp_sync();
@@ -844,55 +923,81 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
         }
         if (err) break;
 
-        // ---- search done: argmin free column, dual update, augmentation
-        double lm = INFINITY; int li = 0x7fffffff;
-        for (int t = tid; t < nFC; t += SP_T) {
-            const int k = L.fcol[t]; const double dk = L.dist[k];
-            if (dk < lm || (dk == lm && k < li)) { lm = dk; li = k; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double v2 = __shfl_xor(lm, o, 64); const int i2 = __shfl_xor(li, o, 64);
-            if (v2 < lm || (v2 == lm && i2 < li)) { lm = v2; li = i2; }
-        }
-        if (lane == 0) { L.rd[wv] = lm; L.ri[wv] = li; }
+        // ---- phase done: every tree accepts its nearest free column at or below the radius
+        if (tid < SP_ROOTS) { L.tmin[tid] = ~0ull; L.tcol[tid] = SP_TNONE; }
         sp_sync();
+        int myslot = -1, myk = 0; unsigned long long myd = ~0ull; int bad = 0;
+        if (wv == 0 && lane < nFC) {
+            const int k = L.fcol[lane]; const double d = L.dist[k];
+            if (d < INFINITY && d <= dfree) {                 // labels above the radius are not final
+                int j = k, g2 = 0;
+                for (;;) {
+                    const unsigned pr = L.pred[j] & 0x7fffffffu;
+                    if (pr == SP_MARK || ++g2 > n + 1) { bad = 1; break; }
+                    const int i = (int)(pr & SP_ROWMASK);
+                    const int aj = L.a[i];
+                    if (aj == (int)SP_NOCOL) {                // a free row: the root of the tree
+                        myslot = (int)SP_SLOT(pr);
+                        if (myslot >= nR || (int)L.rrow[myslot] != i) { bad = 1; myslot = -1; }
+                        break;
+                    }
+                    j = aj;
+                }
+                if (myslot >= 0) { myk = k; myd = (unsigned long long)__double_as_longlong(d); atomicMin(&L.tmin[myslot], myd); }
+            }
+        }
+        sp_sync();
+        if (myslot >= 0 && L.tmin[myslot] == myd) atomicMin(&L.tcol[myslot], myk);       // ties: the lowest column
+        if (bad) L.ri[SP_RI_FLAG] = 3;
+        sp_sync();
+        if (L.ri[SP_RI_FLAG] == 3) { err = 3; break; }
+        double D; int nacc;
         {
-            double bv = L.rd[0]; int bi = L.ri[0];
-            for (int q = 1; q < SP_T / 64; ++q) {
-                const double v2 = L.rd[q]; const int i2 = L.ri[q];
-                if (v2 < bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
-            }
-            lm = bv; li = bi;
+            const bool acc = lane < nR && L.tcol[lane] != SP_TNONE;
+            const unsigned long long tm = acc ? L.tmin[lane] : 0ull;
+            D = sp_wave_max(acc ? __longlong_as_double((long long)tm) : -INFINITY);
+            nacc = __popcll(__ballot(acc));
         }
-        sp_sync();
-        dfree = lm;
-        const int jfree = li;
-        if (!(dfree < INFINITY)) { err = 5; break; }
+        if (nacc == 0 || !(D < INFINITY)) { err = 5; break; }
         for (int k = tid; k < n; k += SP_T) {
-            if (L.owner[k] != SP_NOCOL) {
-                const double dk = L.dist[k];
-                if (dk < dfree) L.p[k] += dfree - dk;        // v_k -= (dfree - d_k)
-            }
+            const double dk = L.dist[k];
+            if (dk < D) L.p[k] += D - dk;                     // v_k -= (D - d_k)
         }
-        for (int t = tid; t < nFC; t += SP_T)
-            if (L.fcol[t] == jfree) L.fcol[t] = L.fcol[nFC - 1];   // single match
-        --nFC;
-        sp_sync();
-        if (tid == 0) {
-            int j = jfree, g2 = 0; bool closed = false;
+        // augment: one lane per accepted tree (vertex-disjoint paths)
+        if (wv == 0 && lane < nR && L.tcol[lane] != SP_TNONE) {
+            int j = L.tcol[lane], g2 = 0; const int r = L.rrow[lane]; bool closed = false;
             while (g2++ <= n) {
-                const int i = (int)(L.pred[j] & 0x7fffffffu);
+                const int i = (int)(L.pred[j] & SP_ROWMASK);
                 const int jprev = L.a[i];
                 L.owner[j] = (unsigned short)i; L.a[i] = (unsigned short)j;
-                if (i == i0) { closed = true; break; }
+                if (i == r) { closed = true; break; }
                 j = jprev;
                 if (j == (int)SP_NOCOL) break;
             }
-            if (!closed) L.ri[32] = 1; else L.ri[32] = 0;
+            if (!closed) L.ri[SP_RI_FLAG] = 3;
         }
         sp_sync();
-        if (L.ri[32]) { err = 3; }
+        // drop the matched rows / columns from the free lists (order preserving; both have <= 64 entries)
+        if (wv == 0) {
+            const int k = (lane < nFC) ? (int)L.fcol[lane] : 0;
+            const bool keepc = lane < nFC && L.owner[k] == SP_NOCOL;
+            const unsigned long long mc = __ballot(keepc);
+            const int r = (lane < nFree) ? (int)L.rrow[lane] : 0;
+            const bool keepr = lane < nFree && L.a[r] == SP_NOCOL;
+            const unsigned long long mr = __ballot(keepr);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (keepc) L.fcol[__popcll(mc & below)] = (unsigned short)k;
+            if (keepr) L.rrow[__popcll(mr & below)] = (unsigned short)r;
+            if (lane == 0) { L.ri[SP_RI_NFC] = __popcll(mc); L.ri[SP_RI_NFR] = __popcll(mr); }
+        }
+        sp_sync();
+        if (L.ri[SP_RI_FLAG] == 3) { err = 3; break; }
+        {
+            const int nfc2 = L.ri[SP_RI_NFC], nfr2 = L.ri[SP_RI_NFR];
+            if (nfc2 != nfr2 || nfr2 != nFree - nacc) { err = 4; break; }
+            nFC = nfc2; nFree = nfr2;
+        }
         sp_sync();
         SP_TICK(4);
     }
@@ -906,15 +1011,16 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
     if (tid == 0) {
         long long* out = reinterpret_cast<long long*>(w.part_d);     // (scratch of the former split relax rounds)
         for (int q = 0; q < 5; ++q) out[q] = dbg[q];
-        out[5] = dbg[5]; out[6] = nfast; out[7] = batches; out[8] = L.ri[126]; for (int q = 0; q < 6; ++q) out[9 + q] = fbv[q]; out[15] = L.ri[125];
+        out[5] = dbg[5]; out[6] = nfast; out[7] = batches; out[8] = phases; for (int q = 0; q < 6; ++q) out[9 + q] = fbv[q]; out[15] = L.ri[125];
     }
 #endif
     if (tid == 0) {
-        st->nFC = nFC;
+        st->nFC = nFC; st->nF = nFree;
         st->st_sap_batches += batches;
         st->st_sap_row_scans += scans;
         st->st_total_row_scans += scans;
         st->st_dense_fallbacks += dense_scans;
+        st->st_ms_phases += phases;
         if (err) st->error = err;
         asg_book(st, MODE_SOLVER);
         asg_enter_cert(st);

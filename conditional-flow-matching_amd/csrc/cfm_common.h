@@ -15,6 +15,14 @@ static inline int cfm_hip(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
 static inline size_t cfm_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// hipFuncSetAttribute and occupancy answers are PER DEVICE: every once-only setup is keyed by the current device
+#define CFM_MAX_DEVICES 16
+static inline int cfm_device_index() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CFM_MAX_DEVICES) dev = 0;
+    return dev;
+}
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; give each
 // XCD a contiguous range of logical ids so neighbouring tiles share its L2.
 // Bijective for any grid size (speed only, never correctness).

@@ -708,9 +708,11 @@ static int ode_dopri5_small(const float* const* W, const float* const* b, const 
     for (int l = 0; l < 4; ++l) { A.W[l] = W[l]; A.b[l] = b[l]; }
     for (int l = 0; l < 5; ++l) A.dims[l] = dims[l];
     const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_ROWS * SM_LD);
-    static int raised = 0, resident = 0;
-    static std::once_flag once;
-    std::call_once(once, [lds] {
+    static int raised_d[CFM_MAX_DEVICES], resident_d[CFM_MAX_DEVICES];
+    static std::once_flag once_d[CFM_MAX_DEVICES];
+    const int dvi = cfm_device_index();
+    int& raised = raised_d[dvi]; int& resident = resident_d[dvi];
+    std::call_once(once_d[dvi], [lds, &raised, &resident] {
         hipError_t e = hipFuncSetAttribute((const void*)ode_small_dopri<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipError_t e2 = hipFuncSetAttribute((const void*)ode_small_dopri<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         int ok = (e == hipSuccess && e2 == hipSuccess) ? 1 : -1;
@@ -808,9 +810,11 @@ static int ode_euler_small(const float* const* W, const float* const* b, const i
     for (int l = 0; l < 4; ++l) { A.W[l] = W[l]; A.b[l] = b[l]; }
     for (int l = 0; l < 5; ++l) A.dims[l] = dims[l];
     const size_t lds = sizeof(float) * (4 * SM_W * SM_LD + 4 * SM_W + SM_W + 2 * SM_ROWS * SM_LD);
-    static int raised = 0;
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static int raised_d[CFM_MAX_DEVICES];
+    static std::once_flag once_d[CFM_MAX_DEVICES];
+    const int dvi = cfm_device_index();
+    int& raised = raised_d[dvi];
+    std::call_once(once_d[dvi], [&raised] {
         hipError_t e = hipFuncSetAttribute((const void*)ode_small_euler, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipGetLastError();
         raised = (e == hipSuccess) ? 1 : -1;

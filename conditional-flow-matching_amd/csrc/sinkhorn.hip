@@ -657,9 +657,10 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, 
     const int row_wgs = (B0 + rows_per_wg - 1) / rows_per_wg;
     int v_in_lds = ((size_t)B1 * 8 <= 128 * 1024) ? 1 : 0;
     if (v_in_lds && (size_t)B1 * 8 > 48 * 1024) {
-        static int raised = 0;   // dynamic LDS above the 64 KiB default needs the attribute
-        static std::once_flag once;
-        std::call_once(once, [] {
+        static int raised_d[CFM_MAX_DEVICES];   // dynamic LDS above the 64 KiB default needs the attribute (per device)
+        static std::once_flag once_d[CFM_MAX_DEVICES];
+        int& raised = raised_d[cfm_device_index()];
+        std::call_once(once_d[cfm_device_index()], [&raised] {
             hipError_t e = hipFuncSetAttribute((const void*)sk_row_pass<true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             hipError_t e2 = hipFuncSetAttribute((const void*)sk_row_pass<false>,
@@ -673,9 +674,11 @@ extern "C" int cfm_sinkhorn_log_f32(const float* M, int B0, int B1, double reg, 
     // streaming row pass: a persistent grid of SK_STREAM_WAVES-wave workgroups
     int stream_grid = 0, stream_nf4 = 0;
     if (row_fast && v_in_lds) {
-        static int per_cu = -1, cus = 0;
-        static std::once_flag once_stream;
-        std::call_once(once_stream, [] {
+        static int per_cu_d[CFM_MAX_DEVICES], cus_d[CFM_MAX_DEVICES];
+        static std::once_flag once_stream_d[CFM_MAX_DEVICES];
+        const int dvi = cfm_device_index();
+        int& per_cu = per_cu_d[dvi]; int& cus = cus_d[dvi];
+        std::call_once(once_stream_d[dvi], [&per_cu, &cus] {
             const char* e = getenv("CFM_SK_STREAM");       // workgroups per CU; 0 = one-shot row pass
             int pc = e ? atoi(e) : 1;
             int dev = 0, c = 0;

@@ -294,8 +294,8 @@ extern "C" int cfm_sinkhorn_log_points_f32(const float* x0, const float* x1, int
     if (stage_cap > n_max) stage_cap = (n_max + PTS_STRIDE * PTS_U - 1) / (PTS_STRIDE * PTS_U) * (PTS_STRIDE * PTS_U);
     const size_t lds = (size_t)stage_cap * (8 + 4 * d);
     {
-        static std::once_flag once;
-        std::call_once(once, [] {
+        static std::once_flag once_d[CFM_MAX_DEVICES];          // the attribute is per device
+        std::call_once(once_d[cfm_device_index()], [] {
             const void* fns[8] = {(const void*)sk_pts_pass<1>, (const void*)sk_pts_pass<2>, (const void*)sk_pts_pass<3>,
                                   (const void*)sk_pts_pass<4>, (const void*)sk_pts_pass<5>, (const void*)sk_pts_pass<6>,
                                   (const void*)sk_pts_pass<7>, (const void*)sk_pts_pass<8>};

@@ -39,19 +39,43 @@ class _MLPTrainFunction(torch.autograd.Function):
         cd = (ctypes.c_int * (n + 1))(*dims)
         check(lib.cfm_mlp_forward_train_f32(ptr(xd), Wp, bp, cd, n, B, hp, zp, ptr(out), stream_ptr()),
               "cfm_mlp_forward_train_f32")
-        ctx.save_for_backward(xd, *hidden, *preact, *Ws)
+        # x and the parameters are saved as the INPUTS they are (graph attached): a double backward
+        # (autograd.grad(..., create_graph=True): GradModel, divergences, Jacobians) re-derives the gradient
+        # from them with differentiable torch ops; the HIP backward reads the detached views
+        ctx.save_for_backward(x, *params, *hidden, *preact)
         ctx.dims, ctx.n = dims, n
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
-        lib = _lib.load()
         n, dims = ctx.n, ctx.dims
         saved = ctx.saved_tensors
-        acts, preact, Ws = saved[:n], saved[n:2 * n - 1], saved[2 * n - 1:]
+        x, params = saved[0], saved[1:1 + 2 * n]
+        if torch.is_grad_enabled():
+            # create_graph=True: the gradient itself must be differentiable (w.r.t. dout, x and the weights),
+            # which the fused kernels are not — recompute the layer chain with torch ops and let autograd build
+            # the second-order graph (exactly what the plain nn.Sequential of the reference would do)
+            with torch.enable_grad():
+                h = x
+                for l in range(n):
+                    h = torch.nn.functional.linear(h, params[2 * l], params[2 * l + 1])
+                    if l < n - 1:
+                        h = torch.nn.functional.selu(h)
+                wanted = [k for k in range(1 + 2 * n) if ctx.needs_input_grad[k]]
+                srcs = [x if k == 0 else params[k - 1] for k in wanted]
+                got = torch.autograd.grad(h, srcs, dout, create_graph=True, allow_unused=True) if srcs else ()
+            grads = [None] * (1 + 2 * n)
+            for k, g in zip(wanted, got):
+                grads[k] = g
+            return tuple(grads)
+        lib = _lib.load()
+        hidden, preact = saved[1 + 2 * n:2 * n + n], saved[2 * n + n:]
+        acts = (x.detach().contiguous(),) + tuple(hidden)
+        Ws = [params[2 * l].detach().contiguous() for l in range(n)]
         dev = dout.device
         B = dout.shape[0]
+        if tuple(dout.shape) != (acts[0].shape[0], dims[n]):
+            raise RuntimeError(f"MLP backward: upstream gradient has shape {tuple(dout.shape)}, expected {(acts[0].shape[0], dims[n])}")
         dout = dout.contiguous().float()
         dW = [torch.empty_like(w) for w in Ws]
         db = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) for w in Ws]
@@ -152,10 +176,16 @@ class MLP(torch.nn.Module):
             lins = self._linears()
             if (self.hip_training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
                     and all(l.weight.is_cuda and l.weight.dtype == torch.float32 and l.bias is not None for l in lins)):
-                params = []
-                for l in lins:
-                    params += [l.weight, l.bias]
-                return _MLPTrainFunction.apply(x, *params)
+                if x.shape[1] != lins[0].in_features:        # what nn.Linear would say (the kernel reads lda = in_features)
+                    raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({x.shape[0]}x{x.shape[1]} and "
+                                       f"{lins[0].in_features}x{lins[0].out_features})")
+                same_dev = all(l.weight.device == x.device and l.bias.device == x.device for l in lins)
+                chained = all(a.out_features == b.in_features for a, b in zip(lins[:-1], lins[1:]))
+                if same_dev and chained:
+                    params = []
+                    for l in lins:
+                        params += [l.weight, l.bias]
+                    return _MLPTrainFunction.apply(x, *params)
             return self.net(x)
         # no-grad inference: any leading shape (the reference's nn.Sequential accepts [..., dim]) and the
         # caller's dtype back

@@ -101,6 +101,7 @@ def assign_exact(M, return_info=False):
 # column L/B1 times: it is massively tied, which is the slow regime of every assignment solver (127 x 128 -> L = 16256
 # was measured at ~200 s on MI355X), so the bound is a usability bound, not a memory bound.
 _RECT_EXACT_MAX = 8192
+_RECT_SCIPY_MAX = 1024      # padded LSAP between batches of very different sizes (sample_plan_with_scipy)
 
 
 def exact_plan_rect(M):
@@ -469,6 +470,12 @@ class OTPlanSampler:
             # minimum total cost and returns the column indices in row order (ref:179: `_, j = ...`).  Zero-cost
             # dummy rows / columns make it a square problem with the same optimum on the real entries.
             n = max(B0, B1)
+            if n > _RECT_SCIPY_MAX and n > 4 * min(B0, B1):
+                # |B0 - B1| identical all-zero dummy lines are the massively tied regime of the assignment solver
+                # (every dummy bids for the same cheapest column: one award per auction round)
+                raise NotImplementedError(
+                    f"sample_plan_with_scipy between {B0} and {B1} samples pads to a {n} x {n} problem with "
+                    f"{abs(B0 - B1)} tied dummy lines; supported up to n = {_RECT_SCIPY_MAX} or a 4 : 1 size ratio")
             Mx = torch.zeros((n, n), dtype=torch.float32, device=dev)
             Mx[:B0, :B1] = M
             full = assign_exact(Mx).long()[:B0]

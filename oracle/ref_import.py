@@ -61,3 +61,17 @@ def import_runner_metrics():
         spec.loader.exec_module(m)
         out[name] = m
     return out["distribution_distances"], out["mmd"]
+
+
+def import_runner_sinkhorn():
+    """The reference's own pure-NumPy statement of POT's unbalanced Sinkhorn-Knopp loop
+    (runner/src/models/components/sinkhorn_knopp_unbalanced.py), unmodified.  With reg_m_1 = reg_m_2 -> infinity
+    its fixed point is the balanced entropic plan, which pins the log-domain solvers at convergence."""
+    path = os.path.join(REFERENCE_ROOT, "runner", "src", "models", "components", "sinkhorn_knopp_unbalanced.py")
+    if not os.path.isfile(path):
+        raise ImportError("reference runner tree not present")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("runner_ref_sinkhorn_knopp_unbalanced", path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m

@@ -20,6 +20,10 @@ Fixture provenance
                       with the accept / reject logs of two independent restatements.
   ub_cases.npz        reference OTPlanSampler("unbalanced" / "partial") wrapper over the restated
                       POT loops (in-repo unbalanced statement; recalled partial Dykstra loop).
+  refsk_cases.npz     (round 3) plans computed by the REFERENCE-HELD Sinkhorn code itself —
+                      runner/src/models/components/sinkhorn_knopp_unbalanced.py imported unmodified
+                      (pure NumPy) and run to its fixed point: unbalanced plans for three (reg, reg_m),
+                      and balanced entropic plans through reg_m_1 = reg_m_2 = 1e12.
 """
 import os
 import sys
@@ -264,7 +268,45 @@ def ub_cases(ot):
     return out
 
 
+REFSK_UNBALANCED = ((0.5, 1.0), (1.0, 0.2), (0.3, 5.0))
+REFSK_BALANCED = (1.0, 2.0, 5.0)
+REFSK_BALANCED_8G = (2.0, 5.0)
+REFSK_REG_M_INF = 1e12
+
+
+def refsk_inputs():
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(96, 3, generator=g)
+    x1 = torch.randn(96, 3, generator=g) * 0.8 + 0.7
+    y0, y1 = oracle.config_inputs("C1", B=96)          # 8 gaussians -> moons (d = 2), the tutorial clouds
+    return x0, x1, y0, y1
+
+
+def refsk_cases():
+    """Fixed points of the reference-held loop (stopThr far below the comparison tolerance, so the loop's own
+    stopping rule — relative change of u / v, not POT's marginal error — plays no role)."""
+    sk = ref_import.import_runner_sinkhorn()
+    x0, x1, y0, y1 = refsk_inputs()
+    out = {"x0": x0.numpy(), "x1": x1.numpy(), "y0": y0.numpy(), "y1": y1.numpy()}
+    M = oracle.ref_cost_f32(x0, x1); M8 = oracle.ref_cost_f32(y0, y1)
+    out["M"], out["M8"] = M, M8
+    kw = dict(numItermax=200000, stopThr=1e-15)
+    for reg, reg_m in REFSK_UNBALANCED:
+        out[f"ub_{reg}_{reg_m}"] = sk.sinkhorn_knopp_unbalanced([], [], M, reg, reg_m, reg_m, **kw)
+    for reg in REFSK_BALANCED:
+        out[f"bal_{reg}"] = sk.sinkhorn_knopp_unbalanced([], [], M, reg, REFSK_REG_M_INF, REFSK_REG_M_INF, **kw)
+    for reg in REFSK_BALANCED_8G:
+        out[f"bal8g_{reg}"] = sk.sinkhorn_knopp_unbalanced([], [], M8, reg, REFSK_REG_M_INF, REFSK_REG_M_INF, **kw)
+    # the docstring KAT through the real function
+    out["kat"] = sk.sinkhorn_knopp_unbalanced([0.5, 0.5], [0.5, 0.5], [[0.0, 1.0], [1.0, 0.0]], 1.0, 1.0, 1.0)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "refsk":      # reference-held NumPy Sinkhorn, imported unmodified
+        np.savez_compressed(os.path.join(HERE, "refsk_cases.npz"), **refsk_cases())
+        print("refsk_cases.npz", os.path.getsize(os.path.join(HERE, "refsk_cases.npz")))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":    # the reference's runner metrics, imported unmodified
         np.savez_compressed(os.path.join(HERE, "metrics_cases.npz"), **metrics_cases())
         print("metrics_cases.npz", os.path.getsize(os.path.join(HERE, "metrics_cases.npz")))
@@ -275,6 +317,7 @@ def main():
         return
     cfm, ot = ref_import.import_reference()
     np.savez_compressed(os.path.join(HERE, "ub_cases.npz"), **ub_cases(ot))
+    np.savez_compressed(os.path.join(HERE, "refsk_cases.npz"), **refsk_cases())
     np.savez_compressed(os.path.join(HERE, "fm_cases.npz"), **fm_cases(cfm))
     np.savez_compressed(os.path.join(HERE, "ot_cases.npz"), **ot_cases(ot))
     np.savez_compressed(os.path.join(HERE, "sinkhorn_cases.npz"), **sinkhorn_cases())

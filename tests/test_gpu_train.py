@@ -164,3 +164,46 @@ def test_training_loop_matches_pytorch_loop(dev):
             loss = torch.mean((m(torch.cat([xt, t[:, None]], dim=-1)) - ut) ** 2)
             loss.backward(); o.step(); log.append(float(loss))
     np.testing.assert_allclose(la, lb, rtol=2e-4)
+
+
+def test_gradmodel_double_backward_through_the_hip_mlp():
+    """GradModel(MLP) differentiates the MLP's input gradient again (create_graph=True,
+    torchcfm/models/models.py:24-32).  The HIP autograd.Function answers a grad-mode backward with differentiable
+    torch ops on its saved inputs, so the second-order graph reaches the weights: one training step gives the same
+    parameter gradients as the plain nn.Sequential graph."""
+    import cfm_amd
+    from cfm_amd.models import GradModel
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    torch.manual_seed(0)
+    act = cfm_amd.MLP(dim=2, out_dim=1, w=64, time_varying=True).to(dev)
+    x = torch.randn(128, 3, device=dev)
+    out = GradModel(act)(x.clone())
+    assert out.shape == (128, 2) and out.requires_grad
+    (out ** 2).mean().backward()
+    # (the last bias does not enter d potential / dx: its gradient is None on both graphs)
+    g_hip = [None if p.grad is None else p.grad.clone() for p in act.parameters()]
+    assert all(torch.isfinite(g).all() for g in g_hip if g is not None)
+    assert sum(g is not None and float(g.abs().max()) > 0 for g in g_hip) >= 6
+    act.zero_grad()
+    inp = x.clone().requires_grad_(True)
+    (d,) = torch.autograd.grad(act.net(inp).sum(), inp, create_graph=True)
+    (d[:, :-1] ** 2).mean().backward()
+    for g, p in zip(g_hip, act.parameters()):
+        assert (g is None) == (p.grad is None)
+        if g is not None:
+            assert (g - p.grad).abs().max() <= 1e-5 * max(1e-6, float(p.grad.abs().max()))
+    # first-order use is still the fused path and still correct after a double-backward use
+    act.zero_grad()
+    y = act(x); y.sum().backward()
+    assert all(p.grad is not None for p in act.parameters())
+
+
+def test_mlp_training_path_validates_the_feature_count():
+    """a forgotten time column must raise like nn.Linear, not misread memory."""
+    import cfm_amd
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    net = cfm_amd.MLP(dim=2, w=64, time_varying=True).to(dev)
+    with pytest.raises(RuntimeError, match="cannot be multiplied"):
+        net(torch.randn(16, 2, device=dev))

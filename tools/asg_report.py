@@ -115,15 +115,15 @@ def main():
     with torch.cuda.stream(torch.cuda.Stream()):
         timing(dev, a.seeds, label="default")
         if a.sweep:
-            for b in (128, 192, 0):
+            for b in (80, 112, 128, 0):
                 lib.cfm_assign_set_bulk(b, 0); timing(dev, 1, label=f"bulk {b}")
-            lib.cfm_assign_set_bulk(160, 0)
+            lib.cfm_assign_set_bulk(96, 0)
             for c in (6, 16):
                 lib.cfm_assign_set_params(0, 0, 0, -1, 0, -1, c); timing(dev, 1, label=f"chunk {c}")
             lib.cfm_assign_set_params(0, 0, 0, -1, 0, -1, 10)
-            for h in (2, 4, 10):
+            for h in (6, 16, 32):
                 lib.cfm_assign_set_handoff(h); timing(dev, 1, label=f"handoff {h}")
-            lib.cfm_assign_set_handoff(6)
+            lib.cfm_assign_set_handoff(64)
             for th in (4.0, 7.0):
                 lib.cfm_assign_set_params(th, 0, 0, -1, 0, -1, 0); timing(dev, 1, label=f"theta {th}")
             lib.cfm_assign_set_params(5.0, 0, 0, -1, 0, -1, 0)
