@@ -187,6 +187,47 @@ def c1_latency(dev, reps=20):
     return {"sample_plan_ms": float(np.median(ts) * 1e3), "solve_ms": float(np.median(tsolve) * 1e3)}
 
 
+def aux_legs(dev):
+    """Timings of the path's other solvers (VERDICT r2 Weak #9: they were parity-only): the SF2M Euler-Maruyama
+    sampler (two 3-64-64-64-2 fields, B = 2048, 100 steps: SF2M_tutorial.ipynb cell 5 shape) and one iteration of the
+    kernel-space unbalanced / partial entropic solvers on the C2 clouds (B = 4096; reg = 5: the float64 Gibbs kernel
+    is alive there; 2 x 8 x B^2 bytes of fp64 kernel per iteration)."""
+    import cfm_amd
+    import cfm_amd.optimal_transport as ot
+    import cfm_oracle as oracle
+    from cfm_amd.sde import FlowScoreSDE, sdeint
+    out = {}
+    torch.manual_seed(0)
+    f = cfm_amd.MLP(dim=2, time_varying=True, w=64).to(dev); sc = cfm_amd.MLP(dim=2, time_varying=True, w=64).to(dev)
+    x0, _ = oracle.config_inputs("C1", B=2048)
+    y0 = x0.to(dev); ts = torch.linspace(0, 1, 2)
+    sde = FlowScoreSDE(f, sc, sigma=0.1)
+    sdeint(sde, y0, ts, dt=0.01); torch.cuda.synchronize()
+    t0 = time.perf_counter(); sdeint(sde, y0, ts, dt=0.01); torch.cuda.synchronize()
+    out["sde_em_ms"] = (time.perf_counter() - t0) * 1e3
+    out["sde_em_config"] = "SF2M Euler-Maruyama, B=2048, d=2, two w=64 fields, 100 steps"
+    a, b = oracle.config_inputs("C2")
+    M = ot.cost_matrix(a.to(dev), b.to(dev))
+    Bn = M.shape[0]
+    for name, fn in (("unbalanced", lambda n: ot.unbalanced_plan(M, 5.0, 1.0, max_iter=n, stop_thr=0.0)),
+                     ("partial", lambda n: ot.partial_plan(M, 5.0, 1.0, max_iter=n, stop_thr=0.0))):
+        fn(5); torch.cuda.synchronize()
+
+        def timed(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); _, info = fn(n); e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1), int(info[0].item())
+        ta, ia = timed(5)
+        tb, ib = timed(25)
+        if ib > ia:                                      # (the loops stop by themselves once they have converged)
+            per = (tb - ta) / (ib - ia)                  # ms per iteration without the kernel build / plan write
+            out[f"{name}_iters_per_s"] = 1e3 / per
+            out[f"{name}_gbs"] = 2 * 8.0 * Bn * Bn / (per * 1e-3) / 1e9
+        out[f"{name}_iters_timed"] = [ia, ib]
+    out["ot_kernel_space_config"] = "C2 clouds, B=4096, reg=5.0 (reg_m=1 / m=1): per-iteration rate from the 25- vs 5-iteration difference (iteration counts read back)"
+    return out
+
+
 def cpu_baseline(B, d, budget_s=25.0):
     """The reference's CPU step restated by the oracle — OTPlanSampler('exact').sample_plan +
     sample_location_and_conditional_flow (optimal_transport.py:63-145, conditional_flow_matching.py:159-199)
@@ -404,6 +445,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=3,
                     help="N > 0: up to N couplings of the next batches in flight on side streams while the "
                          "model steps on batch k (cfm_amd.prefetch); 0: strictly sequential")
+    ap.add_argument("--model-step", default="fused", choices=["fused", "eager"],
+                    help="fused: cfm_amd.RegressionStep (one C call: forward + MSE + backward, then the one-launch Adam); "
+                         "eager: the reference's four lines on the autograd.Function path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the C1 / C2 / C5 / roofline legs")
     ap.add_argument("--cpu-standin", action="store_true",
@@ -442,8 +486,10 @@ def main():
     fm = ExactOptimalTransportConditionalFlowMatcher(sigma=args.sigma)
     torch.manual_seed(0)
     model = cfm_amd.MLP(dim=d, time_varying=True, w=args.width).to(dev)
-    if world > 1:
+    if world > 1 and args.model_step != "fused":
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index])
+    # (fused: RegressionStep averages its flat gradient buffer with one RCCL all-reduce itself; every rank starts
+    #  from the same seed-0 weights)
     opt = cfm_amd.FusedAdam(model.parameters(), lr=1e-3)      # one-launch torch.optim.Adam arithmetic
     np.random.seed(D.shard_seed(1, rank)); torch.manual_seed(D.shard_seed(1, rank))
 
@@ -461,8 +507,14 @@ def main():
         i, j = ot.sample_perm(perm, u, B)
         return fm._sample(x0, x1, t_host.type_as(x0), False, idx=(i, j))
 
+    reg = cfm_amd.RegressionStep(model, opt) if args.model_step == "fused" else None
+
     def model_step(t, xt, ut):
         if args.mode != "train":
+            return
+        if reg is not None:
+            # forward (time column fused) + MSE + backward + [gradient all-reduce] + Adam: 14 launches of the library
+            reg(t, xt, ut)
             return
         opt.zero_grad(set_to_none=True)
         vt = model(torch.cat([xt, t[:, None]], dim=-1))
@@ -499,7 +551,7 @@ def main():
         "config": {"workload": "C3: MNIST-shaped d=784, B=4096 per GPU, ExactOptimalTransportConditionalFlowMatcher "
                                "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd (fp32-MFMA HIP kernels) + fused Adam (HIP)"
                                + ("; one all-gather of the final x_t over RCCL inside the timed region" if world > 1 else ""),
-                   "batch_per_gpu": B, "dim": d, "mlp_width": args.width, "mode": args.mode,
+                   "batch_per_gpu": B, "dim": d, "mlp_width": args.width, "mode": args.mode, "model_step": args.model_step,
                    "schedule": (f"couplings of the next {args.pipeline} batch(es) in flight on side streams during "
                                 "the model step" if args.pipeline else "sequential"),
                    "parallelism": f"dp{world}" if world > 1 else "single"},
@@ -517,6 +569,7 @@ def main():
         c5 = sinkhorn_leg(dev, "C5", 0.1)
         c5.update(c5_ode_leg(dev))
         out["c5"] = c5
+        out["aux"] = aux_legs(dev)
     else:
         out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                            "traffic": None, "note": "reported at N = 1 only"}

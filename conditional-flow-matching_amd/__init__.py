@@ -17,6 +17,7 @@ from .conditional_flow_matching import (  # noqa: F401
 )
 from .models import MLP  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
+from .train import RegressionStep  # noqa: F401
 from .optimal_transport import OTPlanSampler, wasserstein  # noqa: F401
 
 __version__ = "0.1.0"

@@ -173,6 +173,23 @@ extern "C" int cfm_assign_debug_times(const void* ws, double* us32) {
     return 0;
 }
 
+// Control of the bid rounds WITHOUT an arrival: a bid round needs no result of its own launch, only the number of
+// bidders of the PREVIOUS round to decide whether the epsilon phase goes on.  Every workgroup therefore takes that
+// decision itself in its prologue (the count was accumulated with fire-and-forget atomics and is complete: the
+// kernel boundary), from the control record the previous launch left in ctl[parity of this launch]; workgroup 0
+// writes the next record into ctl[other parity] — nobody of this launch reads that one, however late it starts.
+// The launch parity is a kernel argument (the graphs alternate it; every program has an even number of asg_step
+// launches).  Saves the two dependent device-scope atomics + the control step at the end of each of ~100 rounds.
+struct AucCtl {
+    double eps;
+    int mode, tag, round, phase, stop, arr_round;
+    int r;                                   // index of this bid launch (bidder counts: slot r & 3)
+    int auction_rounds, arr_rounds, row_scans;
+    int pad[2];
+};
+struct AsgAuc { AucCtl ctl[2]; alignas(128) int bidcnt[4]; };
+static_assert(sizeof(AsgAuc) <= 512, "AsgAuc has 512 bytes of the workspace");
+
 // SAP scan list entry arrays (two copies: current / next)
 struct SList {
     int* col;       // column j
@@ -185,6 +202,7 @@ struct SList {
 struct AsgWs {
     AsgState* st;
     unsigned long long* arrive_sub;   // 16 first-level arrival words, one per 128-byte line
+    AsgAuc* auc;                      // control records of the bid rounds
     double* p;        // prices (= -v), phase C on
     double* bidval;   // u_i (row minima)
     double* dist;     // SAP labels
@@ -230,13 +248,14 @@ __device__ __forceinline__ SList slist(const AsgWs& w, int c) {
 static inline size_t asg_ws_bytes(int n) {
     size_t N = ((size_t)n + 3) & ~(size_t)3;     // every array starts 16-byte aligned
     size_t lists = (n <= 4096) ? N * 64 * 8 + 8 * N : 0;
-    return 512 + 2048 + 8 * N * (4 + 4) + 4 * N * (10 + 6) + 64 + 16 + 16 * N * MS_YMAX + lists + 256;
+    return 512 + 2048 + 512 + 8 * N * (4 + 4) + 4 * N * (10 + 6) + 64 + 16 + 16 * N * MS_YMAX + lists + 256;
 }
 
 static inline AsgWs asg_carve(void* ws, int n) {
     AsgWs w; char* q = (char*)ws; size_t N = ((size_t)n + 3) & ~(size_t)3;
     w.st = (AsgState*)q; q += 512;
     w.arrive_sub = (unsigned long long*)q; q += 2048;
+    w.auc = (AsgAuc*)q; q += 512;
     w.p = (double*)q; q += 8 * N;
     w.bidval = (double*)q; q += 8 * N;
     w.dist = (double*)q; q += 8 * N;
@@ -1073,8 +1092,33 @@ __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds
 }
 
 // ----------------------------------------------------------------- step ------
+// What the bidder count of the previous round means for the next one (epsilon phases, epsilon = 0 rounds, hand-over).
+__device__ __forceinline__ void auc_decide(AucCtl& C, const AsgState* st, int cnt, int n) {
+    C.row_scans += cnt;
+    const int tag_next = (C.tag % 254) + 1;
+    if (C.mode == MODE_AUCTION) {
+        C.auction_rounds++;
+        const int round = C.round + 1;
+        if (cnt <= C.stop || round >= st->round_cap) {
+            const double e2 = C.eps / st->theta;
+            if (e2 < st->eps_last) { C.mode = MODE_ARR; C.eps = 0.0; C.arr_round = 0; }
+            else {
+                C.eps = e2; C.phase++;
+                const bool is_last = (e2 / st->theta) < st->eps_last;
+                C.stop = (int)((is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
+            }
+            C.tag = tag_next; C.round = 0;    // every row is unassigned again, the prices stay
+        } else C.round = round;
+    } else {
+        C.arr_rounds++;
+        const int ar = C.arr_round + 1;
+        C.arr_round = ar;
+        if (cnt == 0 || ar >= st->arr_cap) C.mode = MODE_CONVERT;
+    }
+}
+
 // control step of a launch: thread 0 of the last-arriving workgroup (MODE_CERT: the whole workgroup)
-__device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode, int n, int payload) {
+__device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode, int n, int payload, int par) {
     if (mode == MODE_CERT) {
         // the pass has filled minslack / total_cost: export the result to the caller's buffers
         int* perm = st->out_perm;
@@ -1104,31 +1148,7 @@ __device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode
     }
     if (threadIdx.x != 0) return;
     asg_book(st, mode);
-    if (mode == MODE_AUCTION || mode == MODE_ARR) {
-        // payload = rows that were unmatched at the START of this round (they all bid in it)
-        const int cnt = payload;
-        st->st_total_row_scans += cnt;
-        const int tag_next = (st->tag % 254) + 1;
-        if (mode == MODE_AUCTION) {
-            st->st_auction_rounds++;
-            const int round = st->round + 1;
-            if (cnt <= st->stop || round >= st->round_cap) {
-                const double e2 = st->eps / st->theta;
-                if (e2 < st->eps_last) { st->mode = MODE_ARR; st->eps = 0.0; st->arr_round = 0; }
-                else {
-                    st->eps = e2; st->phase++;
-                    const bool is_last = (e2 / st->theta) < st->eps_last;
-                    st->stop = (int)((is_last ? st->stop_frac : fmax(st->stop_frac, st->stop_early)) * n);
-                }
-                st->tag = tag_next; st->round = 0;    // every row is unassigned again, the prices stay
-            } else st->round = round;
-        } else {
-            st->st_arr_rounds++;
-            const int ar = st->arr_round + 1;
-            st->arr_round = ar;
-            if (cnt == 0 || ar >= st->arr_cap) st->mode = MODE_CONVERT;
-        }
-    } else if (mode == MODE_SAP) {
+    if (mode == MODE_SAP) {
         // New radius: one tree — the best free-column label (no label at or above it can matter);
         // several trees — the largest free-column label (infinite until every free column is
         // reached).  It only ever decreases within a phase, so an entry skipped once is never
@@ -1156,6 +1176,12 @@ __device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode
     } else if (mode == MODE_INITRED) {
         st->st_total_row_scans += n;
         st->round = 0; st->phase = 0; st->tag = 1;
+        // first control record of the bid rounds, for the NEXT launch (the other parity)
+        AucCtl C;
+        C.eps = st->eps; C.mode = MODE_AUCTION; C.tag = 1; C.round = 0; C.phase = 0; C.stop = st->stop; C.arr_round = 0;
+        C.r = 0; C.auction_rounds = 0; C.arr_rounds = 0; C.row_scans = 0; C.pad[0] = C.pad[1] = 0;
+        w.auc->ctl[par ^ 1] = C;
+        for (int q = 0; q < 4; ++q) asg_st(&w.auc->bidcnt[q], 0);
         st->mode = MODE_AUCTION;
     } else if (mode == MODE_CONVERT || mode == MODE_MS_FINISH) {
         st->mode = asg_ld(&st->next_mode);
@@ -1176,7 +1202,7 @@ __device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode
 // ONE wide kernel for every chip-wide step (modes UMIN0 .. CERT): the host replays it without knowing
 // which step comes next.  LDS (modes are exclusive): bid rounds — prices [n] fp64 + owner rows [n]
 // int; relax — 16 KiB of merge buffers; MS_FINISH — 2 n ints for the path walks; the rest < 8 KiB.
-__global__ __launch_bounds__(WT) void asg_step(AsgWs w, int n_host) {
+__global__ __launch_bounds__(WT) void asg_step(AsgWs w, int n_host, int par) {
     extern __shared__ __attribute__((aligned(16))) char step_lds[];
     __shared__ int sh[32];
     __shared__ double shd[32];
@@ -1199,17 +1225,39 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w, int n_host) {
         kst3 = *reinterpret_cast<const ulonglong2*>(w.key + (j3 < nn ? j3 : 0));
     }
     int pre_bc = (wave_gid < n_host) ? w.bidcol[wave_gid] : -1;
-    const int mode = st->mode;
+    int mode = st->mode;
     gfp M = ASG_GLOBAL(st->Mptr);
     asm volatile("" : "+v"(pre_bc), "+v"(kst0.x), "+v"(kst1.x), "+v"(kst2.x), "+v"(kst3.x) : "s"(mode) : "memory");   // all of it in flight
     if (mode > MODE_CERT || st->error) return;
     const int n = n_host;
     unsigned payload = 0;
+    // bid rounds: every workgroup decides for itself what this launch is (see AucCtl)
+    AucCtl C;
+    const bool bidding = (mode == MODE_AUCTION || mode == MODE_ARR);
+    if (bidding) {
+        C = w.auc->ctl[par & 1];
+        if (C.r > 0) auc_decide(C, st, asg_ld(&w.auc->bidcnt[(C.r - 1) & 3]), n);
+        mode = C.mode;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            asg_book(st, bidding && C.r > 0 ? (C.mode == MODE_CONVERT ? MODE_ARR : C.mode) : MODE_AUCTION);
+            if (mode == MODE_CONVERT) {
+                // the rounds are over: their results go back into the state block, this launch is the CONVERT step
+                st->tag = C.tag; st->eps = C.eps; st->phase = C.phase; st->round = C.round; st->arr_round = C.arr_round;
+                st->st_auction_rounds = C.auction_rounds; st->st_arr_rounds = C.arr_rounds;
+                st->st_total_row_scans += C.row_scans;
+            } else {
+                AucCtl N2 = C; N2.r = C.r + 1;
+                w.auc->ctl[(par & 1) ^ 1] = N2;
+                asg_st(&w.auc->bidcnt[(C.r + 1) & 3], 0);
+            }
+        }
+        if (mode == MODE_CONVERT) __syncthreads();      // (workgroup 0: the state block before ctrl_convert reads it)
+    }
     if (mode == MODE_AUCTION || mode == MODE_ARR) {
         double* p_lds = reinterpret_cast<double*>(step_lds);
         int* r_lds = reinterpret_cast<int*>(step_lds + (size_t)((n + 1) & ~1) * sizeof(double));
-        const double eps = st->eps; const int tag = st->tag, rb = st->rb;
-        const int rnd = (mode == MODE_ARR) ? min(st->arr_round + 1, (1 << ASG_RND_BITS) - 1) : 0;
+        const double eps = C.eps; const int tag = C.tag, rb = st->rb;
+        const int rnd = (mode == MODE_ARR) ? min(C.arr_round + 1, (1 << ASG_RND_BITS) - 1) : 0;
         if (threadIdx.x == 0) sh[0] = 0;
         if (stage_p) {
             const int mb = rb + ASG_RND_BITS;
@@ -1228,7 +1276,9 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w, int n_host) {
         const int nb = wide_bid(M, w, p_lds, r_lds, wave_gid, n_waves, pre_bc, stage_p, n, eps, tag, rb, rnd);
         if (lane == 0 && nb) atomicAdd(&sh[0], nb);
         __syncthreads();
-        payload = (unsigned)sh[0];
+        // the round's bidders, for the decision the next launch takes (no arrival: nothing of this launch needs it)
+        if (threadIdx.x == 0 && sh[0]) atomicAdd(&w.auc->bidcnt[C.r & 3], sh[0]);
+        return;
     } else if (mode == MODE_SAP) {
         double* sh_d = reinterpret_cast<double*>(step_lds);
         int* sh_i = reinterpret_cast<int*>(step_lds + sizeof(double) * WT);
@@ -1266,7 +1316,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w, int n_host) {
         }
     }
     const bool wait = (mode == MODE_SAP || mode == MODE_UMIN0 || mode == MODE_CERT || mode == MODE_CONVERT || mode == MODE_MS_FINISH);
-    if (asg_arrive_last(st, w.arrive_sub, &sh[30], payload, wait)) step_ctrl(w, st, mode, n, sh[31]);
+    if (asg_arrive_last(st, w.arrive_sub, &sh[30], payload, wait)) step_ctrl(w, st, mode, n, sh[31], par & 1);
 }
 
 // ---------------------------------------------------------------- build ------
@@ -1350,18 +1400,23 @@ static int asg_raise_lds() {
 // must not share it
 static thread_local int* g_pinned = nullptr;
 static thread_local int g_small_last[16];      // status block of this thread's last one-workgroup solve (phase times)
+static thread_local int g_fallback[2];         // tuning aid: {solves of this thread that the dense state machine had to redo, last device error code}
+extern "C" void cfm_assign_debug_fallback(int* out2) { out2[0] = g_fallback[0]; out2[1] = g_fallback[1]; }
 extern "C" void cfm_assign_debug_small(int* out16) { for (int q = 0; q < 16; ++q) out16[q] = g_small_last[q]; }
 
 struct AsgLaunch {
     AsgWs w; int n, blocks; size_t lds_step, lds_build, lds_solve; int sparse; hipStream_t s;
-    void step() const { hipLaunchKernelGGL(asg_step, dim3(blocks), dim3(WT), lds_step, s, w, n); }
+    // every program holds an EVEN number of asg_step launches and starts on an even launch count, so the parity
+    // argument (which control record a bid round reads, see AucCtl) is the position inside the program
+    void step(int par) const { hipLaunchKernelGGL(asg_step, dim3(blocks), dim3(WT), lds_step, s, w, n, par & 1); }
     void program(int prg, int chunk, int bulk) const {
-        if (prg == PRG_BULK) { for (int c = 0; c < bulk; ++c) step(); return; }
-        for (int c = 0; c < chunk; ++c) step();
+        int k = 0;
+        if (prg == PRG_BULK) { for (int c = 0; c < bulk; ++c) step(k++); return; }
+        for (int c = 0; c < chunk; ++c) step(k++);
         if (sparse) {
             hipLaunchKernelGGL(asg_build, dim3(blocks), dim3(SP_BUILD_WAVES * 64), lds_build, s, w, n);
             hipLaunchKernelGGL(asg_solve, dim3(1), dim3(SP_T), lds_solve, s, w, n);
-            step(); step();      // certificate + whatever the guess missed
+            step(k++); step(k++);      // certificate + whatever the guess missed
         }
     }
     int count(int prg, int chunk, int bulk) const { return prg == PRG_BULK ? bulk : chunk + (sparse ? 4 : 0); }
@@ -1419,8 +1474,8 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     int rc = cfm_status();
     if (rc) return rc;
 
-    const int chunk = P.chunk > 0 ? P.chunk : 10;
-    const int bulk = (n >= P.bulk_min_n) ? P.bulk : 0;
+    const int chunk = ((P.chunk > 0 ? P.chunk : 10) + 1) & ~1;        // even: see AsgLaunch::step
+    const int bulk = ((n >= P.bulk_min_n) ? P.bulk : 0) & ~1;
     AsgGraph& G = g_graph;
     bool use_graph = asg_graph_enabled() && !G.disabled && n >= 256;
     if (use_graph && !(G.exec[0] && G.ws == ws && G.n == n && G.chunk == chunk && G.bulk == bulk &&
@@ -1477,7 +1532,7 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
         rc = cfm_hip(hipEventSynchronize(G.ev[cur])); if (rc) return rc;
         const int* hs = g_pinned + 16 * cur;
         const int mode = hs[0], err = hs[2];
-        if (err) return CFM_ENOCONV;
+        if (err) { g_fallback[1] = err; return CFM_ENOCONV; }
         if (mode == MODE_DONE) { if (cert_out) *cert_out = hs[3]; break; }
         if (launched >= P.max_launches) return CFM_ETIMEOUT;
         cur ^= 1;
@@ -1524,8 +1579,11 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
     int rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, P, P.sparse, &cert);
     // The candidate-list path is exact by construction; should its certificate ever fail
     // (or its solver report an inconsistency) the dense state machine decides.
-    if (P.sparse && B > 1 && B <= SP_NMAX && (rc == CFM_ENOCONV || (rc == 0 && !cert)))
+    if (P.sparse && B > 1 && B <= SP_NMAX && (rc == CFM_ENOCONV || (rc == 0 && !cert))) {
+        ++g_fallback[0];
+        if (rc == 0) g_fallback[1] = -1;          // uncertified
         rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, P, 0, &cert);
+    }
     if (rc == 0 && B > 1 && !cert) rc = CFM_ENOCONV;     // never hand back an uncertified permutation silently
     return rc;
 }

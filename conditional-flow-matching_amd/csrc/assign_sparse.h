@@ -31,12 +31,13 @@
 #define SP_DENSE 0x8000u      // list entry: relax over the full matrix row
 #define SP_ROOT 0x4000u       // list entry: a free root row of the phase (low bits: its root slot, not a column)
 #define SP_COLMASK 0x0fffu
-#define SP_STALE 0x80000000u  // pred[k]: not improved in the current batch
-#define SP_MARK 0x7fffffffu   // pred[k]: improved in this batch, winner not chosen yet
 #define SP_ROOTS 64           // a phase grows one tree per free row, at most this many (= the hand-off threshold)
-#define SP_ROWMASK 0x0fffu    // pred[k] = root slot << 12 | predecessor row  (| SP_STALE)
-#define SP_SLOT(pr) (((pr) >> 12) & 63u)
+#define SP_ROWMASK 0x0fffull  // pkey[k] = (label bit pattern with its low 12 bits cleared) | predecessor row
+#define SP_NOKEY (~0ull)      // pkey[k]: column not reached in this phase
 #define SP_TNONE 0x7fffffff   // tcol[slot]: the tree accepted no free column
+#define SP_FREEROW 0xf000u    // a[i] >= SP_FREEROW: row i is free; during a phase a[i] = SP_FREEROW | its root slot
+#define SP_INL_NEAR 1u        // inl[k] bit 0: column is in the near pending list
+#define SP_INL_FAR 2u         // inl[k] bit 1: improved to a label above far_thr, to be re-bucketed
 
 #define SP_BUILD_WAVES 8   // waves per workgroup that build lists
 #define SP_CAP 64          // list entries per batch (16 waves x 4 entries kept in registers)
@@ -46,18 +47,21 @@
 static inline size_t sp_build_lds_bytes(int n) {
     return (size_t)SP_BUILD_WAVES * (size_t)((n + 63) / 64) * 64 * sizeof(float) + 64;
 }
-static inline size_t sp_solver_lds_bytes(int n) { return (size_t)n * 34 + 4096; }
+static inline size_t sp_solver_lds_bytes(int n) { return (size_t)((n + 15) & ~15) * 37 + 4096; }
 
 struct SpL {
     double* p;               // prices
     double* dist;            // labels of the current search (>= 0)
-    unsigned* pred;          // predecessor row | SP_STALE
+    unsigned long long* pkey;   // (label & ~0xfff) | predecessor row: ONE atomic min per improvement keeps the
+                                // predecessor of the smallest label (ties within 2^-40 relative: the lowest row)
+    unsigned char* slot;     // root slot (tree) of the column's label — a hint for the radius, written without
+                             // atomics; the finish walks the predecessors for the true tree
     unsigned short* owner;   // col -> row (SP_NOCOL: free)
-    unsigned short* a;       // row -> col (SP_NOCOL: free)
+    unsigned short* a;       // row -> col (>= SP_FREEROW: free)
     unsigned short* fcol;    // free columns
     unsigned short* pl[2];   // pending columns: improved, assigned, not yet relaxed (ping-pong)
     unsigned char* ddone;    // row of this column already relaxed densely at its current label
-    unsigned char* inl;      // column is in the pending list
+    unsigned char* inl;      // SP_INL_NEAR | SP_INL_FAR (updated with 32-bit LDS atomics while a batch runs)
     double* lbase;           // scan list (<= SP_CAP): label of the entry when it was listed
     unsigned short* lcol;    // scan list: column | flags
     double* rd;              // 64 doubles of scratch
@@ -73,15 +77,15 @@ struct SpL {
 #define SP_RI_NPL 64     // pending-list length (atomic append counter)
 #define SP_RI_NS 65      // entries in the scan list
 #define SP_RI_FLAG 66
-#define SP_RD_DFREE 48   // best free-column label
-#define SP_RD_FAR 49     // labels above this are only flagged (inl = 2), not listed, until the near list is empty
+#define SP_RD_DFREE 48   // radius of the phase
+#define SP_RD_FAR 49     // labels above this are only flagged (SP_INL_FAR), not listed, until the near list is empty
 #define SP_RI_RBAD 120   // 2 ints: mask of the root slots that failed the a-posteriori test
 #define SP_RI_NFC 122    // free columns / free rows left after a phase
 #define SP_RI_NFR 123
 #define SP_RI_ANYD 124   // some root of the phase starts dense
 
 __device__ __forceinline__ SpL sp_carve(char* lds, int n) {
-    SpL L; char* q = lds; const size_t N = (size_t)n;
+    SpL L; char* q = lds; const size_t N = (size_t)n;   // 37 bytes per column (rounded up to 16 columns) + 4096
     L.rd = (double*)q; q += 64 * 8;
     L.lbase = (double*)q; q += SP_CAP * 8;
     L.ri = (int*)q; q += 128 * 4;
@@ -92,16 +96,18 @@ __device__ __forceinline__ SpL sp_carve(char* lds, int n) {
     L.tcol = (int*)q; q += SP_ROOTS * 4;
     L.rrow = (unsigned short*)q; q += SP_ROOTS * 2;
     L.rdn = (unsigned char*)q; q += SP_ROOTS;          // + 1472 = 3264 (a multiple of 16) of the 4096 reserved
-    L.p = (double*)q; q += 8 * N;
-    L.dist = (double*)q; q += 8 * N;
-    L.pred = (unsigned*)q; q += 4 * N;
-    L.owner = (unsigned short*)q; q += 2 * N;
-    L.a = (unsigned short*)q; q += 2 * N;
-    L.fcol = (unsigned short*)q; q += 2 * N;
-    L.pl[0] = (unsigned short*)q; q += 2 * N;
-    L.pl[1] = (unsigned short*)q; q += 2 * N;
-    L.ddone = (unsigned char*)q; q += N;
-    L.inl = (unsigned char*)q;
+    const size_t N16 = (N + 15) & ~(size_t)15;
+    L.p = (double*)q; q += 8 * N16;
+    L.dist = (double*)q; q += 8 * N16;
+    L.pkey = (unsigned long long*)q; q += 8 * N16;
+    L.owner = (unsigned short*)q; q += 2 * N16;
+    L.a = (unsigned short*)q; q += 2 * N16;
+    L.fcol = (unsigned short*)q; q += 2 * N16;
+    L.pl[0] = (unsigned short*)q; q += 2 * N16;
+    L.pl[1] = (unsigned short*)q; q += 2 * N16;
+    L.ddone = (unsigned char*)q; q += N16;
+    L.inl = (unsigned char*)q; q += N16;
+    L.slot = (unsigned char*)q;
     return L;
 }
 
@@ -299,35 +305,37 @@ __device__ __forceinline__ double sp_block_min(double v, const SpL& L) {
     return r;
 }
 
-// Candidate update.  sp_lower: lower the label (LDS atomic min on the bit pattern: labels
-// are >= +0) and mark the column as improved.  sp_claim: among the lanes whose candidate
-// equals the final label of a column improved in this batch the lowest row id becomes the
-// predecessor (deterministic under ties); the first claimer files an assigned column in the
-// pending list.
-__device__ __forceinline__ void sp_lower(const SpL& L, int k, double cand, double cur) {
-    if (cand < cur) {
-        const unsigned long long nb = (unsigned long long)__double_as_longlong(cand);
-        const unsigned long long old = atomicMin((unsigned long long*)&L.dist[k], nb);
-        if (old > nb) { L.pred[k] = SP_MARK; L.ddone[k] = 0; }
-    }
-}
-__device__ __forceinline__ void sp_file(const SpL& L, int k, double label, unsigned char state, int plcur,
-                                        double far_thr) {
+// Candidate update, ONE phase.  A candidate below the column's label lowers it with an LDS atomic min on the bit
+// pattern (labels are >= +0), and its predecessor key — the same bits with the low 12 replaced by the row — goes
+// into pkey[k] with a second atomic min: the key that survives belongs to the smallest label, so label and
+// predecessor stay consistent without a second pass over the entries (two candidates closer than 2^-40 relative
+// tie on the key: the lower row is kept, its path is longer than the label by less than that).  Only strict
+// improvements write, so a chain of predecessors never closes a cycle.  The lane that lowered the label files an
+// assigned column in the pending queue.
+__device__ __forceinline__ void sp_file(const SpL& L, int k, double label, int plcur, double far_thr) {
+    // (test-and-set on the column's inl byte: several lanes may lower one column in a batch, one files it)
+    unsigned* w = reinterpret_cast<unsigned*>(L.inl) + (k >> 2);
+    const int sh = 8 * (k & 3);
     if (label <= far_thr) {
-        if (state != 1) {
-            L.inl[k] = 1;
+        const unsigned old = atomicOr(w, SP_INL_NEAR << sh);
+        if (!((old >> sh) & SP_INL_NEAR)) {
             const int pos = atomicAdd(&L.ri[SP_RI_NPL], 1);
             (plcur ? L.pl[1] : L.pl[0])[pos] = (unsigned short)k;
         }
-    } else if (state == 0) {
-        L.inl[k] = 2;
+    } else {
+        atomicOr(w, SP_INL_FAR << sh);
     }
 }
-__device__ __forceinline__ void sp_claim(const SpL& L, int k, double cand, unsigned i, double cur, unsigned pk,
-                                         int plcur, double far_thr) {
-    if (cand == cur && !(pk & SP_STALE)) {
-        const unsigned old = atomicMin(&L.pred[k], i);
-        if (old == SP_MARK && L.owner[k] != SP_NOCOL) sp_file(L, k, cand, L.inl[k], plcur, far_thr);
+__device__ __forceinline__ void sp_improve(const SpL& L, int k, double cand, double cur, double dfree, unsigned row,
+                                           unsigned slot, int plcur, double far_thr) {
+    if (cand < cur && cand < dfree) {                 // labels >= the radius can never matter
+        const unsigned long long nb = (unsigned long long)__double_as_longlong(cand);
+        const unsigned long long old = atomicMin((unsigned long long*)&L.dist[k], nb);
+        atomicMin(&L.pkey[k], (nb & ~SP_ROWMASK) | (unsigned long long)row);
+        if (old > nb) {
+            L.ddone[k] = 0; L.slot[k] = (unsigned char)slot;
+            if (L.owner[k] != SP_NOCOL) sp_file(L, k, cand, plcur, far_thr);
+        }
     }
 }
 __device__ __forceinline__ double sp_cand(double pk, float c, double rj, double base) {
@@ -335,17 +343,15 @@ __device__ __forceinline__ double sp_cand(double pk, float c, double rj, double 
     return base + rc;
 }
 
-// generic entry (dense entries allowed); recomputed in phase W.  A root entry carries its root slot, a
-// column entry inherits the slot of the tree that gave the column its label (pred[j]).
-template <bool PHASE_W>
+// generic entry (dense entries allowed).  A root entry carries its root slot, a column entry inherits the slot of
+// the tree that gave the column its label.
 __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, int n,
                                          unsigned e, double base, int lane, int plcur,
                                          double dfree, double far_thr) {
     const bool dense = (e & SP_DENSE) != 0, root = (e & SP_ROOT) != 0;
     const int j = root ? -1 : (int)(e & SP_COLMASK);
-    const unsigned slot = root ? (e & 63u) : SP_SLOT(L.pred[j]);
+    const unsigned slot = root ? (e & 63u) : (unsigned)L.slot[j];
     const int i = root ? (int)L.rrow[slot] : (int)L.owner[j];
-    const unsigned claim = (slot << 12) | (unsigned)i;
     double rj = root ? L.ru[slot] : 0.0;
     if (!dense) {
         const uint2 cl = w.cl[(size_t)i * SP_K + lane];
@@ -358,11 +364,8 @@ __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, in
             else cij = M[(size_t)i * n + j];
             rj = (double)cij + L.p[j];                        // = u_i: the matched edge is tight
         }
-        if (valid && (int)col != j) {
-            const double cand = sp_cand(L.p[col], c, rj, base);
-            if (PHASE_W) sp_claim(L, (int)col, cand, claim, L.dist[col], L.pred[col], plcur, far_thr);
-            else if (cand < dfree) sp_lower(L, (int)col, cand, L.dist[col]);
-        }
+        if (valid && (int)col != j)
+            sp_improve(L, (int)col, sp_cand(L.p[col], c, rj, base), L.dist[col], dfree, (unsigned)i, slot, plcur, far_thr);
     } else {
         gfp row = M + (size_t)i * n;
         if (!root) rj = (double)row[j] + L.p[j];
@@ -373,11 +376,8 @@ __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, in
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int k = k0 + q * 64 + lane;
-                if (k < n && k != j) {
-                    const double cand = sp_cand(L.p[k], c[q], rj, base);
-                    if (PHASE_W) sp_claim(L, k, cand, claim, L.dist[k], L.pred[k], plcur, far_thr);
-                    else if (cand < dfree) sp_lower(L, k, cand, L.dist[k]);
-                }
+                if (k < n && k != j)
+                    sp_improve(L, k, sp_cand(L.p[k], c[q], rj, base), L.dist[k], dfree, (unsigned)i, slot, plcur, far_thr);
             }
         }
     }
@@ -388,21 +388,20 @@ __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, in
 //     R = max over those trees of (smallest free-column label of the tree)
 // can matter any more.  The radius only ever shrinks (min with the current one): an entry skipped once is never
 // needed later, whatever happens to the trees afterwards — the finish accepts labels <= the final radius only, and
-// every label below it is final.  The tree of a column is the root slot in its predecessor word; a column lowered
-// in the batch that is still being claimed (SP_MARK) has no tree yet: the radius then stays as it is for one batch.
+// every label below it is final.  The tree of a column is read from its slot hint; a stale hint can only make the
+// radius smaller than intended (it stays >= the smallest free-column label), which costs augmentations of this
+// phase, never correctness.
 __device__ __forceinline__ double sp_radius(const SpL& L, int nFC, int lane, double dfree) {
     L.tmin[lane] = ~0ull;
-    double d = INFINITY; unsigned pr = SP_MARK;
-    if (lane < nFC) { const int k = L.fcol[lane]; d = L.dist[k]; pr = L.pred[k] & 0x7fffffffu; }
-    const bool have = d < INFINITY;
-    const bool unknown = have && pr == SP_MARK;
+    double d = INFINITY; unsigned sl = 0;
+    if (lane < nFC) { const int k = L.fcol[lane]; d = L.dist[k]; sl = L.slot[k] & 63u; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reset before the minima (same wave: LDS is in order)
-    if (have && !unknown) atomicMin(&L.tmin[SP_SLOT(pr)], (unsigned long long)__double_as_longlong(d));
+    if (d < INFINITY) atomicMin(&L.tmin[sl], (unsigned long long)__double_as_longlong(d));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long tm = L.tmin[lane];
     const double mine = (tm == ~0ull) ? -INFINITY : __longlong_as_double((long long)tm);
     double R = sp_wave_max(mine);
-    if (!(R > -INFINITY) || __ballot(unknown)) R = INFINITY;
+    if (!(R > -INFINITY)) R = INFINITY;
     return fmin(dfree, R);
 }
 
@@ -417,11 +416,12 @@ __device__ __forceinline__ double sp_rfl_d(double v) {
                             __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
-// One batch of <= SP_CAP sparse entries.  Written in stages over the (at most SP_E) entries
-// of this wave so that the LDS / global round trips of different entries overlap; everything
-// that is uniform over the wave (entry, row, tree, base label, the lane holding the matched edge)
-// is moved to scalar registers so the control flow is scalar.  Candidates stay in registers
-// between the two phases.  The last wave also refreshes the radius (published through LDS).
+// One batch of <= SP_CAP sparse entries: ONE phase, ONE barrier.  Written in stages over the (at most SP_E)
+// entries of this wave so that the LDS / global round trips of different entries overlap; everything that is
+// uniform over the wave (entry, row, tree, base label, the lane holding the matched edge) is moved to scalar
+// registers so the control flow is scalar.  The solver is instruction-issue bound (16 waves share 4 SIMDs): what
+// counts is the number of instructions per entry.  The last wave refreshes the radius after the barrier, while the
+// others start the bookkeeping (it is published for the NEXT batch: a stale, larger radius is always valid).
 __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& L,
                                               int n, int nS, int nFC, double dfree,
                                               int lane, int wv, int plcur, double far_thr, long long* fb) {
@@ -432,7 +432,7 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
     int nq = 0;
     if (nS > swv) { nq = (nS - swv + SP_NW - 1) / SP_NW; if (nq > SP_E) nq = SP_E; }
     int jj[SP_E], ii[SP_E], kk[SP_E]; bool root[SP_E], on[SP_E], use[SP_E];
-    unsigned claim[SP_E];
+    unsigned slot[SP_E];
     double bs[SP_E], cd[SP_E], pj[SP_E], pk[SP_E], dc[SP_E];
     uint2 cl[SP_E];
     // stage 1: entries (uniform LDS reads)
@@ -455,16 +455,16 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
     unsigned ov[SP_E], sv[SP_E];
 #pragma unroll
     for (int q = 0; q < SP_E; ++q) {
-        ov[q] = 0u; sv[q] = ev[q] << 12;
+        ov[q] = 0u; sv[q] = ev[q] & 63u;
         if (on[q]) {
             if (root[q]) ov[q] = L.rrow[ev[q] & 63u];
-            else { ov[q] = L.owner[jj[q]]; sv[q] = L.pred[jj[q]]; }
+            else { ov[q] = L.owner[jj[q]]; sv[q] = L.slot[jj[q]]; }
         }
     }
 #pragma unroll
     for (int q = 0; q < SP_E; ++q) {
         ii[q] = __builtin_amdgcn_readfirstlane((int)ov[q]);
-        claim[q] = (SP_SLOT((unsigned)__builtin_amdgcn_readfirstlane((int)sv[q])) << 12) | (unsigned)ii[q];
+        slot[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)sv[q]) & 63u;
     }
     // stage 3: candidate lists (one 8-byte load per lane and entry, all in flight together)
 #pragma unroll
@@ -483,7 +483,7 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
             kk[q] = use[q] ? (int)col : 0;
             pk[q] = L.p[kk[q]];
             dc[q] = L.dist[kk[q]];
-            pj[q] = root[q] ? L.ru[claim[q] >> 12] : L.p[jj[q]];
+            pj[q] = root[q] ? L.ru[slot[q]] : L.p[jj[q]];
         }
     }
     // stage 5: candidates
@@ -502,162 +502,113 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
             cd[q] = sp_cand(pk[q], __uint_as_float(cl[q].y), rj, bs[q]);
         }
     }
-    // stage 6: lower the labels (all atomics in flight before the first result is used)
-    unsigned long long oldb[SP_E];
+    // stage 6: lower the labels, keep the predecessor keys (all atomics in flight before the first result is used)
+    unsigned long long oldb[SP_E]; bool low[SP_E];
 #pragma unroll
     for (int q = 0; q < SP_E; ++q) {
-        oldb[q] = 0ull;
+        oldb[q] = 0ull; low[q] = false;
         if (on[q]) {
-            if (use[q] && cd[q] < dc[q] && cd[q] < dfree)      // labels >= dfree can never matter
-                oldb[q] = atomicMin((unsigned long long*)&L.dist[kk[q]], (unsigned long long)__double_as_longlong(cd[q]));
+            low[q] = use[q] && cd[q] < dc[q] && cd[q] < dfree;      // labels >= the radius can never matter
+            if (low[q]) {
+                const unsigned long long nb = (unsigned long long)__double_as_longlong(cd[q]);
+                oldb[q] = atomicMin((unsigned long long*)&L.dist[kk[q]], nb);
+                atomicMin(&L.pkey[kk[q]], (nb & ~SP_ROWMASK) | (unsigned long long)(unsigned)ii[q]);
+            }
+        }
+    }
+    // the lanes that lowered a label: tree hint, dense mark, and an assigned column goes to the pending list
+    unsigned ow[SP_E];
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        ow[q] = SP_NOCOL;
+        if (on[q]) {
+            low[q] = low[q] && oldb[q] > (unsigned long long)__double_as_longlong(cd[q]);
+            if (low[q]) { ow[q] = L.owner[kk[q]]; L.ddone[kk[q]] = 0; L.slot[kk[q]] = (unsigned char)slot[q]; }
         }
     }
 #pragma unroll
     for (int q = 0; q < SP_E; ++q)
-        if (on[q] && oldb[q] > (unsigned long long)__double_as_longlong(cd[q])) { L.pred[kk[q]] = SP_MARK; L.ddone[kk[q]] = 0; }
+        if (on[q] && low[q] && ow[q] != SP_NOCOL) sp_file(L, kk[q], cd[q], plcur, far_thr);
     FB_TICK(1);
     sp_sync();
     FB_TICK(2);
-    // phase W, staged the same way
-    unsigned pc[SP_E], oldp[SP_E], ow[SP_E]; unsigned char il[SP_E]; bool won[SP_E];
-#pragma unroll
-    for (int q = 0; q < SP_E; ++q) { dc[q] = -1.0; pc[q] = SP_STALE; if (on[q]) { dc[q] = L.dist[kk[q]]; pc[q] = L.pred[kk[q]]; } }
-#pragma unroll
-    for (int q = 0; q < SP_E; ++q) {
-        oldp[q] = 0u; won[q] = false;
-        if (on[q]) {
-            won[q] = use[q] && cd[q] == dc[q] && !(pc[q] & SP_STALE);
-            if (won[q]) oldp[q] = atomicMin(&L.pred[kk[q]], claim[q]);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < SP_E; ++q) {
-        ow[q] = SP_NOCOL; il[q] = 1;
-        if (on[q]) { won[q] = won[q] && oldp[q] == SP_MARK; ow[q] = L.owner[kk[q]]; il[q] = L.inl[kk[q]]; }
-    }
-#pragma unroll
-    for (int q = 0; q < SP_E; ++q) {
-        if (on[q]) {
-            if (won[q] && ow[q] != SP_NOCOL) sp_file(L, kk[q], cd[q], il[q], plcur, far_thr);
-        }
-    }
-    FB_TICK(3);
-    sp_sync();
-    FB_TICK(4);
-    // the radius from the claimed state (every tree tag of this batch is in place), by the last wave, while the
-    // others start the bookkeeping: it is published for the NEXT batch (a stale, larger radius is always valid)
     if (swv == SP_NW - 1) {
         const double dnew = sp_radius(L, nFC, lane, dfree);
         if (lane == 0) L.rd[SP_RD_DFREE] = dnew;
     }
-    FB_TICK(5);
+    FB_TICK(3);
 }
 
-// Bookkeeping after a batch, ONE wave, on the NEAR pending list (labels <= far_thr; columns
-// improved to a label above far_thr are only flagged inl = 2 and found again by sp_rebucket
-// when the near list runs dry: a two-level bucket queue, so a batch never pays for the whole
-// frontier).  Every listed column gets SP_STALE (its improvement batch is over); columns at
-// or above dfree are dropped; of the rest the ones within `delta` of the smallest label (at
-// most SP_CAP) become the next scan list.  Publishes nS, the new list length and far_thr;
-// returns the adapted delta.
-__device__ __forceinline__ double sp_collect(const SpL& L, int plcur, double dfree, double delta, double far_thr,
-                                             int lane) {
-    const int npl = L.ri[SP_RI_NPL];
-#ifdef SP_PROFILE
-    if (lane == 0) L.ri[125] += npl;
+// Bookkeeping after a batch on the NEAR pending list (labels <= far_thr; columns improved to a label above far_thr
+// are only flagged SP_INL_FAR and found again by the re-bucketing when the near list runs dry: a two-level bucket
+// queue, so a batch never pays for the whole frontier).  Columns at or above dfree are dropped; of the rest the ones
+// within `delta` of the smallest label (at most SP_CAP) become the next scan list — the window keeps the scan order
+// close to the label order, which is what keeps the number of relaxations (and of batches) down: a FIFO bucket queue
+// (64 buckets per epoch, one append per filing, no pass over the list) was built and measured in round 3 — its
+// batches were 25 % cheaper but it needed 1.6 x as many (18 - 22 k scans against 11.5 k), 2.3 - 2.7 ms against 2.0.
+// Publishes nS, the new list length and far_thr; every thread returns the same adapted delta.
+// The solver is instruction-issue bound, so only as many waves as the list needs take part (thread <-> entry, up to
+// SP_IPT entries per thread for lists beyond 1024): the others go straight to the barriers.
+#ifndef SP_FARMULT
+#define SP_FARMULT 3.0   // the near list holds the labels within this many windows of the smallest one (measured: 3 -> 1.82 ms, 5 -> 1.96, 8 -> 1.92 of solver time at C3)
 #endif
-    const unsigned short* src = plcur ? L.pl[1] : L.pl[0];
-    unsigned short* dst = plcur ? L.pl[0] : L.pl[1];
-    double lmin = INFINITY, lmax = 0.0; int np = 0;
-    for (int t = lane; t < npl; t += 64) {
-        const int k = src[t];
-        const double d = L.dist[k];
-        L.pred[k] |= SP_STALE;
-        if (d < dfree) { lmin = fmin(lmin, d); lmax = fmax(lmax, d); ++np; }
-    }
-    const double dmin = sp_wave_min(lmin), dmax = sp_wave_max(lmax);
-    const int npend = sp_wave_total(np);
-    if (!(far_thr < INFINITY) && delta < INFINITY && npend > 2 * SP_CAP) far_thr = dmin + 8.0 * delta;
-    const double tau = dmin + delta;
-    int nsel = 0, nkeep = 0;
-    for (int t0 = 0; t0 < npl; t0 += 64) {
-        const int t = t0 + lane;
-        int k = 0; double d = INFINITY; bool live = false;
-        if (t < npl) { k = src[t]; d = L.dist[k]; live = d < dfree; }
-        const bool want = live && d <= tau;
-        const int sinc = sp_wave_scan(want ? 1 : 0);
-        const int spos = nsel + sinc - 1;
-        const bool sel = want && spos < SP_CAP;
-        const bool keep = live && !sel && d <= far_thr;
-        const int kinc = sp_wave_scan(keep ? 1 : 0);
-        if (sel) { L.lcol[spos] = (unsigned short)k; L.lbase[spos] = d; L.inl[k] = 0; }
-        if (keep) dst[nkeep + kinc - 1] = (unsigned short)k;
-        if (t < npl && !sel && !keep) L.inl[k] = live ? 2 : 0;
-        nsel += __builtin_amdgcn_readlane(sinc, 63);
-        nkeep += __builtin_amdgcn_readlane(kinc, 63);
-    }
-    if (lane == 0) {
-        L.ri[SP_RI_NS] = nsel < SP_CAP ? nsel : SP_CAP; L.ri[SP_RI_NPL] = nkeep; L.rd[SP_RD_FAR] = far_thr;
-    }
-    // adapt the window: aim at 32 .. 64 entries per batch
-    if (nsel > SP_CAP) delta = 0.5 * fmin(delta, dmax - dmin);
-    else if (nsel < SP_CAP / 2 && npend > nsel) delta = fmax(2.0 * delta, (dmax - dmin) * (1.0 / 64.0));
-    return delta;
-}
-
-// The same bookkeeping by ALL 16 waves (sp_collect's single wave was 40 % of a batch): every
-// thread owns up to SP_IPT entries of the near list, the waves exchange (min, max, count) and then
-// their selection counts through LDS, two barriers in all.  Entries are taken in (wave, slot,
-// lane) order instead of list order — the list order is arbitrary anyway (atomic appends).
-// Every thread returns the same adapted delta; nS / list length / far_thr are published in LDS.
 #define SP_RI_WANT 16    // 16 per-wave selection counts
 #define SP_RI_KEEP 96    // 16 per-wave keep counts
 __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double dfree, double delta,
                                                  double far_thr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int npl = L.ri[SP_RI_NPL];
+    const int nslot = (npl + SP_T - 1) / SP_T;                     // entries per thread (uniform)
+    const int nwav = npl >= SP_T ? SP_NW : (npl + 63) / 64;        // waves that hold entries (uniform)
+    const bool active = wv < nwav;
     const unsigned short* src = plcur ? L.pl[1] : L.pl[0];
     unsigned short* dst = plcur ? L.pl[0] : L.pl[1];
     int kk[SP_IPT]; double dd[SP_IPT]; bool have[SP_IPT], live[SP_IPT];
     double lmin = INFINITY, lmax = 0.0; int np = 0;
 #pragma unroll
     for (int e = 0; e < SP_IPT; ++e) {
-        const int t = e * SP_T + tid;
-        have[e] = t < npl; kk[e] = 0; dd[e] = INFINITY; live[e] = false;
-        if (have[e]) {
-            kk[e] = src[t];
-            dd[e] = L.dist[kk[e]];
-            L.pred[kk[e]] |= SP_STALE;
-            live[e] = dd[e] < dfree;
-            if (live[e]) { lmin = fmin(lmin, dd[e]); lmax = fmax(lmax, dd[e]); ++np; }
+        have[e] = false; kk[e] = 0; dd[e] = INFINITY; live[e] = false;
+        if (e < nslot && active) {
+            const int t = e * SP_T + tid;
+            have[e] = t < npl;
+            if (have[e]) {
+                kk[e] = src[t];
+                dd[e] = L.dist[kk[e]];
+                live[e] = dd[e] < dfree;
+                if (live[e]) { lmin = fmin(lmin, dd[e]); lmax = fmax(lmax, dd[e]); ++np; }
+            }
         }
     }
-    {
+    if (active) {
         const double wmin = sp_wave_min(lmin), wmax = sp_wave_max(lmax);
         const int wnp = sp_wave_total(np);
         if (lane == 0) { L.rd[wv] = wmin; L.rd[16 + wv] = wmax; L.ri[wv] = wnp; }
     }
     sp_sync();
-    const double dmin = sp_wave_min(lane < SP_NW ? L.rd[lane] : INFINITY);
-    const double dmax = sp_wave_max(lane < SP_NW ? L.rd[16 + lane] : 0.0);
-    const int npend = sp_wave_total(lane < SP_NW ? L.ri[lane] : 0);
-    if (!(far_thr < INFINITY) && delta < INFINITY && npend > 2 * SP_CAP) far_thr = dmin + 8.0 * delta;
+    const double dmin = sp_wave_min(lane < nwav ? L.rd[lane] : INFINITY);
+    const double dmax = sp_wave_max(lane < nwav ? L.rd[16 + lane] : 0.0);
+    const int npend = sp_wave_total(lane < nwav ? L.ri[lane] : 0);
+    if (!(far_thr < INFINITY) && delta < INFINITY && npend > 2 * SP_CAP) far_thr = dmin + SP_FARMULT * delta;
     const double tau = dmin + delta;
     bool want[SP_IPT], keep[SP_IPT]; int wpos[SP_IPT], kpos[SP_IPT];
     int wtot = 0, ktot = 0;
 #pragma unroll
     for (int e = 0; e < SP_IPT; ++e) {
-        want[e] = live[e] && dd[e] <= tau;
-        keep[e] = live[e] && !want[e] && dd[e] <= far_thr;
-        const int winc = sp_wave_scan(want[e] ? 1 : 0), kinc = sp_wave_scan(keep[e] ? 1 : 0);
-        wpos[e] = wtot + winc - 1; kpos[e] = ktot + kinc - 1;
-        wtot += __builtin_amdgcn_readlane(winc, 63); ktot += __builtin_amdgcn_readlane(kinc, 63);
+        want[e] = false; keep[e] = false; wpos[e] = 0; kpos[e] = 0;
+        if (e < nslot && active) {
+            want[e] = live[e] && dd[e] <= tau;
+            keep[e] = live[e] && !want[e] && dd[e] <= far_thr;
+            const unsigned long long mw = __ballot(want[e]), mk = __ballot(keep[e]);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            wpos[e] = wtot + __popcll(mw & below); kpos[e] = ktot + __popcll(mk & below);
+            wtot += __popcll(mw); ktot += __popcll(mk);
+        }
     }
-    if (lane == 0) { L.ri[SP_RI_WANT + wv] = wtot; L.ri[SP_RI_KEEP + wv] = ktot; }
+    if (lane == 0 && active) { L.ri[SP_RI_WANT + wv] = wtot; L.ri[SP_RI_KEEP + wv] = ktot; }
     sp_sync();
     int woff, koff, nsel, nkeep;
     {
-        const int wc = (lane < SP_NW) ? L.ri[SP_RI_WANT + lane] : 0, kc = (lane < SP_NW) ? L.ri[SP_RI_KEEP + lane] : 0;
+        const int wc = (lane < nwav) ? L.ri[SP_RI_WANT + lane] : 0, kc = (lane < nwav) ? L.ri[SP_RI_KEEP + lane] : 0;
         const int ws = sp_wave_scan(wc), ks = sp_wave_scan(kc);
         nsel = __builtin_amdgcn_readlane(ws, 63); nkeep = __builtin_amdgcn_readlane(ks, 63);
         woff = __shfl(ws - wc, wv, 64); koff = __shfl(ks - kc, wv, 64);
@@ -668,16 +619,18 @@ __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double
         ktot = 0;
 #pragma unroll
         for (int e = 0; e < SP_IPT; ++e) {
-            const bool sel = want[e] && (woff + wpos[e]) < SP_CAP;
-            keep[e] = live[e] && !sel && dd[e] <= far_thr;
-            want[e] = sel;
-            const int kinc = sp_wave_scan(keep[e] ? 1 : 0);
-            kpos[e] = ktot + kinc - 1;
-            ktot += __builtin_amdgcn_readlane(kinc, 63);
+            if (e < nslot && active) {
+                const bool sel = want[e] && (woff + wpos[e]) < SP_CAP;
+                keep[e] = live[e] && !sel && dd[e] <= far_thr;
+                want[e] = sel;
+                const unsigned long long mk = __ballot(keep[e]);
+                kpos[e] = ktot + __popcll(mk & ((1ull << lane) - 1ull));
+                ktot += __popcll(mk);
+            }
         }
-        if (lane == 0) L.ri[SP_RI_KEEP + wv] = ktot;
+        if (lane == 0 && active) L.ri[SP_RI_KEEP + wv] = ktot;
         sp_sync();
-        const int kc = (lane < SP_NW) ? L.ri[SP_RI_KEEP + lane] : 0;
+        const int kc = (lane < nwav) ? L.ri[SP_RI_KEEP + lane] : 0;
         const int ks = sp_wave_scan(kc);
         nkeep = __builtin_amdgcn_readlane(ks, 63);
         koff = __shfl(ks - kc, wv, 64);
@@ -692,11 +645,14 @@ __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double
         } else if (keep[e]) {
             dst[koff + kpos[e]] = (unsigned short)k;
         } else {
-            L.inl[k] = live[e] ? 2 : 0;
+            L.inl[k] = live[e] ? (unsigned char)SP_INL_FAR : (unsigned char)0;
         }
     }
     if (tid == 0) {
         L.ri[SP_RI_NS] = nsel < SP_CAP ? nsel : SP_CAP; L.ri[SP_RI_NPL] = nkeep; L.rd[SP_RD_FAR] = far_thr;
+#ifdef SP_PROFILE
+        L.ri[125] += npl;
+#endif
     }
     // adapt the window: aim at 32 .. 64 entries per batch
     if (nsel > SP_CAP) delta = 0.5 * fmin(delta, dmax - dmin);
@@ -751,7 +707,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
         const int nR = nFree;                 // every free row is a root of this phase (slot s <-> rrow[s])
         ++phases;
         for (int k = tid; k < n; k += SP_T) {
-            L.dist[k] = INFINITY; L.pred[k] = SP_STALE | SP_MARK; L.ddone[k] = 0; L.inl[k] = 0;
+            L.dist[k] = INFINITY; L.pkey[k] = SP_NOKEY; L.ddone[k] = 0; L.inl[k] = 0; L.slot[k] = 0;
         }
         // roots: u_r = min_k (c_rk + p_k), one wave per root.  The candidate minimum is the row minimum iff it does
         // not exceed the bound T_r of the dropped columns; otherwise take it over the full row and start the root
@@ -770,6 +726,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 u0 = sp_wave_min(mm);
             }
             if (lane == 0) {
+                L.a[i0] = (unsigned short)(SP_FREEROW | (unsigned)s0);      // free, root slot s0 of this phase
                 L.ru[s0] = u0; L.rdn[s0] = rdense ? 1 : 0;
                 L.lcol[s0] = (unsigned short)(SP_ROOT | (rdense ? SP_DENSE : 0u) | (unsigned)s0); L.lbase[s0] = 0.0;
                 if (rdense) L.ri[SP_RI_ANYD] = 1;
@@ -792,12 +749,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 } else {
                     for (int t = wv; t < nS; t += SP_NW) {
                         const double b = L.lbase[t];
-                        if (b < dfree) sp_entry<false>(M, w, L, n, L.lcol[t], b, lane, plcur, dfree, far_thr);
-                    }
-                    sp_sync();
-                    for (int t = wv; t < nS; t += SP_NW) {
-                        const double b = L.lbase[t];
-                        if (b < dfree) sp_entry<true>(M, w, L, n, L.lcol[t], b, lane, plcur, dfree, far_thr);
+                        if (b < dfree) sp_entry(M, w, L, n, L.lcol[t], b, lane, plcur, dfree, far_thr);
                     }
                     sp_sync();
                     if (wv == SP_NW - 1) {
@@ -810,8 +762,8 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 if (!any_dense) { SP_TICK(1); ++nfast; } else { SP_TICK(5); }
 #endif
             }
-            // (the batch's radius is published by the last wave after the batch's final barrier: it is read below,
-            //  behind the barriers of the bookkeeping, which itself still works with the previous, larger one)
+            // (the batch's radius is published by the last wave after the batch's barrier: it is read below, behind
+            //  the barriers of the bookkeeping, which itself still works with the previous, larger one)
             delta = sp_collect_all(L, plcur, dfree, delta, far_thr);
             sp_sync();
             dfree = L.rd[SP_RD_DFREE];
@@ -827,7 +779,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 for (int e = 0; e < SP_IPT; ++e) {
                     const int k = e * SP_T + tid;
                     far[e] = false; dk4[e] = INFINITY;
-                    if (k < n && L.inl[k] == 2) {
+                    if (k < n && L.inl[k] == (unsigned char)SP_INL_FAR) {
                         const double d = L.dist[k];
                         if (d < dfree) { far[e] = true; dk4[e] = d; lm = fmin(lm, d); }
                         else L.inl[k] = 0;
@@ -835,7 +787,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 }
                 const double fmin_ = sp_block_min(lm, L);
                 if (fmin_ < INFINITY) {
-                    far_thr = fmin_ + 8.0 * delta;
+                    far_thr = fmin_ + SP_FARMULT * delta;
                     int cnt2 = 0;
 #pragma unroll
                     for (int e = 0; e < SP_IPT; ++e) { far[e] = far[e] && dk4[e] <= far_thr; cnt2 += far[e] ? 1 : 0; }
@@ -850,7 +802,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
 #pragma unroll
                     for (int e = 0; e < SP_IPT; ++e) {
                         const int k = e * SP_T + tid;
-                        if (far[e]) { near[off2++] = (unsigned short)k; L.inl[k] = 1; }
+                        if (far[e]) { near[off2++] = (unsigned short)k; L.inl[k] = (unsigned char)SP_INL_NEAR; }
                     }
                     if (tid == 0) { L.ri[SP_RI_NPL] = nmove; L.rd[SP_RD_FAR] = far_thr; }
                     sp_sync();
@@ -932,13 +884,13 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
             if (d < INFINITY && d <= dfree) {                 // labels above the radius are not final
                 int j = k, g2 = 0;
                 for (;;) {
-                    const unsigned pr = L.pred[j] & 0x7fffffffu;
-                    if (pr == SP_MARK || ++g2 > n + 1) { bad = 1; break; }
+                    const unsigned long long pr = L.pkey[j];
+                    if (pr == SP_NOKEY || ++g2 > n + 1) { bad = 1; break; }
                     const int i = (int)(pr & SP_ROWMASK);
                     const int aj = L.a[i];
-                    if (aj == (int)SP_NOCOL) {                // a free row: the root of the tree
-                        myslot = (int)SP_SLOT(pr);
-                        if (myslot >= nR || (int)L.rrow[myslot] != i) { bad = 1; myslot = -1; }
+                    if (aj >= (int)SP_FREEROW) {              // a free row: the root of the tree, marked with its slot
+                        myslot = aj & 63;
+                        if (aj == (int)SP_NOCOL || myslot >= nR || (int)L.rrow[myslot] != i) { bad = 1; myslot = -1; }
                         break;
                     }
                     j = aj;
@@ -967,12 +919,12 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
         if (wv == 0 && lane < nR && L.tcol[lane] != SP_TNONE) {
             int j = L.tcol[lane], g2 = 0; const int r = L.rrow[lane]; bool closed = false;
             while (g2++ <= n) {
-                const int i = (int)(L.pred[j] & SP_ROWMASK);
+                const int i = (int)(L.pkey[j] & SP_ROWMASK);
                 const int jprev = L.a[i];
                 L.owner[j] = (unsigned short)i; L.a[i] = (unsigned short)j;
                 if (i == r) { closed = true; break; }
                 j = jprev;
-                if (j == (int)SP_NOCOL) break;
+                if (j >= (int)SP_FREEROW) break;
             }
             if (!closed) L.ri[SP_RI_FLAG] = 3;
         }
@@ -983,7 +935,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
             const bool keepc = lane < nFC && L.owner[k] == SP_NOCOL;
             const unsigned long long mc = __ballot(keepc);
             const int r = (lane < nFree) ? (int)L.rrow[lane] : 0;
-            const bool keepr = lane < nFree && L.a[r] == SP_NOCOL;
+            const bool keepr = lane < nFree && L.a[r] >= SP_FREEROW;
             const unsigned long long mr = __ballot(keepr);
             const unsigned long long below = (1ull << lane) - 1ull;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1005,7 +957,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
     for (int k = tid; k < n; k += SP_T) {
         w.p[k] = L.p[k];
         w.owner[k] = (L.owner[k] == SP_NOCOL) ? -1 : (int)L.owner[k];
-        w.a[k] = (L.a[k] == SP_NOCOL) ? -1 : (int)L.a[k];
+        w.a[k] = (L.a[k] >= SP_FREEROW) ? -1 : (int)L.a[k];
     }
 #ifdef SP_PROFILE
     if (tid == 0) {

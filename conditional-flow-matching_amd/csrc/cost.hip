@@ -21,6 +21,7 @@
 //                  8x8 super-tiles of workgroups per XCD so both operand panels
 //                  stay in that XCD's 4 MiB L2.
 #include "cfm_common.h"
+#include "gemm_core.h"
 #include <stdlib.h>
 
 // ---------------------------------------------------------------- small d ----
@@ -228,17 +229,16 @@ __global__ __launch_bounds__(256) void cost_norms(const float* __restrict__ x0, 
     if (lane == 0) nrm[row] = s;
 }
 
-// BM x 128 output tile per workgroup, 2 x 2 waves.
+// 128 x 128 output tile per workgroup on the shared tile engine (gemm_core.h): both clouds K-contiguous,
+// centred by mu on the way into LDS.
 template <int BM, bool VEC>
 __global__ __launch_bounds__(256) void cost_gemm(const float* __restrict__ x0, const float* __restrict__ x1,
                                                  int B0, int B1, int d, const float* __restrict__ mu,
                                                  const float* __restrict__ nrm, float* __restrict__ M,
                                                  int tiles_m, int tiles_n) {
-    constexpr int BN = 128, BK = 32, LD = BK + 1;
-    constexpr int MT = BM / 64;                    // 32-row MFMA tiles per wave along M
-    constexpr int QA = BM / 32, QB = BN / 32;      // float4 per thread and stage (A, B)
-    __shared__ float As[BM * LD];
-    __shared__ float Bs[BN * LD];
+    constexpr int BN = 128, BK = 16;
+    using Core = GemmCore<BM, BN, BK, false, false, VEC, VEC>;
+    __shared__ __attribute__((aligned(16))) float lds[Core::LDS_FLOATS];
 
     // XCD-aware super-tile order (as cost_tiled): each XCD walks 8x8 groups of tiles
     unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
@@ -256,128 +256,38 @@ __global__ __launch_bounds__(256) void cost_gemm(const float* __restrict__ x0, c
         tn = gcol * G + rr % cols_in_group;
     }
     const int row0 = tm * BM, col0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;          // 2 x 2 waves, (BM / 2) x 64 outputs each
+    const int tid = threadIdx.x, lane = tid & 63;
 
-    cost_f32x16 acc[MT][2];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    Core g;
+    g.zero();
+    auto pre = [&](auto& oa, auto& ob, int k0) { oa.sub_k(mu, k0, d); ob.sub_k(mu, k0, d); };
+    g.run(lds, x0, d, row0, B0, x1, d, col0, B1, 0, d, pre, GcNoPost());
 
-    // a stage is [128 rows x 32 k] per operand.  VEC: thread owns float4 (row (tid >> 3) + 32 q,
-    // k = 4 (tid & 7)); otherwise single floats (row (tid >> 5) + 8 q, k = tid & 31): the k slot of
-    // a thread is the same for all of its elements, so mu is read once per stage.
-    float4 ra[QA], rb[QB];
-    auto fetch = [&](int k0) {
-        if (VEC) {
-            const int gk = k0 + 4 * (tid & 7);
-            const bool kin = gk < d;
-            const float4 m4 = kin ? *reinterpret_cast<const float4*>(mu + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int q = 0; q < QA; ++q) {
-                const int ga = row0 + (tid >> 3) + 32 * q;
-                float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kin && ga < B0) {
-                    va = *reinterpret_cast<const float4*>(x0 + (size_t)ga * d + gk);
-                    va.x -= m4.x; va.y -= m4.y; va.z -= m4.z; va.w -= m4.w;
-                }
-                ra[q] = va;
-            }
-#pragma unroll
-            for (int q = 0; q < QB; ++q) {
-                const int gb = col0 + (tid >> 3) + 32 * q;
-                float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kin && gb < B1) {
-                    vb = *reinterpret_cast<const float4*>(x1 + (size_t)gb * d + gk);
-                    vb.x -= m4.x; vb.y -= m4.y; vb.z -= m4.z; vb.w -= m4.w;
-                }
-                rb[q] = vb;
-            }
-        } else {
-            const int gk = k0 + (tid & 31);
-            const bool kin = gk < d;
-            const float m1 = kin ? mu[gk] : 0.f;
-            float* fa = reinterpret_cast<float*>(ra);
-            float* fb = reinterpret_cast<float*>(rb);
-#pragma unroll
-            for (int q = 0; q < 4 * QA; ++q) {
-                const int ga = row0 + (tid >> 5) + 8 * q;
-                fa[q] = (kin && ga < B0) ? x0[(size_t)ga * d + gk] - m1 : 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < 4 * QB; ++q) {
-                const int gb = col0 + (tid >> 5) + 8 * q;
-                fb[q] = (kin && gb < B1) ? x1[(size_t)gb * d + gk] - m1 : 0.f;
-            }
-        }
-    };
-    auto stash = [&]() {
-        if (VEC) {
-            const int kc = 4 * (tid & 7);
-#pragma unroll
-            for (int q = 0; q < QA; ++q) {
-                float* pa = &As[((tid >> 3) + 32 * q) * LD + kc];
-                pa[0] = ra[q].x; pa[1] = ra[q].y; pa[2] = ra[q].z; pa[3] = ra[q].w;
-            }
-#pragma unroll
-            for (int q = 0; q < QB; ++q) {
-                float* pb = &Bs[((tid >> 3) + 32 * q) * LD + kc];
-                pb[0] = rb[q].x; pb[1] = rb[q].y; pb[2] = rb[q].z; pb[3] = rb[q].w;
-            }
-        } else {
-            const float* fa = reinterpret_cast<const float*>(ra);
-            const float* fb = reinterpret_cast<const float*>(rb);
-#pragma unroll
-            for (int q = 0; q < 4 * QA; ++q) As[((tid >> 5) + 8 * q) * LD + (tid & 31)] = fa[q];
-#pragma unroll
-            for (int q = 0; q < 4 * QB; ++q) Bs[((tid >> 5) + 8 * q) * LD + (tid & 31)] = fb[q];
-        }
-    };
-
-    fetch(0);
-    const int fr = lane & 31, fk = lane >> 5;
-    for (int k0 = 0; k0 < d; k0 += BK) {
-        stash();
-        __syncthreads();
-        if (k0 + BK < d) fetch(k0 + BK);            // in flight while the MFMAs run
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[MT], b[2];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = As[(wm * (BM / 2) + m * 32 + fr) * LD + kk + fk];
-#pragma unroll
-            for (int nn = 0; nn < 2; ++nn) b[nn] = Bs[(wn * 64 + nn * 32 + fr) * LD + kk + fk];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[nn], acc[m][nn], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // ---- epilogue.  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
-    if (tid < BM) As[tid] = (row0 + tid < B0) ? nrm[row0 + tid] : 0.f;
-    if (tid < BN) Bs[tid] = (col0 + tid < B1) ? nrm[B0 + col0 + tid] : 0.f;
+    // ---- epilogue: |a|^2 + |b|^2 - 2 a.b, clamped; entries that cancel are recomputed directly by their wave ----
+    __syncthreads();                                   // every wave is done with the last stage
+    float* An = lds; float* Bn = lds + BM;
+    if (tid < BM) An[tid] = (row0 + tid < B0) ? nrm[row0 + tid] : 0.f;
+    if (tid < BN) Bn[tid] = (col0 + tid < B1) ? nrm[B0 + col0 + tid] : 0.f;
     __syncthreads();
+    constexpr int NT = Core::EU, MT = Core::EM, ER = Core::ER;
+    const int cl = Core::col_lo();
+    const float ny[2] = {Bn[cl], Bn[cl + NT - 1]};
+    const bool pair = NT == 2 && (B1 & 1) == 0 && col0 + cl + 1 < B1;
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-        const int cl = wn * 64 + nn * 32 + (lane & 31);
-        const int gc = col0 + cl;
-        const float ny = Bs[cl];
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int r = 0; r < ER; ++r) {
+            const int rl = Core::row_of(m, r);
+            const int gr = row0 + rl;
+            float v[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * (BM / 2) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int gr = row0 + rl;
-                const float sum = As[rl] + ny;
-                float v = fmaxf(fmaf(-2.f, acc[m][nn][r], sum), 0.f);
+            for (int u = 0; u < NT; ++u) {
+                const int gc = col0 + cl + u;
+                const float sum = An[rl] + ny[u];
+                float x = fmaxf(fmaf(-2.f, g.at(m, u, r), sum), 0.f);
                 const bool ok = gr < B0 && gc < B1;
                 // cancellation: this wave recomputes the entry in the direct form
-                unsigned long long mask = __ballot(ok && v < 0.125f * sum);
+                unsigned long long mask = __ballot(ok && x < 0.125f * sum);
                 while (mask) {
                     const int l = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -390,15 +300,22 @@ __global__ __launch_bounds__(256) void cost_gemm(const float* __restrict__ x0, c
                         p = fmaf(t, t, p);
                     }
                     p = wave_sum_f(p);
-                    if (lane == l) v = p;
+                    if (lane == l) x = p;
                 }
-                if (ok) M[(size_t)gr * B1 + gc] = v;
+                v[u] = x;
+            }
+            if (gr < B0) {
+                float* po = M + (size_t)gr * B1 + col0 + cl;
+                if (pair) *reinterpret_cast<float2*>(po) = make_float2(v[0], v[NT - 1]);
+                else {
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) if (col0 + cl + u < B1) po[u] = v[u];
+                }
             }
         }
     }
 }
 
-// ------------------------------------------------------- max / scale / sqrt --
 __global__ __launch_bounds__(256) void max_reduce_f32(const float* __restrict__ M, size_t n,
                                                       unsigned* __restrict__ out_bits) {
     float m = 0.f;  // costs are >= 0

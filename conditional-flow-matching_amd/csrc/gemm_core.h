@@ -25,14 +25,13 @@
 
 typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gc_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gc_f32x4 __attribute__((ext_vector_type(4)));
 
 template <int ROWS, bool KMAJOR> struct GcLd { static constexpr int value = KMAJOR ? ROWS + 4 : ROWS + 2; };
 
 // One operand of a stage: ROWS x BK floats, element (row, k).  `src(row, k)` addressing:
 //   KMAJOR = false: p[row * ld + k]       KMAJOR = true: p[k * ld + row]
-// rows >= nrows and k >= kend read as zero.  VEC: 16-byte loads (ld % 4 == 0, base 16-byte aligned, and the
-// vector never straddles the valid range because nrows / kend are then multiples of 4 or the tail is masked per
-// element below).
+// rows >= nrows and k >= kend read as zero.  VEC: 16-byte loads (preconditions at fetch()).
 template <int ROWS, int BK, bool KMAJOR, bool VEC>
 struct GcOperand {
     static constexpr int LD = GcLd<ROWS, KMAJOR>::value;
@@ -40,9 +39,15 @@ struct GcOperand {
     static constexpr int NS = ROWS * BK / 256;            // floats per thread and stage (scalar path)
     float4 v[VEC ? NV : 1];
     float s[VEC ? 1 : NS];
+    unsigned okm;            // bit q: element q of this thread lies inside the operand (applied when the registers are
+                             // consumed — stash / sub_k — so that nothing waits for a load right after issuing it)
 
+    // Loads are unconditional from a clamped (always valid) address and zeroed afterwards: no branches in the main
+    // loop.  VEC preconditions (the launchers check them): K-contiguous: ld % 4 == 0, kend % 4 == 0, 16-byte aligned
+    // base; K-major: ld % 4 == 0, nrows % 4 == 0, aligned base — so a vector never straddles the valid range.
     __device__ __forceinline__ void fetch(const float* __restrict__ p, int ld, int row0, int nrows, int k0, int kend) {
         const int tid = threadIdx.x;
+        okm = 0u;
         if (VEC) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
@@ -50,21 +55,10 @@ struct GcOperand {
                 if (!KMAJOR) { k = 4 * (tid % (BK / 4)); r = tid / (BK / 4) + q * (1024 / BK); }
                 else { r = 4 * (tid % (ROWS / 4)); k = tid / (ROWS / 4) + q * (1024 / ROWS); }
                 const int gr = row0 + r, gk = k0 + k;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!KMAJOR) {
-                    if (gr < nrows && gk < kend) {
-                        const float* a = p + (size_t)gr * ld + gk;
-                        if (gk + 3 < kend) x = *reinterpret_cast<const float4*>(a);
-                        else { x.x = a[0]; if (gk + 1 < kend) x.y = a[1]; if (gk + 2 < kend) x.z = a[2]; }
-                    }
-                } else {
-                    if (gk < kend && gr < nrows) {
-                        const float* a = p + (size_t)gk * ld + gr;
-                        if (gr + 3 < nrows) x = *reinterpret_cast<const float4*>(a);
-                        else { x.x = a[0]; if (gr + 1 < nrows) x.y = a[1]; if (gr + 2 < nrows) x.z = a[2]; }
-                    }
-                }
-                v[q] = x;
+                const bool ok = gr < nrows && gk < kend;
+                const int cr = ok ? gr : 0, ck = ok ? gk : 0;
+                v[q] = *reinterpret_cast<const float4*>(KMAJOR ? p + (size_t)ck * ld + cr : p + (size_t)cr * ld + ck);
+                okm |= ok ? (1u << q) : 0u;
             }
         } else {
 #pragma unroll
@@ -73,26 +67,30 @@ struct GcOperand {
                 if (!KMAJOR) { k = tid % BK; r = tid / BK + q * (256 / BK); }
                 else { r = tid % ROWS; k = tid / ROWS + q * (256 / ROWS); }
                 const int gr = row0 + r, gk = k0 + k;
-                s[q] = (gr < nrows && gk < kend) ? (KMAJOR ? p[(size_t)gk * ld + gr] : p[(size_t)gr * ld + gk]) : 0.f;
+                const bool ok = gr < nrows && gk < kend;
+                const int cr = ok ? gr : 0, ck = ok ? gk : 0;
+                s[q] = KMAJOR ? p[(size_t)ck * ld + cr] : p[(size_t)cr * ld + ck];
+                okm |= ok ? (1u << q) : 0u;
             }
         }
     }
 
-    // optional per-k offset (cost_gemm subtracts the common centre mu[k] on the way in)
+    // optional per-k offset (cost_gemm subtracts the common centre mu[k] on the way in): the offsets of the fetched
+    // k slice are loaded here and applied at stash time
+    float4 off4; float off1; bool has_off = false;
     __device__ __forceinline__ void sub_k(const float* __restrict__ mu, int k0, int kend) {
         const int tid = threadIdx.x;
+        has_off = true;
         if (VEC) {
             static_assert(!KMAJOR, "sub_k: K-contiguous operands only");
             const int gk = k0 + 4 * (tid % (BK / 4));
-            float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < kend) { m.x = mu[gk]; if (gk + 1 < kend) m.y = mu[gk + 1]; if (gk + 2 < kend) m.z = mu[gk + 2]; if (gk + 3 < kend) m.w = mu[gk + 3]; }
-#pragma unroll
-            for (int q = 0; q < NV; ++q) { v[q].x -= m.x; v[q].y -= m.y; v[q].z -= m.z; v[q].w -= m.w; }
+            const bool in = gk < kend;                   // kend % 4 == 0 (VEC precondition)
+            off4 = *reinterpret_cast<const float4*>(mu + (in ? gk : 0));
+            if (!in) off4 = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
             const int gk = k0 + tid % BK;
-            const float m = gk < kend ? mu[gk] : 0.f;
-#pragma unroll
-            for (int q = 0; q < NS; ++q) s[q] -= m;
+            off1 = mu[gk < kend ? gk : 0];
+            if (!(gk < kend)) off1 = 0.f;
         }
     }
 
@@ -101,13 +99,16 @@ struct GcOperand {
         if (VEC) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
+                float4 x = v[q];
+                if (has_off) { x.x -= off4.x; x.y -= off4.y; x.z -= off4.z; x.w -= off4.w; }
+                if (!((okm >> q) & 1u)) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!KMAJOR) {
                     const int k = 4 * (tid % (BK / 4)), r = tid / (BK / 4) + q * (1024 / BK);
-                    T[(k + 0) * LD + r] = v[q].x; T[(k + 1) * LD + r] = v[q].y;
-                    T[(k + 2) * LD + r] = v[q].z; T[(k + 3) * LD + r] = v[q].w;
+                    T[(k + 0) * LD + r] = x.x; T[(k + 1) * LD + r] = x.y;
+                    T[(k + 2) * LD + r] = x.z; T[(k + 3) * LD + r] = x.w;
                 } else {
                     const int r = 4 * (tid % (ROWS / 4)), k = tid / (ROWS / 4) + q * (1024 / ROWS);
-                    *reinterpret_cast<float4*>(T + k * LD + r) = v[q];
+                    *reinterpret_cast<float4*>(T + k * LD + r) = x;
                 }
             }
         } else {
@@ -116,7 +117,9 @@ struct GcOperand {
                 int r, k;
                 if (!KMAJOR) { k = tid % BK; r = tid / BK + q * (256 / BK); }
                 else { r = tid % ROWS; k = tid / ROWS + q * (256 / ROWS); }
-                T[k * LD + r] = s[q];
+                float x = s[q];
+                if (has_off) x -= off1;
+                T[k * LD + r] = ((okm >> q) & 1u) ? x : 0.f;
             }
         }
     }
@@ -132,46 +135,117 @@ struct GemmCore {
     static_assert((BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile");
     static_assert(BK % 8 == 0 && (BM * BK) % 1024 == 0 && (BN * BK) % 1024 == 0, "stage");
 
-    gc_f32x16 acc[MT][NT];
+    // 64 x 64 tiles (one 32 x 32 block per wave) run on v_mfma_f32_16x16x4_f32 instead: a 32 x 32 block is then FOUR
+    // independent 16 x 16 accumulators in rotation.  With a single 32x32x2 accumulator every MFMA depends on the
+    // previous one and anything issued between two of them stretches the chain (measured: MFMA-busy 37 %, 51 % of the
+    // wave cycles waiting to issue); same k order, same bits.
+    static constexpr bool M16 = (BM == 64 && BN == 64);
+    static constexpr int EM = M16 ? 2 : MT, EU = M16 ? 2 : NT, ER = M16 ? 4 : 16;   // epilogue: at(m, u, r), m < EM, u < EU, r < ER
+
+    gc_f32x16 acc[M16 ? 1 : MT][M16 ? 1 : NT];
+    gc_f32x4 acc16[2][2];
 
     __device__ __forceinline__ void zero() {
+        if (M16) {
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < NT; ++b)
+                for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) acc16[a][b][r] = 0.f;
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        }
     }
+    __device__ __forceinline__ float at(int m, int u, int r) const { return M16 ? acc16[m][u][r] : acc[M16 ? 0 : m][M16 ? 0 : u][r]; }
 
-    // the MFMAs of one stage
-    __device__ __forceinline__ void compute(const float* __restrict__ As, const float* __restrict__ Bs) {
+    // One K step: the MFMAs of the current stage with, woven between them IN SOURCE ORDER (LDS stores cannot be
+    // moved across LDS loads by the scheduler, so the source order is the issue order), the stores of the next
+    // stage's registers into the other LDS stage and the global loads of the stage after next.  A wave alone on its
+    // SIMD (one 128 x 64 tile per CU at the C3 layer shapes) then spends the step issuing MFMAs back to back: the
+    // stores / loads go out in the 64-cycle shadows of the matrix pipe.  Fragment reads run two k-pair groups ahead
+    // (a group = two k-pairs = one ds_read2 per operand = 2 MT NT MFMAs).
+    template <bool NEXT, typename OA, typename OB, typename Fetch>
+    __device__ __forceinline__ void step(const float* __restrict__ As, const float* __restrict__ Bs,
+                                         float* __restrict__ An, float* __restrict__ Bn, OA& oa, OB& ob, Fetch fetch_next) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         const int wm = wv >> 1, wn = wv & 1;
+        if (M16) {
+            // fragment of a 16x16x4 MFMA: lane -> (row = lane & 15, k = lane >> 4); the wave's 32 rows are interleaved
+            // over the two row blocks (block t owns local rows 2 j + t): one ds_read_b64 per operand and k-quad
+            const int fr = lane & 15, fq = lane >> 4;
+            const float* pa = As + fq * LDA + wm * WM + 2 * fr;
+            const float* pb = Bs + fq * LDB + wn * WN + 2 * fr;
+            constexpr int NQ = BK / 4, NG = NQ / 2;
+            float a[NQ][2], b[NQ][2];
+            auto rd = [&](int q) {
+                const gc_f32x2 ta = *reinterpret_cast<const gc_f32x2*>(pa + 4 * q * LDA); a[q][0] = ta.x; a[q][1] = ta.y;
+                const gc_f32x2 tb = *reinterpret_cast<const gc_f32x2*>(pb + 4 * q * LDB); b[q][0] = tb.x; b[q][1] = tb.y;
+            };
+            auto mm = [&](int q) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn)
+                        acc16[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][m], b[q][nn], acc16[m][nn], 0, 0, 0);
+            };
+            rd(0); rd(1);
+            if (NG > 1) { rd(2); rd(3); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                mm(2 * g);
+                if (NEXT && g == 0) oa.stash(An);
+                if (NEXT && g == 1) ob.stash(Bn);
+                if (NEXT && NG == 1 && g == 0) ob.stash(Bn);
+                if (NEXT && g == (NG > 2 ? 2 : NG - 1)) fetch_next();
+                mm(2 * g + 1);
+                if (g + 2 < NG) { rd(2 * g + 4); rd(2 * g + 5); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         const int fr = lane & 31, fk = lane >> 5;
         const float* pa = As + fk * LDA + wm * WM + (MT == 2 ? 2 * fr : fr);
         const float* pb = Bs + fk * LDB + wn * WN + (NT == 2 ? 2 * fr : fr);
-        float a[2][2], b[2][2];
-        auto rd = [&](int kk, int buf) {
-            if (MT == 2) { const gc_f32x2 t = *reinterpret_cast<const gc_f32x2*>(pa + kk * LDA); a[buf][0] = t.x; a[buf][1] = t.y; }
-            else a[buf][0] = pa[kk * LDA];
-            if (NT == 2) { const gc_f32x2 t = *reinterpret_cast<const gc_f32x2*>(pb + kk * LDB); b[buf][0] = t.x; b[buf][1] = t.y; }
-            else b[buf][0] = pb[kk * LDB];
+        constexpr int NP = BK / 2, NG = NP / 2;
+        float a[NP][2], b[NP][2];
+        auto rd = [&](int q) {
+            if (MT == 2) { const gc_f32x2 t = *reinterpret_cast<const gc_f32x2*>(pa + 2 * q * LDA); a[q][0] = t.x; a[q][1] = t.y; }
+            else { a[q][0] = pa[2 * q * LDA]; a[q][1] = 0.f; }
+            if (NT == 2) { const gc_f32x2 t = *reinterpret_cast<const gc_f32x2*>(pb + 2 * q * LDB); b[q][0] = t.x; b[q][1] = t.y; }
+            else { b[q][0] = pb[2 * q * LDB]; b[q][1] = 0.f; }
         };
-        rd(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int cur = (kk >> 1) & 1;
-            if (kk + 2 < BK) rd(kk + 2, cur ^ 1);
+        auto mm = [&](int q) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m], b[cur][nn], acc[m][nn], 0, 0, 0);
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][m], b[q][nn], acc[m][nn], 0, 0, 0);
+        };
+        rd(0); rd(1);
+        if (NG > 1) { rd(2); rd(3); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            mm(2 * g);
+            if (NEXT && g == 0) oa.stash(An);
+            if (NEXT && g == 1) ob.stash(Bn);
+            if (NEXT && NG == 1 && g == 0) ob.stash(Bn);
+            if (NEXT && g == (NG > 2 ? 2 : NG - 1)) fetch_next();
+            mm(2 * g + 1);
+            if (g + 2 < NG) { rd(2 * g + 4); rd(2 * g + 5); }
+            __builtin_amdgcn_sched_barrier(0);       // the reads of group g + 2 stay in front of the MFMAs of group g + 1
         }
     }
 
     // Main loop over [k_begin, k_end).  pre(opA, opB, k0): hook applied to freshly fetched registers (cost_gemm's
-    // centring); post(As_stage): hook run once per stage after its barrier, before the MFMAs (wgrad's bias sums).
+    // centring); post(As_stage, k0): hook run once per stage after its barrier, before the MFMAs (wgrad's bias sums).
     template <typename Pre, typename Post>
     __device__ __forceinline__ void run(float* __restrict__ lds, const float* __restrict__ A, int lda, int row0, int M,
                                         const float* __restrict__ B, int ldb, int col0, int N, int k_begin, int k_end,
@@ -185,19 +259,21 @@ struct GemmCore {
         oa.stash(As); ob.stash(Bs);
         __syncthreads();
         int st = 0;
-        const bool more = k_begin + BK < k_end;
-        if (more) { oa.fetch(A, lda, row0, M, k_begin + BK, k_end); ob.fetch(B, ldb, col0, N, k_begin + BK, k_end); pre(oa, ob, k_begin + BK); }
+        if (k_begin + BK < k_end) { oa.fetch(A, lda, row0, M, k_begin + BK, k_end); ob.fetch(B, ldb, col0, N, k_begin + BK, k_end); pre(oa, ob, k_begin + BK); }
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-            post(As + st * STAGE_A);
-            compute(As + st * STAGE_A, Bs + st * STAGE_B);
+            float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
+            post(Ac, k0);
             if (k0 + BK < k_end) {
-                oa.stash(As + (st ^ 1) * STAGE_A); ob.stash(Bs + (st ^ 1) * STAGE_B);
+                step<true>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob, [&]() {
+                    if (k0 + 2 * BK < k_end) {
+                        oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end);
+                        pre(oa, ob, k0 + 2 * BK);
+                    }
+                });
                 __syncthreads();
-                if (k0 + 2 * BK < k_end) {
-                    oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end);
-                    pre(oa, ob, k0 + 2 * BK);
-                }
                 st ^= 1;
+            } else {
+                step<false>(Ac, Bc, nullptr, nullptr, oa, ob, []() {});
             }
         }
     }
@@ -205,16 +281,19 @@ struct GemmCore {
     // Epilogue geometry.  C/D layout of the MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     // A lane owns local columns col_lo() (+ 1 when NT == 2: acc[m][0][r], acc[m][1][r] are ADJACENT columns, one
     // 8-byte store) and, for accumulator register r of row block m, local row row_of(m, r).
+    // (16x16x4 mode: col = lane & 15, row = 4 (lane >> 4) + r, both interleaved over the two blocks.)
     __device__ __forceinline__ static int col_lo() {
         const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 1;
+        if (M16) return wn * WN + 2 * (lane & 15);
         return wn * WN + (NT == 2 ? 2 * (lane & 31) : (lane & 31));
     }
     __device__ __forceinline__ static int row_of(int m, int r) {
         const int lane = threadIdx.x & 63, wm = threadIdx.x >> 7;
+        if (M16) return wm * WM + 2 * (4 * (lane >> 4) + r) + m;
         const int rho = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         return wm * WM + (MT == 2 ? 2 * rho + m : rho);
     }
 };
 
 struct GcNoPre { template <typename OA, typename OB> __device__ __forceinline__ void operator()(OA&, OB&, int) const {} };
-struct GcNoPost { __device__ __forceinline__ void operator()(const float*) const {} };
+struct GcNoPost { __device__ __forceinline__ void operator()(const float*, int) const {} };

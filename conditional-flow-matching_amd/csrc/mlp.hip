@@ -10,14 +10,12 @@
 //   * GEMM on v_mfma_f32_32x32x2_f32 — exact fp32 (bitwise an fmaf chain), so
 //     1e-5 parity with the fp32 reference is natural; 157 TFLOP/s peak;
 //   * both operands are K-contiguous in memory (torch.nn.Linear keeps W as
-//     [out, in]) -> "NT" GEMM, k-contiguous LDS rows with odd stride
-//     (conflict-free ds_read_b32 fragments: lane&31 -> row, lane>>5 -> k);
-//   * next K-tile is fetched into registers while the current one feeds the
-//     matrix pipe (issue-early / write-late staging);
+//     [out, in]) -> "NT" GEMM on the shared tile engine (gemm_core.h): K-major LDS
+//     tiles, two stages and one barrier per K step, ds_read_b64 fragments;
 //   * bias + time column + SELU fused into the accumulator epilogue.
 #include "cfm_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "gemm_core.h"
+#include <stdlib.h>
 
 #define SELU_SCALE 1.0507009873554805f
 #define SELU_ALPHA 1.6732632423543772f
@@ -28,7 +26,9 @@ __device__ __forceinline__ float selu_f(float x) {
 
 // X [B,K] (row stride lda), W [N, *] (row stride ldw, first K columns used),
 // out [B,N].  tcol: column index of the time weight inside W rows (ldw > K) or -1.
-template <int BM, int BN, bool ACT>
+// The product runs on the shared tile engine (gemm_core.h): both operands K-contiguous, K-major LDS tiles,
+// double-buffered stages, ds_read_b64 fragments; VEC = 16-byte global loads (rows 16-byte aligned).
+template <int BM, int BN, int BK, bool ACT, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, int lda,
                                                  const float* __restrict__ W, int ldw,
                                                  const float* __restrict__ bias,
@@ -36,91 +36,50 @@ __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, in
                                                  int t_per_row, int tcol, int B, int K, int N,
                                                  float* __restrict__ out, int tiles_n,
                                                  float* __restrict__ zout = nullptr) {
-    constexpr int BK = 32, LD = BK + 1;
-    constexpr int WM = BM / 2, WN = BN / 2;          // per-wave tile (2x2 waves)
-    constexpr int MT = WM / 32, NT = WN / 32;        // 32x32 MFMA tiles per wave
-    constexpr int A_PER = BM * BK / 256, B_PER = BN * BK / 256;   // floats per thread per stage
-    __shared__ float As[BM * LD];
-    __shared__ float Bs[BN * LD];
-
+    using Core = GemmCore<BM, BN, BK, false, false, VECA, VECB>;
+    __shared__ __attribute__((aligned(16))) float lds[Core::LDS_FLOATS];
     const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
     const int tm = lid / tiles_n, tn = lid % tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    float ra[A_PER], rb[B_PER];
-    // element e of a [R x BK] stage: row = e / BK, k = e % BK; thread owns
-    // e = tid + 256*q (consecutive lanes -> consecutive k: coalesced 128-B rows)
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < A_PER; ++q) {
-            const int e = tid + 256 * q, r = e / BK, k = e % BK;
-            const int gr = row0 + r, gk = k0 + k;
-            ra[q] = (gr < B && gk < K) ? X[(size_t)gr * lda + gk] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < B_PER; ++q) {
-            const int e = tid + 256 * q, r = e / BK, k = e % BK;
-            const int gr = col0 + r, gk = k0 + k;
-            rb[q] = (gr < N && gk < K) ? W[(size_t)gr * ldw + gk] : 0.f;
-        }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int q = 0; q < A_PER; ++q) { const int e = tid + 256 * q; As[(e / BK) * LD + (e % BK)] = ra[q]; }
-#pragma unroll
-        for (int q = 0; q < B_PER; ++q) { const int e = tid + 256 * q; Bs[(e / BK) * LD + (e % BK)] = rb[q]; }
-    };
-
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        stash();
-        __syncthreads();
-        if (k0 + BK < K) fetch(k0 + BK);            // in flight while the MFMAs run
-        const int fr = lane & 31, fk = lane >> 5;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[MT], b[NT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = As[(wm * WM + m * 32 + fr) * LD + kk + fk];
-#pragma unroll
-            for (int nn = 0; nn < NT; ++nn) b[nn] = Bs[(wn * WN + nn * 32 + fr) * LD + kk + fk];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int nn = 0; nn < NT; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[nn], acc[m][nn], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    Core g;
+    g.zero();
+    g.run(lds, X, lda, row0, B, W, ldw, col0, N, 0, K, GcNoPre(), GcNoPost());
+    // epilogue: bias + time column + (pre-activation) + SELU; a lane owns EU adjacent columns
+    constexpr int EU = Core::EU, EM = Core::EM, ER = Core::ER;
     const float tsc = (tcol >= 0 && !t_per_row) ? (tptr ? tptr[0] : tval) : 0.f;
+    const int gc = col0 + Core::col_lo();
+    float bv[2] = {0.f, 0.f}, wt[2] = {0.f, 0.f};
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
-        const int gc = col0 + wn * WN + nn * 32 + (lane & 31);
-        if (gc >= N) continue;
-        const float bv = bias ? bias[gc] : 0.f;
-        const float wt = (tcol >= 0) ? W[(size_t)gc * ldw + tcol] : 0.f;
+    for (int u = 0; u < EU; ++u) {
+        if (gc + u < N) {
+            bv[u] = bias ? bias[gc + u] : 0.f;
+            wt[u] = (tcol >= 0) ? W[(size_t)(gc + u) * ldw + tcol] : 0.f;
+        }
+    }
+    const bool pair = EU == 2 && (N & 1) == 0 && gc + 1 < N;       // 8-byte aligned store of both columns
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < EM; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gr = row0 + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (gr >= B) continue;
-                float v = acc[m][nn][r] + bv;
-                if (tcol >= 0) v = fmaf(t_per_row ? tptr[gr] : tsc, wt, v);
-                if (zout) zout[(size_t)gr * N + gc] = v;      // training: the pre-activation (SELU' needs exp(z), not h)
-                if (ACT) v = selu_f(v);
-                out[(size_t)gr * N + gc] = v;
+        for (int r = 0; r < ER; ++r) {
+            const int gr = row0 + Core::row_of(m, r);
+            if (gr >= B || gc >= N) continue;
+            const float tv = (tcol >= 0) ? (t_per_row ? tptr[gr] : tsc) : 0.f;
+            float v[2], z[2];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                float x = g.at(m, u, r) + bv[u];
+                if (tcol >= 0) x = fmaf(tv, wt[u], x);
+                z[u] = x;
+                v[u] = ACT ? selu_f(x) : x;
+            }
+            float* po = out + (size_t)gr * N + gc;
+            if (pair) {
+                *reinterpret_cast<float2*>(po) = make_float2(v[0], v[EU - 1]);
+                if (zout) *reinterpret_cast<float2*>(zout + (size_t)gr * N + gc) = make_float2(z[0], z[EU - 1]);   // training: SELU' needs exp(z), not h
+            } else {
+#pragma unroll
+                for (int u = 0; u < EU; ++u)
+                    if (gc + u < N) { po[u] = v[u]; if (zout) zout[(size_t)gr * N + gc + u] = z[u]; }
             }
         }
     }
@@ -130,21 +89,57 @@ extern "C" size_t cfm_mlp_ws_bytes_internal(int B, int width) {
     return 2 * sizeof(float) * (size_t)B * (size_t)width + 256;
 }
 
-// one layer launch; picks the tile so the grid covers the chip
+// Tile choice of the dense products (shared with mlp_train.hip): 0 = 128 x 128 x 16, 1 = 128 x 64 x 32,
+// 2 = 64 x 64 x 32 — the largest tile that still gives the chip about one workgroup per CU.
+// CFM_GEMM_TILE=0|1|2 forces one (measurement switch: same bits whatever the tile).
+int cfm_gemm_pick_tile(long M, long N, long splits) {
+    static const int forced = [] { const char* e = getenv("CFM_GEMM_TILE"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
+    if (forced >= 0) return forced;
+    // measured at the C3 layer shapes (tools/gemm_bench.py): 128 x 128 needs >= 2 workgroups per CU to pay
+    // (cost matrix: 1024 tiles); below that the 64 x 64 tile (four 16x16x4 accumulators per wave, 2+ workgroups
+    // per CU) beats 128 x 64 at one workgroup per CU
+    const long t0 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
+    if (t0 >= 512) return 0;
+    return 2;
+}
+
+template <bool ACT, bool VECA, bool VECB>
+static void launch_layer_t(int tile, const float* X, int lda, const float* W, int ldw, const float* bias,
+                           const float* t, float tval, int t_per_row, int tcol, int B, int K, int N, float* out,
+                           hipStream_t s, float* zout) {
+    if (tile == 0) {
+        const int tm = (B + 127) / 128, tn = (N + 127) / 128;
+        hipLaunchKernelGGL((mlp_layer<128, 128, 16, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
+    } else if (tile == 1) {
+        const int tm = (B + 127) / 128, tn = (N + 63) / 64;
+        hipLaunchKernelGGL((mlp_layer<128, 64, 32, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
+    } else {
+        const int tm = (B + 63) / 64, tn = (N + 63) / 64;
+        hipLaunchKernelGGL((mlp_layer<64, 64, 32, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
+    }
+}
+
+// one layer launch; picks the tile so the grid covers the chip.  16-byte loads per operand when its rows allow it
+// (K % 4 == 0, row pitch % 4 == 0, aligned base): the 785-wide rows of a time-varying first layer do not.
 static int launch_layer(const float* X, int lda, const float* W, int ldw, const float* bias,
                         const float* t, float tval, int t_per_row, int tcol, int B, int K, int N, float* out,
                         bool act, hipStream_t s, float* zout = nullptr) {
-    const long tiles128 = (long)((B + 127) / 128) * ((N + 127) / 128);
-    if (tiles128 >= 512) {
-        const int tm = (B + 127) / 128, tn = (N + 127) / 128;
-        if (act) hipLaunchKernelGGL((mlp_layer<128, 128, true>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
-        else     hipLaunchKernelGGL((mlp_layer<128, 128, false>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
-    } else {
-        const int tm = (B + 63) / 64, tn = (N + 63) / 64;
-        if (act) hipLaunchKernelGGL((mlp_layer<64, 64, true>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
-        else     hipLaunchKernelGGL((mlp_layer<64, 64, false>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
-    }
+    const int tile = cfm_gemm_pick_tile(B, N, 1);
+    const bool va = (K % 4 == 0) && (lda % 4 == 0) && ((uintptr_t)X & 15) == 0;
+    const bool vb = (K % 4 == 0) && (ldw % 4 == 0) && ((uintptr_t)W & 15) == 0;
+#define CFM_LL(ACT_, VA_, VB_) launch_layer_t<ACT_, VA_, VB_>(tile, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, s, zout)
+    if (act) { if (va) { if (vb) CFM_LL(true, true, true); else CFM_LL(true, true, false); }
+               else    { if (vb) CFM_LL(true, false, true); else CFM_LL(true, false, false); } }
+    else     { if (va) { if (vb) CFM_LL(false, true, true); else CFM_LL(false, true, false); }
+               else    { if (vb) CFM_LL(false, false, true); else CFM_LL(false, false, false); } }
+#undef CFM_LL
     return cfm_status();
+}
+
+// (mlp_train.hip: the fused regression step runs its forward through the same launcher)
+int cfm_mlp_launch_layer(const float* X, int lda, const float* W, int ldw, const float* bias, const float* t,
+                         int t_per_row, int tcol, int B, int K, int N, float* out, bool act, hipStream_t s, float* zout) {
+    return launch_layer(X, lda, W, ldw, bias, t, 0.f, t_per_row, tcol, B, K, N, out, act, s, zout);
 }
 
 // Forward through all layers.  dims[0] counts the time column when the net is

@@ -20,13 +20,11 @@
 //   Adam                 one launch for every parameter tensor of the model (pointer table), torch.optim.Adam
 //                        arithmetic (lerp / addcmul / addcdiv order, bias corrections as Python doubles)
 //
-// All GEMMs are v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak), LDS tiles laid out so that
-// every fragment read is a conflict-free ds_read_b32 whatever the operand's storage order:
-//   operand stored k-contiguous ([row][k], e.g. activations as the A of dgrad): tile [rows][BK + 1]
-//   operand stored k-major      ([k][row], e.g. W as the B of dgrad, both operands of wgrad): tile [BK][rows]
+// All GEMMs are v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak) on the shared tile engine of gemm_core.h:
+// K-major LDS tiles whatever the operand's storage order (k-contiguous operands are transposed on the way in),
+// two stages, ds_read_b64 fragments.
 #include "cfm_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "gemm_core.h"
 
 #define SELU_SCALE 1.0507009873554805f
 #define SELU_ALPHA 1.6732632423543772f
@@ -38,123 +36,86 @@ __device__ __forceinline__ float selu_grad(float z) {
 
 enum { EPI_PLAIN = 0, EPI_SELU_GRAD = 1 };
 
-// C[M,N] (+ epilogue) = A[M,Kc] . B[Kc,N], contraction over [k_begin, k_end) of this workgroup's split.
+// C[M,N] (+ epilogue) = A[M,Kc] . B[Kc,N], contraction over [k_begin, k_end) of this workgroup's split, on the
+// shared tile engine (gemm_core.h).
 //   A_KMAJOR = false: A(i,k) = A[i * lda + k]      true: A(i,k) = A[k * lda + i]
 //   B_KMAJOR = false: B(k,j) = Bm[j * ldb + k]     true: B(k,j) = Bm[k * ldb + j]
 // grid: x = tiles_m * tiles_n (XCD-remapped), y = split index s; split s writes C + s * split_stride.
-template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR, int EPI>
+template <int BM, int BN, int BK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A, int lda,
                                                      const float* __restrict__ Bm, int ldb,
                                                      float* __restrict__ C, int ldc, size_t split_stride,
                                                      const float* __restrict__ H,     // EPI_SELU_GRAD: pre-activations [M, ldc]
                                                      int M, int N, int Kc, int k_chunk, int tiles_n,
-                                                     float* __restrict__ colsum = nullptr) {   // A_KMAJOR: sum_k A(i, k) per split -> colsum[s * M + i]
-    constexpr int BK = 32;
-    constexpr int LDA = A_KMAJOR ? BM : BK + 1, LDB = B_KMAJOR ? BN : BK + 1;
-    constexpr int WM = BM / 2, WN = BN / 2;          // per-wave tile (2x2 waves)
-    constexpr int MT = WM / 32, NT = WN / 32;        // 32x32 MFMA tiles per wave
-    constexpr int A_PER = BM * BK / 256, B_PER = BN * BK / 256;
-    __shared__ float As[A_KMAJOR ? BK * LDA : BM * LDA];
-    __shared__ float Bs[B_KMAJOR ? BK * LDB : BN * LDB];
-
+                                                     float* __restrict__ colsum = nullptr,     // A_KMAJOR: sum_k A(i, k) per split -> colsum[s * M + i]
+                                                     const float* __restrict__ tvec = nullptr, // A_KMAJOR: weights t[k] of a second column sum
+                                                     float* __restrict__ tsum = nullptr) {     //   sum_k A(i, k) t[k] per split -> tsum[s * M + i]
+    using Core = GemmCore<BM, BN, BK, A_KMAJOR, B_KMAJOR, VECA, VECB>;
+    __shared__ __attribute__((aligned(16))) float lds[Core::LDS_FLOATS];
     const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
     const int tm = lid / tiles_n, tn = lid % tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
+    const int tid = threadIdx.x;
     const int k_begin = blockIdx.y * k_chunk;
     const int k_end = (k_begin + k_chunk < Kc) ? k_begin + k_chunk : Kc;
 
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    float ra[A_PER], rb[B_PER];
-    // thread owns elements e = tid + 256 q of a stage; consecutive lanes walk the operand's contiguous
-    // dimension (coalesced global rows) and consecutive LDS addresses
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < A_PER; ++q) {
-            const int e = tid + 256 * q;
-            const int r = A_KMAJOR ? e % BM : e / BK, k = A_KMAJOR ? e / BM : e % BK;
-            const int gr = row0 + r, gk = k0 + k;
-            ra[q] = (gr < M && gk < k_end) ? (A_KMAJOR ? A[(size_t)gk * lda + gr] : A[(size_t)gr * lda + gk]) : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < B_PER; ++q) {
-            const int e = tid + 256 * q;
-            const int r = B_KMAJOR ? e % BN : e / BK, k = B_KMAJOR ? e / BN : e % BK;
-            const int gc = col0 + r, gk = k0 + k;
-            rb[q] = (gc < N && gk < k_end) ? (B_KMAJOR ? Bm[(size_t)gk * ldb + gc] : Bm[(size_t)gc * ldb + gk]) : 0.f;
-        }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int q = 0; q < A_PER; ++q) {
-            const int e = tid + 256 * q;
-            if (A_KMAJOR) As[(e / BM) * LDA + (e % BM)] = ra[q]; else As[(e / BK) * LDA + (e % BK)] = ra[q];
-        }
-#pragma unroll
-        for (int q = 0; q < B_PER; ++q) {
-            const int e = tid + 256 * q;
-            if (B_KMAJOR) Bs[(e / BN) * LDB + (e % BN)] = rb[q]; else Bs[(e / BK) * LDB + (e % BK)] = rb[q];
-        }
-    };
-
-    // bias gradient rides along: the workgroups of the first tile column add up their A tile (dz) over k
+    // bias gradient rides along: the workgroups of the first tile column add up their A tile (dz) over k, from the
+    // K-major LDS stage every step (same ascending-k order as before)
+    // (the time column of a time-varying first layer is not part of the GEMM operand: its gradient
+    //  dW[:, d] = sum_b dz[b, :] t[b] is a second, weighted column sum of the same tile)
     const bool do_colsum = A_KMAJOR && colsum != nullptr && tn == 0 && tid < BM;
-    float csum = 0.f;
-    if (k_begin < k_end) fetch(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        stash();
-        __syncthreads();
-        if (k0 + BK < k_end) fetch(k0 + BK);            // in flight while the MFMAs run
+    const bool do_tsum = do_colsum && tvec != nullptr && tsum != nullptr;
+    float csum = 0.f, wsum = 0.f;
+    auto post = [&](const float* As, int k0) {
         if (A_KMAJOR && do_colsum) {
+            if (do_tsum) {
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDA + tid];
-        }
-        const int fr = lane & 31, fk = lane >> 5;
+                for (int kk = 0; kk < BK; ++kk) {
+                    const float a = As[kk * Core::LDA + tid];
+                    csum += a;
+                    wsum = fmaf(a, (k0 + kk < k_end) ? tvec[k0 + kk] : 0.f, wsum);
+                }
+            } else {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[MT], b[NT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int i = wm * WM + m * 32 + fr;
-                a[m] = A_KMAJOR ? As[(kk + fk) * LDA + i] : As[i * LDA + kk + fk];
+                for (int kk = 0; kk < BK; ++kk) csum += As[kk * Core::LDA + tid];
             }
-#pragma unroll
-            for (int nn = 0; nn < NT; ++nn) {
-                const int j = wn * WN + nn * 32 + fr;
-                b[nn] = B_KMAJOR ? Bs[(kk + fk) * LDB + j] : Bs[j * LDB + kk + fk];
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int nn = 0; nn < NT; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[nn], acc[m][nn], 0, 0, 0);
         }
-        __syncthreads();
+    };
+    Core g;
+    g.zero();
+    g.run(lds, A, lda, row0, M, Bm, ldb, col0, N, k_begin, k_end, GcNoPre(), post);
+    if (A_KMAJOR && do_colsum && row0 + tid < M) {
+        colsum[(size_t)blockIdx.y * M + row0 + tid] = csum;
+        if (do_tsum) tsum[(size_t)blockIdx.y * M + row0 + tid] = wsum;
     }
-    if (A_KMAJOR && do_colsum && row0 + tid < M) colsum[(size_t)blockIdx.y * M + row0 + tid] = csum;
-    // epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+
+    constexpr int EU = Core::EU, EM = Core::EM, ER = Core::ER;
     float* Cs = C + (size_t)blockIdx.y * split_stride;
+    const int gc = col0 + Core::col_lo();
+    const bool pair = EU == 2 && (ldc & 1) == 0 && gc + 1 < N;
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
-        const int gc = col0 + wn * WN + nn * 32 + (lane & 31);
-        if (gc >= N) continue;
+    for (int m = 0; m < EM; ++m) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int r = 0; r < ER; ++r) {
+            const int gr = row0 + Core::row_of(m, r);
+            if (gr >= M || gc >= N) continue;
+            float v[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gr = row0 + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (gr >= M) continue;
-                float v = acc[m][nn][r];
-                if (EPI == EPI_SELU_GRAD) v *= selu_grad(H[(size_t)gr * ldc + gc]);
-                Cs[(size_t)gr * ldc + gc] = v;
+            for (int u = 0; u < EU; ++u) v[u] = g.at(m, u, r);
+            if (EPI == EPI_SELU_GRAD) {
+                if (pair) {
+                    const float2 h = *reinterpret_cast<const float2*>(H + (size_t)gr * ldc + gc);
+                    v[0] *= selu_grad(h.x); v[EU - 1] *= selu_grad(h.y);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < EU; ++u) if (gc + u < N) v[u] *= selu_grad(H[(size_t)gr * ldc + gc + u]);
+                }
+            }
+            float* po = Cs + (size_t)gr * ldc + gc;
+            if (pair) *reinterpret_cast<float2*>(po) = make_float2(v[0], v[EU - 1]);
+            else {
+#pragma unroll
+                for (int u = 0; u < EU; ++u) if (gc + u < N) po[u] = v[u];
             }
         }
     }
@@ -162,9 +123,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
 
 // out[e] = sum_s partial[s * stride + e] in split order (deterministic), for every tensor of the table
 // (all weight and bias gradients of a backward pass in ONE launch)
-struct ReduceJob { const float* partial; float* out; unsigned long long stride, n; int S, pad; };
+struct ReduceJob { const float* partial; float* out; unsigned long long stride, n; int S, cols, ld_out, pad; };   // cols > 0: out[(e / cols) * ld_out + e % cols]
 #define MLP_MAX_LAYERS 16
-struct ReduceTable { ReduceJob job[2 * MLP_MAX_LAYERS]; int count; };
+struct ReduceTable { ReduceJob job[2 * MLP_MAX_LAYERS + 2]; int count; };
 
 __global__ __launch_bounds__(256) void reduce_splits_multi(ReduceTable T) {
     for (int q = blockIdx.y; q < T.count; q += gridDim.y) {
@@ -172,7 +133,8 @@ __global__ __launch_bounds__(256) void reduce_splits_multi(ReduceTable T) {
         for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < J.n; e += (size_t)gridDim.x * 256) {
             float v = J.partial[e];
             for (int s = 1; s < J.S; ++s) v += J.partial[(size_t)s * J.stride + e];
-            J.out[e] = v;
+            if (J.cols > 0) J.out[(e / (unsigned)J.cols) * (size_t)J.ld_out + (e % (unsigned)J.cols)] = v;
+            else J.out[e] = v;
         }
     }
 }
@@ -181,24 +143,48 @@ __global__ __launch_bounds__(256) void reduce_splits_multi(ReduceTable T) {
 extern "C" size_t cfm_mlp_train_ws_bytes_internal(int B, int maxw, int max_params) {
     // two [B, maxw] gradient buffers + per-layer split-K partials (weights and biases; <= MLP_MAX_LAYERS layers
     // are sized here by the largest one: callers pass the largest dims[l] * dims[l+1])
-    return sizeof(float) * ((size_t)2 * B * maxw + (size_t)MLP_MAX_SPLITS * ((size_t)max_params + maxw) * 4) + 1024;
+    // (+ 1 KiB of loss partials for cfm_mlp_regression_step_f32, + slack)
+    return sizeof(float) * ((size_t)2 * B * maxw + (size_t)MLP_MAX_SPLITS * ((size_t)max_params + maxw) * 4) + 2048;
+}
+
+int cfm_gemm_pick_tile(long M, long N, long splits);      // mlp.hip
+int cfm_mlp_launch_layer(const float* X, int lda, const float* W, int ldw, const float* bias, const float* t,
+                         int t_per_row, int tcol, int B, int K, int N, float* out, bool act, hipStream_t s, float* zout);
+
+template <bool AK, bool BK_, int EPI, bool VA, bool VB>
+static void launch_gemm_t(int tile, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, size_t split_stride,
+                          const float* H, int M, int N, int Kc, int k_chunk, int S, hipStream_t s, float* colsum,
+                          const float* tvec, float* tsum) {
+    if (tile == 0) {
+        const int tm = (M + 127) / 128, tn = (N + 127) / 128;
+        hipLaunchKernelGGL((gemm_f32_mfma<128, 128, 16, AK, BK_, EPI, VA, VB>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
+                           split_stride, H, M, N, Kc, k_chunk, tn, colsum, tvec, tsum);
+    } else if (tile == 1) {
+        const int tm = (M + 127) / 128, tn = (N + 63) / 64;
+        hipLaunchKernelGGL((gemm_f32_mfma<128, 64, 32, AK, BK_, EPI, VA, VB>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
+                           split_stride, H, M, N, Kc, k_chunk, tn, colsum, tvec, tsum);
+    } else {
+        const int tm = (M + 63) / 64, tn = (N + 63) / 64;
+        hipLaunchKernelGGL((gemm_f32_mfma<64, 64, 32, AK, BK_, EPI, VA, VB>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
+                           split_stride, H, M, N, Kc, k_chunk, tn, colsum, tvec, tsum);
+    }
 }
 
 template <bool AK, bool BK_, int EPI>
 static int launch_gemm(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, size_t split_stride,
-                       const float* H, int M, int N, int Kc, int S, hipStream_t s, float* colsum = nullptr) {
+                       const float* H, int M, int N, int Kc, int S, hipStream_t s, float* colsum = nullptr,
+                       const float* tvec = nullptr, float* tsum = nullptr) {
     int k_chunk = (Kc + S - 1) / S;
     k_chunk = (k_chunk + 31) / 32 * 32;
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (t128 * S >= 192) {
-        const int tm = (M + 127) / 128, tn = (N + 127) / 128;
-        hipLaunchKernelGGL((gemm_f32_mfma<128, 128, AK, BK_, EPI>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
-                           split_stride, H, M, N, Kc, k_chunk, tn, colsum);
-    } else {
-        const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-        hipLaunchKernelGGL((gemm_f32_mfma<64, 64, AK, BK_, EPI>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
-                           split_stride, H, M, N, Kc, k_chunk, tn, colsum);
-    }
+    const int tile = cfm_gemm_pick_tile(M, N, S);
+    // 16-byte loads per operand: K-contiguous needs Kc % 4 == 0 (k_chunk is a multiple of 32), K-major needs the row
+    // extent % 4 == 0; both need the pitch % 4 == 0 and an aligned base
+    const bool va = (lda % 4 == 0) && ((uintptr_t)A & 15) == 0 && ((AK ? M : Kc) % 4 == 0);
+    const bool vb = (ldb % 4 == 0) && ((uintptr_t)Bm & 15) == 0 && ((BK_ ? N : Kc) % 4 == 0);
+#define CFM_LG(VA_, VB_) launch_gemm_t<AK, BK_, EPI, VA_, VB_>(tile, A, lda, Bm, ldb, C, ldc, split_stride, H, M, N, Kc, k_chunk, S, s, colsum, tvec, tsum)
+    if (va) { if (vb) CFM_LG(true, true); else CFM_LG(true, false); }
+    else    { if (vb) CFM_LG(false, true); else CFM_LG(false, false); }
+#undef CFM_LG
     return cfm_status();
 }
 
@@ -207,13 +193,13 @@ static int launch_gemm(const float* A, int lda, const float* Bm, int ldb, float*
 // Writes dW[l] ([dims[l+1], dims[l]]), db[l] and, if dx is not NULL, the input gradient [B, dims[0]].
 // Launches: per layer one wgrad (bias column sums ride along) and one dgrad, then ONE reduction of every
 // split-K partial (weights and biases of all layers).
-extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const* preact, const float* const* W,
-                                    const int* dims, int n_layers, int B, const float* dout, float* const* dW,
-                                    float* const* db, float* dx, void* ws, void* stream) {
-    if (!acts || !W || !dims || !dout || !dW || !db || n_layers < 1 || n_layers > MLP_MAX_LAYERS || B < 0 || !ws) return CFM_EINVAL;
-    if (n_layers > 1 && !preact) return CFM_EINVAL;
-    if (B == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
+// tvec != NULL: the network input is [acts[0] (B x dims[0] - 1, pitch dims[0] - 1), tvec (B)] — the time column is
+// kept apart (the fused regression step never concatenates it); its weight gradient is the weighted column sum.
+// extra: one more job for the final reduction (the loss partials of the fused step), or NULL.
+static int mlp_backward_impl(const float* const* acts, const float* const* preact, const float* const* W,
+                             const int* dims, int n_layers, int B, const float* dout, float* const* dW,
+                             float* const* db, float* dx, void* ws, hipStream_t s, const float* tvec,
+                             const ReduceJob* extra) {
     int maxw = 0; size_t maxp = 0;
     for (int l = 0; l <= n_layers; ++l) maxw = dims[l] > maxw ? dims[l] : maxw;
     for (int l = 0; l < n_layers; ++l) { const size_t p = (size_t)dims[l] * dims[l + 1]; maxp = p > maxp ? p : maxp; }
@@ -224,19 +210,25 @@ extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const
     ReduceTable T; T.count = 0;
     const float* dz = dout;
     for (int l = n_layers - 1; l >= 0; --l) {
-        const int K = dims[l], N = dims[l + 1];
+        const bool split_t = (l == 0 && tvec != nullptr);
+        const int Kfull = dims[l], N = dims[l + 1];
+        const int K = split_t ? Kfull - 1 : Kfull;            // columns of the GEMM operand
         // wgrad: dW[N,K] = dz^T[N,B] . h[B,K], contraction over the batch, S splits; db partials ride along
         const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
         int S = 1;
         while (S < MLP_MAX_SPLITS && tiles * S < 256 && B / (2 * S) >= 64) S *= 2;
         const size_t np = (size_t)N * K;
-        if (used + (size_t)S * (np + N) > pool_floats) return CFM_EINVAL;      // more layers than the workspace was sized for
+        if (used + (size_t)S * (np + 2 * (size_t)N) > pool_floats) return CFM_EINVAL;      // more layers than the workspace was sized for
         float* part = pool + used; used += (size_t)S * np;
         float* bpart = pool + used; used += (size_t)S * N;
-        int rc = launch_gemm<true, true, EPI_PLAIN>(dz, N, acts[l], K, part, K, np, nullptr, N, K, B, S, s, bpart);
+        float* tpart = nullptr;
+        if (split_t) { tpart = pool + used; used += (size_t)S * N; }
+        int rc = launch_gemm<true, true, EPI_PLAIN>(dz, N, acts[l], K, part, K, np, nullptr, N, K, B, S, s, bpart,
+                                                    split_t ? tvec : nullptr, tpart);
         if (rc) return rc;
-        T.job[T.count++] = ReduceJob{part, dW[l], np, np, S, 0};
-        T.job[T.count++] = ReduceJob{bpart, db[l], (unsigned long long)N, (unsigned long long)N, S, 0};
+        T.job[T.count++] = ReduceJob{part, dW[l], np, np, S, split_t ? K : 0, Kfull, 0};
+        T.job[T.count++] = ReduceJob{bpart, db[l], (unsigned long long)N, (unsigned long long)N, S, 0, 0, 0};
+        if (split_t) T.job[T.count++] = ReduceJob{tpart, dW[l] + K, (unsigned long long)N, (unsigned long long)N, S, 1, Kfull, 0};
         // dgrad: dz_prev[B,K] = (dz[B,N] . W[N,K]) * selu'(z_prev)
         if (l > 0) {
             float* dst = gbuf[l & 1];
@@ -244,12 +236,95 @@ extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const
             if (rc) return rc;
             dz = dst;
         } else if (dx) {
-            rc = launch_gemm<false, true, EPI_PLAIN>(dz, N, W[0], K, dx, K, 0, nullptr, B, K, N, 1, s);
+            rc = launch_gemm<false, true, EPI_PLAIN>(dz, N, W[0], Kfull, dx, Kfull, 0, nullptr, B, Kfull, N, 1, s);
             if (rc) return rc;
         }
     }
+    if (extra) T.job[T.count++] = *extra;
     hipLaunchKernelGGL(reduce_splits_multi, dim3(256, T.count), dim3(256), 0, s, T);
     return cfm_status();
+}
+
+extern "C" int cfm_mlp_backward_f32(const float* const* acts, const float* const* preact, const float* const* W,
+                                    const int* dims, int n_layers, int B, const float* dout, float* const* dW,
+                                    float* const* db, float* dx, void* ws, void* stream) {
+    if (!acts || !W || !dims || !dout || !dW || !db || n_layers < 1 || n_layers > MLP_MAX_LAYERS - 1 || B < 0 || !ws) return CFM_EINVAL;
+    if (n_layers > 1 && !preact) return CFM_EINVAL;
+    if (B == 0) return 0;
+    return mlp_backward_impl(acts, preact, W, dims, n_layers, B, dout, dW, db, dx, ws, (hipStream_t)stream, nullptr, nullptr);
+}
+
+// ------------------------------------------------------- fused regression step ----
+// g = (2 / n) (v - u) in place of v, and the partial sums of (v - u)^2 (one per workgroup, summed in block order by
+// the backward's final reduction: deterministic)
+#define MSE_BLOCKS 256
+__global__ __launch_bounds__(256) void mse_grad(float* __restrict__ v, const float* __restrict__ u, size_t n, float scale,
+                                                float inv_n, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
+        float4 a = reinterpret_cast<float4*>(v)[e];
+        const float4 b = reinterpret_cast<const float4*>(u)[e];
+        a.x -= b.x; a.y -= b.y; a.z -= b.z; a.w -= b.w;
+        acc = fmaf(a.x, a.x, acc); acc = fmaf(a.y, a.y, acc); acc = fmaf(a.z, a.z, acc); acc = fmaf(a.w, a.w, acc);
+        a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+        reinterpret_cast<float4*>(v)[e] = a;
+    }
+    if (blockIdx.x == 0)
+        for (size_t e = n4 * 4 + threadIdx.x; e < n; e += 256) { const float d = v[e] - u[e]; acc = fmaf(d, d, acc); v[e] = d * scale; }
+    acc = wave_sum_f(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) * inv_n;
+}
+
+// One regression step of the vector field on a coupled batch, everything but the optimizer update:
+//     v = net([xt, t]);  loss = mean((v - ut)^2);  dW, db = d loss / d parameters
+// — what `vt = model(torch.cat([xt, t[:, None]], -1)); loss = torch.mean((vt - ut) ** 2); loss.backward()` does in the
+// reference's loops (examples/images/cifar10/train_cifar10.py:147-149, every 2D tutorial).  t == NULL: the net is
+// not time varying (dims[0] = columns of xt); otherwise dims[0] = columns of xt + 1 and the time column is never
+// materialised: forward adds its rank-1 term in the first layer's epilogue, backward takes its weight gradient
+// as a weighted column sum.  g [B, dims[n]] receives d loss / d v (the caller may ignore it); *loss a device float.
+// 13 launches for the 4-layer field, all kernels of this library (no eager elementwise ops in between).
+extern "C" int cfm_mlp_regression_step_f32(const float* xt, const float* t, const float* ut,
+                                           const float* const* W, const float* const* b, const int* dims, int n_layers,
+                                           int B, float* const* hidden, float* const* preact, float* g,
+                                           float* const* dW, float* const* db, float* loss, void* ws, void* stream) {
+    if (!xt || !ut || !W || !b || !dims || !g || !dW || !db || !loss || !ws || n_layers < 1 || n_layers > MLP_MAX_LAYERS - 1 || B < 1)
+        return CFM_EINVAL;
+    if (n_layers > 1 && (!hidden || !preact)) return CFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int has_t = t != nullptr;
+    if (has_t && dims[0] < 2) return CFM_EINVAL;
+    // forward, keeping h_l and z_l
+    const float* cur = xt;
+    for (int l = 0; l < n_layers; ++l) {
+        const bool last = (l == n_layers - 1);
+        const bool first_t = (l == 0 && has_t);
+        const int K = first_t ? dims[0] - 1 : dims[l];
+        float* dst = last ? g : hidden[l];
+        int rc = cfm_mlp_launch_layer(cur, K, W[l], dims[l], b[l], first_t ? t : nullptr, first_t ? 1 : 0, first_t ? K : -1,
+                                      B, K, dims[l + 1], dst, !last, s, last ? nullptr : preact[l]);
+        if (rc) return rc;
+        cur = dst;
+    }
+    // loss + its gradient seed
+    int maxw = 0; size_t maxp = 0;
+    for (int l = 0; l <= n_layers; ++l) maxw = dims[l] > maxw ? dims[l] : maxw;
+    for (int l = 0; l < n_layers; ++l) { const size_t p = (size_t)dims[l] * dims[l + 1]; maxp = p > maxp ? p : maxp; }
+    float* lpart = (float*)((char*)ws + cfm_mlp_train_ws_bytes_internal(B, maxw, (int)maxp) - 2048);   // MSE_BLOCKS floats
+    const size_t nel = (size_t)B * dims[n_layers];
+    const float inv_n = 1.0f / (float)nel;
+    hipLaunchKernelGGL(mse_grad, dim3(MSE_BLOCKS), dim3(256), 0, s, g, ut, nel, 2.0f * inv_n, inv_n, lpart);
+    int rc = cfm_status();
+    if (rc) return rc;
+    // backward (+ the loss partials in its final reduction)
+    const float* acts[MLP_MAX_LAYERS]; const float* zs[MLP_MAX_LAYERS];
+    acts[0] = xt; zs[0] = nullptr;
+    for (int l = 1; l < n_layers; ++l) { acts[l] = hidden[l - 1]; zs[l] = preact[l - 1]; }
+    const ReduceJob lj = ReduceJob{lpart, loss, 1ull, 1ull, MSE_BLOCKS, 0, 0, 0};
+    return mlp_backward_impl(acts, zs, W, dims, n_layers, B, g, dW, db, nullptr, ws, s, has_t ? t : nullptr, &lj);
 }
 
 // ------------------------------------------------------------------- Adam ----

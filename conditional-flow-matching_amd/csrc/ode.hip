@@ -769,6 +769,125 @@ static int ode_dopri5_small(const float* const* W, const float* const* b, const 
     return cur.done && cur.pad == 0 ? 0 : CFM_ENOCONV;
 }
 
+// ------------------------------------------------------------ SF2M: Euler-Maruyama ----
+// y <- y + h (v(te, y) + s(te, y)) + g sqrt|h| xi  for every step of the grid, the whole trajectory of a tile in ONE
+// launch: both small fields (flow v and score s: 4 layers, widths <= 64) live in LDS (2 x 69 KB), the state in
+// registers.  Same arithmetic, in the same order, as the launch-per-step scheme (sde.py: two forward passes on
+// mlp_layer + cfm_sde_em_step_f32: f = fma(1, s, +-v); r = fma(h, f, y); r = fma(g sqrt|h|, xi, r)) — with the
+// caller's noise (xi != NULL) the trajectory is bit-equal to it.  xi == NULL: N(0, 1) from Philox4x32-10 in the
+// kernel (counter = step, element index; key = seed), Box-Muller.
+// Replaces torchsde.sdeint(SDE(model, score_model), x0, ts, method="euler", dt=...) of SF2M_tutorial.ipynb cell 5 and
+// runner/src/models/components/solver.py:157-182 for the small fields those examples train.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned step, unsigned long long elem, float (&z)[4]) {
+    unsigned c[4] = {(unsigned)elem, (unsigned)(elem >> 32), step, 0x5f2du};
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    // Box-Muller on (0, 1] uniforms
+    const float u0 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2] >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u1, &s0, &c0); sincosf(6.283185307179586f * u3, &s1, &c1);
+    z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+}
+
+struct EmStep { float te, h, gs; int is_out; };      // per step: field time, step, g sqrt|h|, trajectory point after it
+
+__global__ __launch_bounds__(256) void ode_small_em(SmArgs F, SmArgs S, int has_s, int B, int d,
+                                                    const EmStep* __restrict__ steps, int n_steps, int reverse,
+                                                    const float* __restrict__ xi, unsigned long long seed,
+                                                    const float* __restrict__ y0, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float small_lds[];
+    float* WlF = small_lds;
+    float* blF = WlF + 4 * SM_W * SM_LD;
+    float* wtF = blF + 4 * SM_W;
+    float* WlS = wtF + SM_W;
+    float* blS = WlS + 4 * SM_W * SM_LD;
+    float* wtS = blS + 4 * SM_W;
+    float* Ab0 = wtS + SM_W;
+    float* Ab1 = Ab0 + SM_ROWS * SM_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    sm_stage_weights(F, d, WlF, blF, wtF, tid);
+    if (has_s) sm_stage_weights(S, d, WlS, blS, wtS, tid);
+    const size_t n = (size_t)B * d;
+    const int col = wv * 16 + (lane & 15);
+    for (int row0 = blockIdx.x * SM_ROWS; row0 < B; row0 += gridDim.x * SM_ROWS) {
+        SmTile x;
+#pragma unroll
+        for (int i = 0; i < SM_V; ++i) {
+            const int gr = row0 + sm_row(i, lane);
+            x.v[i] = (gr < B && col < d) ? y0[(size_t)gr * d + col] : 0.f;
+        }
+        __syncthreads();
+        int oidx = 0;
+        for (int k = 0; k < n_steps; ++k) {
+            const EmStep st = steps[k];
+            const SmTile v = sm_field(x, st.te, F, d, Ab0, Ab1, WlF, blF, wtF, wv, lane);
+            SmTile sc;
+            if (has_s) sc = sm_field(x, st.te, S, d, Ab0, Ab1, WlS, blS, wtS, wv, lane);
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!xi && st.gs != 0.f) philox_normal4(seed, (unsigned)k, (unsigned long long)(row0 / SM_ROWS) * 256 + tid, z);
+#pragma unroll
+            for (int i = 0; i < SM_V; ++i) {
+                const int gr = row0 + sm_row(i, lane);
+                const bool ok = gr < B && col < d;
+                float f = reverse ? -v.v[i] : v.v[i];
+                if (has_s) f = fmaf(1.0f, sc.v[i], f);
+                float r = fmaf(st.h, f, x.v[i]);
+                const float noise = xi ? (ok ? xi[(size_t)k * n + (size_t)gr * d + col] : 0.f) : z[i & 3];
+                r = fmaf(st.gs, noise, r);
+                x.v[i] = ok ? r : 0.f;
+                if (st.is_out && ok) out[(size_t)oidx * n + (size_t)gr * d + col] = r;
+            }
+            oidx += st.is_out ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+// steps_host: n_steps records {te, h, g sqrt|h|, is_out} (host); ws: >= 16 n_steps bytes of device scratch.
+// Ws == NULL: no score field.  Returns CFM_EINVAL for anything but two 4-layer fields of widths <= 64 with a time
+// column (the caller then steps launch by launch).
+extern "C" int cfm_sde_em_mlp_f32(const float* const* Wf, const float* const* bf, const float* const* Ws,
+                                  const float* const* bs, const int* dims, int n_layers, const float* y0, int B,
+                                  const void* steps_host, int n_steps, int reverse, const float* xi,
+                                  unsigned long long seed, float* out, void* ws, void* stream) {
+    if (!Wf || !bf || !dims || !y0 || !out || !steps_host || !ws || B < 0 || n_steps < 0) return CFM_EINVAL;
+    if (n_layers != 4) return CFM_EINVAL;
+    const int d = dims[4];
+    if (dims[0] != d + 1 || d > SM_W) return CFM_EINVAL;
+    for (int l = 1; l <= 3; ++l) if (dims[l] > SM_W || dims[l] < 1) return CFM_EINVAL;
+    if (B == 0 || n_steps == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    SmArgs F, S;
+    for (int l = 0; l < 4; ++l) { F.W[l] = Wf[l]; F.b[l] = bf[l]; S.W[l] = Ws ? Ws[l] : Wf[l]; S.b[l] = bs ? bs[l] : bf[l]; }
+    for (int l = 0; l < 5; ++l) { F.dims[l] = dims[l]; S.dims[l] = dims[l]; }
+    const size_t lds = sizeof(float) * (2 * (4 * SM_W * SM_LD + 4 * SM_W + SM_W) + 2 * SM_ROWS * SM_LD);
+    static int raised_d[CFM_MAX_DEVICES];
+    static std::once_flag once_d[CFM_MAX_DEVICES];
+    const int dvi = cfm_device_index();
+    int& raised = raised_d[dvi];
+    std::call_once(once_d[dvi], [&raised] {
+        hipError_t e = hipFuncSetAttribute((const void*)ode_small_em, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        raised = (e == hipSuccess) ? 1 : -1;
+    });
+    if (raised < 0) return CFM_EINVAL;
+    int rc = cfm_hip(hipMemcpyAsync(ws, steps_host, sizeof(EmStep) * (size_t)n_steps, hipMemcpyHostToDevice, s));
+    if (rc) return rc;
+    const int tiles = (B + SM_ROWS - 1) / SM_ROWS;
+    hipLaunchKernelGGL(ode_small_em, dim3(tiles < 4096 ? tiles : 4096), dim3(256), lds, s, F, S, (Ws && bs) ? 1 : 0, B, d,
+                       (const EmStep*)ws, n_steps, reverse, xi, seed, y0, out);
+    return cfm_status();
+}
+
 // Fixed-step Euler for the same small fields: x_{k+1} = x_k + dt_k f(t_k, x_k), every step of the
 // tile inside one launch (same arithmetic as ode_combine: fmaf(dt, 1.f * k, x)).
 __global__ __launch_bounds__(256) void ode_small_euler(SmArgs A, int B, int d, const float* __restrict__ tspan, int n_t,

@@ -57,11 +57,33 @@ def _grid(ts, dt):
     return steps
 
 
+def _fused_fields(sde):
+    """(drift, score) as two 4-layer time-varying MLPs of widths <= 64 with identical layer sizes, or None."""
+    f, s = sde.drift, sde.score
+    if not (isinstance(f, MLP) and isinstance(s, MLP) and f.time_varying and s.time_varying):
+        return None
+    lf, ls = f._linears(), s._linears()
+    df = [lf[0].in_features] + [l.out_features for l in lf]
+    ds = [ls[0].in_features] + [l.out_features for l in ls]
+    if len(lf) != 4 or df != ds or max(df[1:]) > 64 or df[0] != df[4] + 1:
+        return None
+    return f, s, df
+
+
 @torch.no_grad()
-def sdeint(sde, y0, ts, method="euler", dt=1e-3, generator=None, **unused):
-    """Euler-Maruyama trajectory [len(ts), B, d] of ``sde`` (an object with f(t, y), g(t, y)) from y0."""
+def sdeint(sde, y0, ts, method="euler", dt=1e-3, generator=None, noise="philox", fused=None, **unused):
+    """Euler-Maruyama trajectory [len(ts), B, d] of ``sde`` (an object with f(t, y), g(t, y)) from y0.
+
+    Two small ``cfm_amd.MLP`` fields (4 layers, widths <= 64: the SF2M tutorial's and the single-cell models) run the
+    WHOLE trajectory in one launch (``cfm_sde_em_mlp_f32``: weights of both fields in LDS, state in registers).
+    ``noise="philox"`` (default): N(0, 1) from Philox4x32-10 inside the kernel, seeded from ``generator`` (or torch's
+    default CUDA generator), so ``torch.manual_seed`` makes runs repeatable; ``noise="torch"``: the increments are
+    drawn with ``torch.randn`` step by step exactly as the launch-per-step scheme draws them — same trajectory, bit for
+    bit, as that scheme.  ``fused=False`` forces the launch-per-step scheme (measurement / test switch)."""
     if method != "euler":
         raise NotImplementedError(f"sdeint method {method!r}: only 'euler' (Euler-Maruyama) is built")
+    if noise not in ("philox", "torch"):
+        raise ValueError("noise must be 'philox' or 'torch'")
     steps = _grid(ts, float(dt))
     fast = (isinstance(sde, FlowScoreSDE) and isinstance(sde.drift, MLP) and isinstance(sde.score, MLP)
             and not callable(sde.sigma) and y0.dim() == 2 and torch.cuda.is_available())
@@ -70,6 +92,36 @@ def sdeint(sde, y0, ts, method="euler", dt=1e-3, generator=None, **unused):
         lib = _lib.load()
         dev = _lib.require_gpu()
         y = _lib.to_dev_f32(y0, dev).clone()
+        fields = _fused_fields(sde) if (y.shape[1] <= 64 and fused is not False) else None
+        if fused is True and fields is None:
+            raise ValueError("sdeint(fused=True): needs two 4-layer time-varying cfm_amd.MLP fields of widths <= 64")
+        if fields is not None:
+            import ctypes
+            import struct
+            f, s, dims = fields
+            B, d = y.shape
+            recs, n_out = [], 0
+            for t, h, is_out in steps:
+                te = (1.0 - t) if sde.reverse else t
+                # the casts of the launch-per-step path: float32 time, float32 step, float32 (g sqrt|h|)
+                recs.append(struct.pack("<fffi", te, h, float(sde.sigma) * math.sqrt(abs(h)), 1 if is_out else 0))
+                n_out += 1 if is_out else 0
+            host = (ctypes.c_char * (16 * len(steps))).from_buffer_copy(b"".join(recs))
+            xi = None
+            seed = 0
+            if noise == "torch":
+                xi = torch.stack([torch.randn((B, d), device=dev, dtype=torch.float32, generator=generator) for _ in steps])
+            else:
+                seed = int(torch.randint(0, 2 ** 62, (1,), device=dev, generator=generator).item())
+            Wf, bf, _, keep_f = f.hip_params(dev)
+            Ws, bs, _, keep_s = s.hip_params(dev)
+            cd = (ctypes.c_int * 5)(*dims)
+            traj = torch.empty((n_out, B, d), dtype=torch.float32, device=dev)
+            ws = torch.empty(16 * len(steps) + 256, dtype=torch.uint8, device=dev)
+            check(lib.cfm_sde_em_mlp_f32(Wf, bf, Ws, bs, cd, 4, ptr(y), B, host, len(steps), 1 if sde.reverse else 0,
+                                         ptr(xi), seed, ptr(traj), ptr(ws), stream_ptr()), "cfm_sde_em_mlp_f32")
+            torch.cuda.current_stream().synchronize()          # `host` (pageable) must outlive the copy
+            return torch.cat([y0.to(torch.float32)[None].to(y0.device), traj.to(y0.device)])
         sign = 1.0
         for t, h, is_out in steps:
             te = (1.0 - t) if sde.reverse else t

@@ -259,6 +259,20 @@ int cfm_mlp_forward_train_f32(const float* x, const float* const* W, const float
 int cfm_mlp_backward_f32(const float* const* acts, const float* const* preact, const float* const* W,
                          const int* dims, int n_layers, int B, const float* dout, float* const* dW,
                          float* const* db, float* dx, void* ws, void* stream);
+/* One regression step of the vector field on a coupled batch, everything but the optimizer update, in 13
+ * launches of this library's kernels (4-layer field) and nothing in between:
+ *     v = net([xt, t]);  loss = mean((v - ut)^2);  dW, db = d loss / d parameters
+ * Replaces `vt = model(torch.cat([xt, t[:, None]], -1)); loss = torch.mean((vt - ut) ** 2); loss.backward()` of the
+ * reference's training loops: examples/images/cifar10/train_cifar10.py:147-149,
+ * examples/2D_tutorials/Flow_matching_tutorial.ipynb cell 9 (torchcfm/models/models.py:10-21 is the net).
+ * xt [B, dims[0] - 1] and t [B] when the net is time varying (the time column is never materialised), or
+ * xt [B, dims[0]] and t = NULL.  hidden / preact as in cfm_mlp_forward_train_f32; g [B, dims[n_layers]] receives
+ * d loss / d v; dW[l] [dims[l+1], dims[l]], db[l]; loss: device float.  Deterministic (fixed-order reductions).
+ * ws: cfm_workspace_bytes(CFM_OP_MLP_TRAIN, B, widest layer incl. input/output, largest dims[l]*dims[l+1]). */
+int cfm_mlp_regression_step_f32(const float* xt, const float* t, const float* ut,
+                                const float* const* W, const float* const* b, const int* dims, int n_layers,
+                                int B, float* const* hidden, float* const* preact, float* g,
+                                float* const* dW, float* const* db, float* loss, void* ws, void* stream);
 /* One torch.optim.Adam step (amsgrad=False, maximize=False) on n_tensors fp32 tensors in ONE launch.
  * table: DEVICE array of n_tensors records {float* param; const float* grad; float* exp_avg;
  * float* exp_avg_sq; uint64 numel} (40 bytes each).  step >= 1 is the step count AFTER this update
@@ -272,6 +286,19 @@ int cfm_adam_step_f32(const void* table, int n_tensors, double lr, double beta1,
  * runner/src/models/components/solver.py:129-139,157-182.  s and xi may be NULL. */
 int cfm_sde_em_step_f32(float* y, const float* v, const float* s, const float* xi, double dt, double g,
                         double score_sign, size_t n, void* stream);
+/* SF2M sampling — the WHOLE Euler-Maruyama trajectory of a batch in one launch, for two small MLP fields (flow v and
+ * score s: 4 layers, widths <= 64, time column last; Ws = bs = NULL: no score):
+ *     y <- y + h (+-v(te, y) + s(te, y)) + g sqrt|h| xi        (reverse: -v, fields evaluated at te = 1 - t)
+ * Replaces torchsde.sdeint(SDE(model, score_model, ...), x0, ts, method="euler", dt=...): SF2M_tutorial.ipynb cell 5,
+ * runner/src/models/components/solver.py:129-139,157-182.  steps_host: n_steps records {float te, h, g_sqrt_h;
+ * int is_out} on the HOST (copied into ws: >= 16 n_steps bytes of device scratch); out [n_out, B, d] receives the
+ * state after every step with is_out != 0.  xi: caller's N(0,1) noise [n_steps, B, d] (then the trajectory is
+ * bit-equal to stepping with cfm_mlp_forward_f32 + cfm_sde_em_step_f32), or NULL: Philox4x32-10 noise from `seed`
+ * in the kernel.  CFM_EINVAL for other field shapes (step launch by launch instead). */
+int cfm_sde_em_mlp_f32(const float* const* Wf, const float* const* bf, const float* const* Ws,
+                       const float* const* bs, const int* dims, int n_layers, const float* y0, int B,
+                       const void* steps_host, int n_steps, int reverse, const float* xi,
+                       unsigned long long seed, float* out, void* ws, void* stream);
 /* Mixture-RBF kernel sum  out[0] += sum_e sum_q exp(-gammas[q] * D[e])  over a squared-distance matrix D
  * (n elements, device fp32; gammas device fp32[n_gamma]; out device double, zeroed by the caller).
  * Replaces the K_XX / K_XY / K_YY matrices of mix_rbf_mmd2: runner/src/models/components/mmd.py:43-63,80-110. */

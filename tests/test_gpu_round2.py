@@ -313,7 +313,7 @@ def test_sdeint_hip_path_equals_eager_scheme_and_has_brownian_variance(dev):
     x0 = oracle.eight_gaussians(256, 1).to(dev)
     ts = torch.linspace(0, 1, 11)
     g1 = torch.Generator(device=dev).manual_seed(7)
-    a = sdeint(FlowScoreSDE(v, s, sigma=0.7), x0, ts, dt=0.02, generator=g1)
+    a = sdeint(FlowScoreSDE(v, s, sigma=0.7), x0, ts, dt=0.02, generator=g1, noise="torch")
 
     class Eager(torch.nn.Module):          # same scheme through the generic (callable) path
         noise_type, sde_type = "diagonal", "ito"
@@ -336,6 +336,38 @@ def test_sdeint_hip_path_equals_eager_scheme_and_has_brownian_variance(dev):
     y = sdeint(FlowScoreSDE(v, s, sigma=2.0), torch.zeros(20000, 2), torch.tensor([0.0, 1.0]), dt=0.01)
     var = float((y[-1] - y[0]).var())
     assert abs(var - 4.0) < 0.15, var
+
+
+def test_sdeint_fused_sampler_is_bit_equal_to_the_launch_per_step_scheme(dev):
+    """cfm_sde_em_mlp_f32 (the whole Euler-Maruyama trajectory in one launch, both fields in LDS) with the caller's
+    noise against two forward passes + cfm_sde_em_step_f32 per step: same bits, forward and reverse time; and the
+    Philox mode is repeatable under torch.manual_seed and has the right moments."""
+    from cfm_amd.sde import FlowScoreSDE, sdeint
+    for d, w, rev in ((2, 64, False), (2, 64, True), (50, 64, False), (5, 32, False)):
+        v, s = _two_fields(dev, d=d, w=w, seed=11 + d)
+        x0 = torch.randn(300, d, generator=torch.Generator().manual_seed(d)).to(dev)
+        ts = torch.linspace(0, 1, 6)
+        sde = FlowScoreSDE(v, s, sigma=0.4, reverse=rev)
+        a = sdeint(sde, x0, ts, dt=0.05, generator=torch.Generator(device=dev).manual_seed(3), noise="torch", fused=True)
+        b = sdeint(sde, x0, ts, dt=0.05, generator=torch.Generator(device=dev).manual_seed(3), noise="torch", fused=False)
+        assert a.shape == b.shape == (6, 300, d)
+        assert torch.equal(a.cpu(), b.cpu()), float((a.cpu() - b.cpu()).abs().max())
+    v, s = _two_fields(dev, seed=5)
+    sde = FlowScoreSDE(v, s, sigma=0.5)
+    x0 = oracle.eight_gaussians(512, 2).to(dev)
+    torch.manual_seed(123); p1 = sdeint(sde, x0, torch.linspace(0, 1, 3), dt=0.02)
+    torch.manual_seed(123); p2 = sdeint(sde, x0, torch.linspace(0, 1, 3), dt=0.02)
+    torch.manual_seed(124); p3 = sdeint(sde, x0, torch.linspace(0, 1, 3), dt=0.02)
+    assert torch.equal(p1, p2) and not torch.equal(p1, p3)
+    for net in (v, s):
+        for p in net.parameters():
+            p.data.zero_()
+    y = sdeint(FlowScoreSDE(v, s, sigma=2.0), torch.zeros(40000, 2), torch.tensor([0.0, 1.0]), dt=0.01)
+    inc = (y[-1] - y[0]).double()
+    assert abs(float(inc.var()) - 4.0) < 0.1 and abs(float(inc.mean())) < 0.03
+    z = inc / 2.0
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.15              # Gaussian kurtosis: the Box-Muller tails are there
+    assert abs(float((z[:, 0] * z[:, 1]).mean())) < 0.02         # the two coordinates of a point are independent
 
 
 def test_runner_metrics_vs_reference_fixture(dev, golden_dir):

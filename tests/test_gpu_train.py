@@ -207,3 +207,83 @@ def test_mlp_training_path_validates_the_feature_count():
     net = cfm_amd.MLP(dim=2, w=64, time_varying=True).to(dev)
     with pytest.raises(RuntimeError, match="cannot be multiplied"):
         net(torch.randn(16, 2, device=dev))
+
+
+def test_regression_step_matches_the_autograd_path_and_float64(dev):
+    """cfm_mlp_regression_step_f32 (time column fused, MSE + seed on the device, one reduction) against the
+    reference's four lines on the autograd path and against float64 autograd on the host: loss and every gradient
+    <= 1e-5 relative (the two HIP paths round the time column differently: epilogue fmaf vs a 785th k step)."""
+    import cfm_amd
+    torch.manual_seed(3)
+    B, d, w = 512, 20, 64
+    net = cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev)
+    t = torch.rand(B, device=dev); xt = torch.randn(B, d, device=dev); ut = torch.randn(B, d, device=dev)
+    opt = cfm_amd.FusedAdam(net.parameters(), lr=1e-3)
+    reg = cfm_amd.RegressionStep(net, opt)
+    loss = float(reg.backward_only(t, xt, ut))
+    g_fused = [p.grad.detach().double().cpu().clone() for p in net.parameters()]
+    # float64 on the host
+    n64 = cfm_amd.MLP(dim=d, time_varying=True, w=w).double()
+    n64.load_state_dict({k: v.double().cpu() for k, v in net.state_dict().items()})
+    l64 = ((n64.net(torch.cat([xt, t[:, None]], -1).double().cpu()) - ut.double().cpu()) ** 2).mean()
+    l64.backward()
+    assert abs(loss - float(l64)) <= 1e-5 * float(l64)
+    for g, p in zip(g_fused, n64.parameters()):
+        assert (g - p.grad).abs().max() <= 1e-5 * p.grad.abs().max(), (g - p.grad).abs().max() / p.grad.abs().max()
+    # the eager four lines on the autograd.Function path
+    for p in net.parameters():
+        p.grad = None
+    le = torch.mean((net(torch.cat([xt, t[:, None]], -1)) - ut) ** 2); le.backward()
+    assert abs(float(le) - loss) <= 1e-5 * abs(loss)
+    for g, p in zip(g_fused, net.parameters()):
+        assert (g - p.grad.double().cpu()).abs().max() <= 1e-5 * g.abs().max()
+    # determinism: the same call twice gives the same bits
+    reg2 = cfm_amd.RegressionStep(net, opt)
+    a = float(reg2.backward_only(t, xt, ut)); ga = [p.grad.clone() for p in net.parameters()]
+    b = float(reg2.backward_only(t, xt, ut))
+    assert a == b and all(torch.equal(x, p.grad) for x, p in zip(ga, net.parameters()))
+
+
+def test_regression_step_c3_shape_and_training_loop(dev):
+    """C3 field (785-512-512-512-784, B = 4096): gradients vs float64; then 5 steps of RegressionStep + FusedAdam
+    track the eager loop (autograd path + torch.optim.Adam) started from the same weights."""
+    import copy
+    import cfm_amd
+    torch.manual_seed(5)
+    B, d = 4096, 784
+    net = cfm_amd.MLP(dim=d, time_varying=True, w=512).to(dev)
+    ref = copy.deepcopy(net)
+    t = torch.rand(B, device=dev); xt = torch.randn(B, d, device=dev); ut = torch.randn(B, d, device=dev) * 0.5
+    opt = cfm_amd.FusedAdam(net.parameters(), lr=1e-3)
+    reg = cfm_amd.RegressionStep(net, opt)
+    loss = float(reg.backward_only(t, xt, ut))
+    n64 = cfm_amd.MLP(dim=d, time_varying=True, w=512).double()
+    n64.load_state_dict({k: v.double().cpu() for k, v in net.state_dict().items()})
+    l64 = ((n64.net(torch.cat([xt, t[:, None]], -1).double().cpu()) - ut.double().cpu()) ** 2).mean(); l64.backward()
+    assert abs(loss - float(l64)) <= 1e-5 * float(l64)
+    for p, q in zip(net.parameters(), n64.parameters()):
+        assert (p.grad.double().cpu() - q.grad).abs().max() <= 1e-5 * q.grad.abs().max()
+    o2 = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    la, lb = [], []
+    for _ in range(5):
+        la.append(float(reg(t, xt, ut)))
+        o2.zero_grad(set_to_none=True)
+        l2 = torch.mean((ref(torch.cat([xt, t[:, None]], -1)) - ut) ** 2); l2.backward(); o2.step(); lb.append(float(l2))
+    assert all(abs(a - b) <= 1e-4 * abs(b) for a, b in zip(la, lb)), (la, lb)
+    assert la[-1] < la[0]
+
+
+def test_regression_step_without_time_column(dev):
+    import cfm_amd
+    torch.manual_seed(7)
+    net = cfm_amd.MLP(dim=6, time_varying=False, w=32).to(dev)
+    x = torch.randn(200, 6, device=dev); u = torch.randn(200, 6, device=dev)
+    reg = cfm_amd.RegressionStep(net, cfm_amd.FusedAdam(net.parameters()))
+    loss = float(reg.backward_only(None, x, u))
+    g = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    le = torch.mean((net(x) - u) ** 2); le.backward()
+    assert abs(float(le) - loss) <= 1e-6 * abs(loss)
+    for a, p in zip(g, net.parameters()):
+        assert (a - p.grad).abs().max() <= 1e-5 * p.grad.abs().max()

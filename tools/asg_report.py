@@ -18,6 +18,8 @@ import torch
 
 import cfm_amd  # noqa: F401
 from cfm_amd import _lib
+if os.environ.get("CFM_LIB_PATH"):          # a variant build of the library (tools/probe/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["CFM_LIB_PATH"])
 import cfm_amd.optimal_transport as ot
 import cfm_oracle as oracle
 import bench
@@ -43,7 +45,8 @@ def check(name, Mnp, dev, unique=True):
     ok = ok and c <= cr + 1e-9 * max(1.0, abs(cr))
     if unique:
         ok = ok and np.array_equal(p, ref)
-    print(f"  {'ok  ' if ok else 'FAIL'} {name}: n={n} {dt*1e3:.1f} ms stats={info['stats']}", flush=True)
+    fb = (ctypes.c_int * 2)(); _lib.load().cfm_assign_debug_fallback(fb)
+    print(f"  {'ok  ' if ok else 'FAIL'} {name}: n={n} {dt*1e3:.1f} ms stats={info['stats']} fallbacks(total,last err)={fb[0]},{fb[1]}", flush=True)
     return ok
 
 
@@ -91,7 +94,8 @@ def timing(dev, seeds, B=4096, d=784, label=""):
         torch.cuda.synchronize(); t0 = time.perf_counter(); ot.assign_exact(M); walls.append((time.perf_counter() - t0) * 1e6)
     n = len(Ms)
     st = np.array(stats, dtype=np.float64).mean(0)
-    print(f"[{label}] B={B} d={d}: {n} instances, perm checksum {chk}")
+    fb = (ctypes.c_int * 2)(); lib.cfm_assign_debug_fallback(fb)
+    print(f"[{label}] B={B} d={d}: {n} instances, perm checksum {chk}; dense-machine fallbacks so far {fb[0]} (last device error {fb[1]})")
     print(f"  mean solve {np.mean(evs):.0f} us (events, incl. read-back)  host wall w/o read-back {np.mean(walls):.0f} us "
           f"(min {np.min(walls):.0f} max {np.max(walls):.0f}); booked on the device {acc[:16].sum()/n:.0f} us")
     print(f"  stats mean: auction_rounds {st[0]:.1f} arr {st[1]:.1f} free_after_arr {st[2]:.1f} sap_batches {st[3]:.1f} "
@@ -108,6 +112,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=2)
     ap.add_argument("--zoo", type=int, default=1)
     ap.add_argument("--sweep", type=int, default=0)
+    ap.add_argument("--sweep2", type=int, default=0, help="round-3 sweep: epsilon = 0 rounds, last epsilon, theta (forest phases in the list solver)")
     a = ap.parse_args()
     lib = _lib.load(); dev = _lib.require_gpu()
     if a.zoo:
@@ -131,6 +136,17 @@ def main():
                 lib.cfm_assign_set_params(0, 0, 0, -1, 0, ac, 0); timing(dev, 1, label=f"arr_cap {ac}")
             lib.cfm_assign_set_params(0, 0, 0, -1, 0, 15, 0)
             lib.cfm_assign_set_mode(0); timing(dev, 1, label="dense only (no list solver)"); lib.cfm_assign_set_mode(1)
+        if a.sweep2:
+            for ac in (3, 6, 10):
+                lib.cfm_assign_set_params(0, 0, 0, -1, 0, ac, 0); timing(dev, 1, label=f"arr_cap {ac}")
+            lib.cfm_assign_set_params(0, 0, 0, -1, 0, 10, 0)
+            for el in (1e-5, 1e-4):
+                lib.cfm_assign_set_params(0, 0, el, -1, 0, -1, 0); timing(dev, 1, label=f"eps_last {el} (arr_cap 10)")
+            lib.cfm_assign_set_params(0, 0, 1e-6, -1, 0, -1, 0)
+            for th in (7.0, 10.0):
+                lib.cfm_assign_set_params(th, 0, 0, -1, 0, -1, 0); timing(dev, 1, label=f"theta {th} (arr_cap 10)")
+            lib.cfm_assign_set_params(5.0, 0, 0, -1, 0, 15, 0)
+            return
         timing(dev, 1, B=8192, d=50, label="B=8192 d=50")
         timing(dev, 1, B=1024, d=784, label="B=1024")
         timing(dev, 1, B=256, d=2, label="B=256 d=2")

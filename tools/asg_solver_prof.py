@@ -12,8 +12,8 @@ import cfm_amd.optimal_transport as ot
 import bench
 lib = _lib.load(); dev = _lib.require_gpu()
 B = 4096
-names = ["init/search", "fast batches", "collect", "a-posteriori", "augment", "dense batches", "#fast", "#batches", "-",
-         "fb: entries+lists issue", "fb: gathers+lower", "fb: barrier1", "fb: dfree", "fb: phase W", "fb: barrier2", "pending seen"]
+names = ["phase init (labels, roots)", "fast batches", "collect", "a-posteriori", "phase finish (accept, duals, augment)", "dense batches", "#fast", "#batches", "#phases",
+         "fb: entries+lists issue", "fb: gathers+lower", "fb: barrier1", "fb: phase W", "fb: barrier2", "fb: radius (last wave)", "pending seen"]
 with torch.cuda.stream(torch.cuda.Stream()):
     Ms = [ot.cost_matrix(x0, x1) for (x0, x1) in bench.synth_batches(B, 784, 8, 1000, dev)]
     ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)

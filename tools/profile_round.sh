@@ -21,6 +21,17 @@ python tools/prof_summary.py pmc $O/raw/mfma_pmc $O/mfma_pmc.csv
 python tools/prof_summary.py util $O/mfma_pmc.csv $O/mfma_util.csv
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/raw/mfma_pmc2 -- python tools/mfma_probe.py > $O/mfma_pmc2.log 2>&1
 python tools/prof_summary.py pmc $O/raw/mfma_pmc2 $O/mfma_pmc2.csv
+# Sinkhorn: per-config kernel statistics and HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes), VALU-busy of variant B
+for CFG in C5 C2; do
+  rocprofv3 --kernel-trace --output-format csv -d $O/raw/sk_$CFG -- python tools/sk_probe.py $CFG > /dev/null 2>&1
+  python tools/prof_summary.py stats $O/raw/sk_$CFG $O/sk_${CFG}_kernel_stats.csv
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/raw/sk_${CFG}_$C -- python tools/sk_probe.py $CFG > /dev/null 2>&1
+    python tools/prof_summary.py pmc $O/raw/sk_${CFG}_$C $O/sk_${CFG}_pmc_$C.csv
+  done
+done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/raw/sk_C2_valu -- python tools/sk_probe.py C2 > /dev/null 2>&1
+python tools/prof_summary.py pmc $O/raw/sk_C2_valu $O/sk_C2_pmc_valu.csv
 rocprofv3 -L 2>/dev/null | grep -i -E "mfma|FETCH_SIZE|WRITE_SIZE|MfmaUtil" | head -40 > $O/counters_available.txt
 rm -rf $O/raw
 ls -la $O
