@@ -126,11 +126,21 @@ def sinkhorn_leg(dev, cfg, reg, iters=200):
                 "bytes move; achieved = the algorithmic 2 x 4 x B^2 bytes per iteration / time (it may exceed the "
                 "HBM peak: it is an equivalent rate, the kernel is VALU / exp bound); matrix-streaming solver on the "
                 "same input: %.0f it/s" % (iters / (ms_stream * 1e-3)))
+    # HBM bytes per iteration from the committed counter passes (profiles/r3_sk_pmc_summary.json: rocprofv3 --pmc
+    # FETCH_SIZE x2 + WRITE_SIZE over tools/sk_probe.py), next to the algorithmic figure
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_sk_pmc_summary.json")))
+        traffic = pmc.get(f"{cfg}_points_hbm_bytes_per_iteration" if points else f"{cfg}_streaming_hbm_bytes_per_iteration")
+        traffic_stream = pmc.get(f"{cfg}_streaming_hbm_bytes_per_iteration")
+    except Exception:  # noqa: BLE001
+        traffic_stream = None
     return {"config": f"{cfg}: B={B0}, d={x0.shape[1]}, eps={reg}", "sinkhorn_iters_per_s": iters / (ms * 1e-3),
             "ms_per_iter": ms / iters, "variant": "points (on-the-fly cost)" if points else "matrix streaming",
             "sinkhorn_iters_per_s_matrix_streaming": iters / (ms_stream * 1e-3),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_iter": per_iter_bytes, "note": note}}
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_matrix_streaming": traffic_stream,
+                         "bytes_per_iter": per_iter_bytes, "note": note}}
 
 
 def c5_ode_leg(dev):
@@ -345,7 +355,7 @@ def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
     t_step = float(np.mean(step_us)) * 1e-6
     gbs = bytes_solve / t_step / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r2_asg_pmc_summary.json")
+    pmc = os.path.join(ROOT, "profiles", "r3_asg_pmc_summary.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("asg_step_hbm_bytes_per_launch")

@@ -77,6 +77,7 @@ struct SpL {
 #define SP_RI_NPL 64     // pending-list length (atomic append counter)
 #define SP_RI_NS 65      // entries in the scan list
 #define SP_RI_FLAG 66
+#define SP_RI_FREECHG 68 // a free column's label was lowered since the radius was last computed
 #define SP_RD_DFREE 48   // radius of the phase
 #define SP_RD_FAR 49     // labels above this are only flagged (SP_INL_FAR), not listed, until the near list is empty
 #define SP_RI_RBAD 120   // 2 ints: mask of the root slots that failed the a-posteriori test
@@ -335,6 +336,7 @@ __device__ __forceinline__ void sp_improve(const SpL& L, int k, double cand, dou
         if (old > nb) {
             L.ddone[k] = 0; L.slot[k] = (unsigned char)slot;
             if (L.owner[k] != SP_NOCOL) sp_file(L, k, cand, plcur, far_thr);
+            else L.ri[SP_RI_FREECHG] = 1;
         }
     }
 }
@@ -473,6 +475,43 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
         if (on[q]) cl[q] = w.cl[(size_t)ii[q] * SP_K + lane];
     }
     FB_TICK(0);
+#ifndef SP_SLOT_BLOCKS
+#define SP_SLOT_BLOCKS 1
+#endif
+#if SP_SLOT_BLOCKS
+    // stages 4 - 6, one self-contained block per entry slot (no defaults carried across slots: the staged form below
+    // spends a third of its instructions on moves / selects for slots that are off — and this kernel is issue bound;
+    // the LDS round trips of a slot are covered by the other three waves of its SIMD)
+#pragma unroll
+    for (int q = 0; q < SP_E; ++q) {
+        if (on[q]) {                                             // (wave uniform)
+            double rj;
+            if (root[q]) rj = sp_rfl_d(L.ru[slot[q]]);
+            else {
+                const unsigned long long hit = __ballot((int)cl[q].x == jj[q]);
+                float cij;
+                if (hit) cij = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)cl[q].y, __ffsll((long long)hit) - 1));
+                else cij = M[(size_t)ii[q] * n + jj[q]];
+                rj = (double)cij + sp_rfl_d(L.p[jj[q]]);         // = u_i: the matched edge is tight
+            }
+            const unsigned col = cl[q].x;
+            if (col != SP_NOCOL && (int)col != jj[q]) {
+                const int k = (int)col;
+                const double cand = sp_cand(L.p[k], __uint_as_float(cl[q].y), rj, bs[q]);
+                if (cand < L.dist[k] && cand < dfree) {          // labels >= the radius can never matter
+                    const unsigned long long nb = (unsigned long long)__double_as_longlong(cand);
+                    const unsigned long long old = atomicMin((unsigned long long*)&L.dist[k], nb);
+                    atomicMin(&L.pkey[k], (nb & ~SP_ROWMASK) | (unsigned long long)(unsigned)ii[q]);
+                    if (old > nb) {
+                        L.ddone[k] = 0; L.slot[k] = (unsigned char)slot[q];
+                        if (L.owner[k] != SP_NOCOL) sp_file(L, k, cand, plcur, far_thr);
+                        else L.ri[SP_RI_FREECHG] = 1;           // only then can the radius move
+                    }
+                }
+            }
+        }
+    }
+#else
     // stage 4: prices / labels of the candidates; price of the matched column, or the root's u
 #pragma unroll
     for (int q = 0; q < SP_E; ++q) {
@@ -528,13 +567,14 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
     }
 #pragma unroll
     for (int q = 0; q < SP_E; ++q)
-        if (on[q] && low[q] && ow[q] != SP_NOCOL) sp_file(L, kk[q], cd[q], plcur, far_thr);
+        if (on[q] && low[q]) { if (ow[q] != SP_NOCOL) sp_file(L, kk[q], cd[q], plcur, far_thr); else L.ri[SP_RI_FREECHG] = 1; }
+#endif
     FB_TICK(1);
     sp_sync();
     FB_TICK(2);
-    if (swv == SP_NW - 1) {
+    if (swv == SP_NW - 1 && L.ri[SP_RI_FREECHG]) {              // (free-column labels change a few times per phase)
         const double dnew = sp_radius(L, nFC, lane, dfree);
-        if (lane == 0) L.rd[SP_RD_DFREE] = dnew;
+        if (lane == 0) { L.rd[SP_RD_DFREE] = dnew; L.ri[SP_RI_FREECHG] = 0; }
     }
     FB_TICK(3);
 }
@@ -554,21 +594,21 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
 #endif
 #define SP_RI_WANT 16    // 16 per-wave selection counts
 #define SP_RI_KEEP 96    // 16 per-wave keep counts
-__device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double dfree, double delta,
-                                                 double far_thr) {
+template <int NSL>
+__device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double dfree, double delta,
+                                               double far_thr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int npl = L.ri[SP_RI_NPL];
-    const int nslot = (npl + SP_T - 1) / SP_T;                     // entries per thread (uniform)
     const int nwav = npl >= SP_T ? SP_NW : (npl + 63) / 64;        // waves that hold entries (uniform)
     const bool active = wv < nwav;
     const unsigned short* src = plcur ? L.pl[1] : L.pl[0];
     unsigned short* dst = plcur ? L.pl[0] : L.pl[1];
-    int kk[SP_IPT]; double dd[SP_IPT]; bool have[SP_IPT], live[SP_IPT];
+    int kk[NSL]; double dd[NSL]; bool have[NSL], live[NSL];
     double lmin = INFINITY, lmax = 0.0; int np = 0;
 #pragma unroll
-    for (int e = 0; e < SP_IPT; ++e) {
+    for (int e = 0; e < NSL; ++e) {
         have[e] = false; kk[e] = 0; dd[e] = INFINITY; live[e] = false;
-        if (e < nslot && active) {
+        if (active) {
             const int t = e * SP_T + tid;
             have[e] = t < npl;
             if (have[e]) {
@@ -590,12 +630,12 @@ __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double
     const int npend = sp_wave_total(lane < nwav ? L.ri[lane] : 0);
     if (!(far_thr < INFINITY) && delta < INFINITY && npend > 2 * SP_CAP) far_thr = dmin + SP_FARMULT * delta;
     const double tau = dmin + delta;
-    bool want[SP_IPT], keep[SP_IPT]; int wpos[SP_IPT], kpos[SP_IPT];
+    bool want[NSL], keep[NSL]; int wpos[NSL], kpos[NSL];
     int wtot = 0, ktot = 0;
 #pragma unroll
-    for (int e = 0; e < SP_IPT; ++e) {
+    for (int e = 0; e < NSL; ++e) {
         want[e] = false; keep[e] = false; wpos[e] = 0; kpos[e] = 0;
-        if (e < nslot && active) {
+        if (active) {
             want[e] = live[e] && dd[e] <= tau;
             keep[e] = live[e] && !want[e] && dd[e] <= far_thr;
             const unsigned long long mw = __ballot(want[e]), mk = __ballot(keep[e]);
@@ -618,8 +658,8 @@ __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double
         sp_sync();                                   // everybody has read the first keep counts
         ktot = 0;
 #pragma unroll
-        for (int e = 0; e < SP_IPT; ++e) {
-            if (e < nslot && active) {
+        for (int e = 0; e < NSL; ++e) {
+            if (active) {
                 const bool sel = want[e] && (woff + wpos[e]) < SP_CAP;
                 keep[e] = live[e] && !sel && dd[e] <= far_thr;
                 want[e] = sel;
@@ -636,7 +676,7 @@ __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double
         koff = __shfl(ks - kc, wv, 64);
     }
 #pragma unroll
-    for (int e = 0; e < SP_IPT; ++e) {
+    for (int e = 0; e < NSL; ++e) {
         if (!have[e]) continue;
         const int k = kk[e];
         if (want[e]) {
@@ -658,6 +698,12 @@ __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double
     if (nsel > SP_CAP) delta = 0.5 * fmin(delta, dmax - dmin);
     else if (nsel < SP_CAP / 2 && npend > nsel) delta = fmax(2.0 * delta, (dmax - dmin) * (1.0 / 64.0));
     return delta;
+}
+
+// (the near list rarely exceeds 1024 entries: one entry per thread then, without the code of the other three slots)
+__device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double dfree, double delta, double far_thr) {
+    if (L.ri[SP_RI_NPL] <= SP_T) return sp_collect_n<1>(L, plcur, dfree, delta, far_thr);
+    return sp_collect_n<SP_IPT>(L, plcur, dfree, delta, far_thr);
 }
 
 #ifdef SP_PROFILE
@@ -732,7 +778,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 if (rdense) L.ri[SP_RI_ANYD] = 1;
             }
         }
-        if (tid == 0) { L.ri[SP_RI_NPL] = 0; L.rd[SP_RD_DFREE] = INFINITY; L.rd[SP_RD_FAR] = INFINITY; }
+        if (tid == 0) { L.ri[SP_RI_NPL] = 0; L.rd[SP_RD_DFREE] = INFINITY; L.rd[SP_RD_FAR] = INFINITY; L.ri[SP_RI_FREECHG] = 0; }
         sp_sync();
         int nS = nR, plcur = 0;
         bool any_dense = L.ri[SP_RI_ANYD] != 0;
@@ -752,9 +798,9 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                         if (b < dfree) sp_entry(M, w, L, n, L.lcol[t], b, lane, plcur, dfree, far_thr);
                     }
                     sp_sync();
-                    if (wv == SP_NW - 1) {
+                    if (wv == SP_NW - 1 && L.ri[SP_RI_FREECHG]) {
                         const double dnew = sp_radius(L, nFC, lane, dfree);
-                        if (lane == 0) L.rd[SP_RD_DFREE] = dnew;
+                        if (lane == 0) { L.rd[SP_RD_DFREE] = dnew; L.ri[SP_RI_FREECHG] = 0; }
                     }
                 }
                 ++batches; scans += nS;

@@ -80,9 +80,11 @@ def assign_exact(M, return_info=False):
             f"assignment problem); got {tuple(M.shape)}")
     dev = M.device
     perm = torch.empty(B, dtype=torch.int32, device=dev)
-    cert = torch.zeros(1, dtype=torch.int32, device=dev)
-    tot = torch.zeros(1, dtype=torch.float64, device=dev)
-    stats = torch.zeros(8, dtype=torch.int32, device=dev)
+    # (no zero fills: the library writes all three on success and returns an error code otherwise — three eager fill
+    #  launches per coupling less)
+    cert = torch.empty(1, dtype=torch.int32, device=dev)
+    tot = torch.empty(1, dtype=torch.float64, device=dev)
+    stats = torch.empty(8, dtype=torch.int32, device=dev)
     ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
     check(lib.cfm_assign_exact_f32(ptr(M), B, ptr(perm), ptr(cert), ptr(tot), ptr(stats), ptr(ws),
                                    stream_ptr()), "cfm_assign_exact_f32")
