@@ -594,6 +594,17 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
 #endif
 #define SP_RI_WANT 16    // 16 per-wave selection counts
 #define SP_RI_KEEP 96    // 16 per-wave keep counts
+// (round 3, after the cycle counters: the 16 waves no longer reduce the partial minima / counts redundantly and there
+//  are no prefix scans over the waves — a wave adds its partials to three LDS words with atomics, and takes its block of
+//  the scan list / the kept list with ONE returning atomic add each; the order of the lists is arbitrary anyway.  Two
+//  barriers instead of three, and the kept-list counter IS the append counter of the next pending list.)
+#ifndef SP_TLO
+#define SP_TLO (SP_CAP / 2)   // the window doubles while a batch holds fewer entries than this
+#endif
+#define SP_RD_CMIN 52    // bit patterns (labels >= +0 order like integers): smallest / largest live pending label
+#define SP_RD_CMAX 53
+#define SP_RI_CNP 69     // live pending entries
+#define SP_RI_CSEL 70    // entries wanted for the scan list (may exceed SP_CAP)
 template <int NSL>
 __device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double dfree, double delta,
                                                double far_thr) {
@@ -605,6 +616,9 @@ __device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double d
     unsigned short* dst = plcur ? L.pl[0] : L.pl[1];
     int kk[NSL]; double dd[NSL]; bool have[NSL], live[NSL];
     double lmin = INFINITY, lmax = 0.0; int np = 0;
+    if (tid == 0) {
+        L.rd[SP_RD_CMIN] = INFINITY; L.rd[SP_RD_CMAX] = 0.0; L.ri[SP_RI_CNP] = 0; L.ri[SP_RI_CSEL] = 0;
+    }
 #pragma unroll
     for (int e = 0; e < NSL; ++e) {
         have[e] = false; kk[e] = 0; dd[e] = INFINITY; live[e] = false;
@@ -619,87 +633,82 @@ __device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double d
             }
         }
     }
-    if (active) {
-        const double wmin = sp_wave_min(lmin), wmax = sp_wave_max(lmax);
-        const int wnp = sp_wave_total(np);
-        if (lane == 0) { L.rd[wv] = wmin; L.rd[16 + wv] = wmax; L.ri[wv] = wnp; }
+    double wmin = INFINITY, wmax = 0.0; int wnp = 0;
+    if (active) { wmin = sp_wave_min(lmin); wmax = sp_wave_max(lmax); wnp = sp_wave_total(np); }
+    sp_sync();                                      // everybody has read the list length; the words above are reset
+    if (active && lane == 0 && wnp > 0) {
+        atomicMin(reinterpret_cast<unsigned long long*>(&L.rd[SP_RD_CMIN]), (unsigned long long)__double_as_longlong(wmin));
+        atomicMax(reinterpret_cast<unsigned long long*>(&L.rd[SP_RD_CMAX]), (unsigned long long)__double_as_longlong(wmax));
+        atomicAdd(&L.ri[SP_RI_CNP], wnp);
     }
+    if (tid == 0) L.ri[SP_RI_NPL] = 0;              // from here on: the append counter of the list being built
     sp_sync();
-    const double dmin = sp_wave_min(lane < nwav ? L.rd[lane] : INFINITY);
-    const double dmax = sp_wave_max(lane < nwav ? L.rd[16 + lane] : 0.0);
-    const int npend = sp_wave_total(lane < nwav ? L.ri[lane] : 0);
+    const double dmin = L.rd[SP_RD_CMIN], dmax = L.rd[SP_RD_CMAX];
+    const int npend = L.ri[SP_RI_CNP];
     if (!(far_thr < INFINITY) && delta < INFINITY && npend > 2 * SP_CAP) far_thr = dmin + SP_FARMULT * delta;
     const double tau = dmin + delta;
-    bool want[NSL], keep[NSL]; int wpos[NSL], kpos[NSL];
-    int wtot = 0, ktot = 0;
-#pragma unroll
-    for (int e = 0; e < NSL; ++e) {
-        want[e] = false; keep[e] = false; wpos[e] = 0; kpos[e] = 0;
-        if (active) {
-            want[e] = live[e] && dd[e] <= tau;
-            keep[e] = live[e] && !want[e] && dd[e] <= far_thr;
-            const unsigned long long mw = __ballot(want[e]), mk = __ballot(keep[e]);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            wpos[e] = wtot + __popcll(mw & below); kpos[e] = ktot + __popcll(mk & below);
-            wtot += __popcll(mw); ktot += __popcll(mk);
-        }
-    }
-    if (lane == 0 && active) { L.ri[SP_RI_WANT + wv] = wtot; L.ri[SP_RI_KEEP + wv] = ktot; }
-    sp_sync();
-    int woff, koff, nsel, nkeep;
-    {
-        const int wc = (lane < nwav) ? L.ri[SP_RI_WANT + lane] : 0, kc = (lane < nwav) ? L.ri[SP_RI_KEEP + lane] : 0;
-        const int ws = sp_wave_scan(wc), ks = sp_wave_scan(kc);
-        nsel = __builtin_amdgcn_readlane(ws, 63); nkeep = __builtin_amdgcn_readlane(ks, 63);
-        woff = __shfl(ws - wc, wv, 64); koff = __shfl(ks - kc, wv, 64);
-    }
-    if (nsel > SP_CAP) {
-        // over the cap (rare: delta halves below): the wants past SP_CAP stay pending
-        sp_sync();                                   // everybody has read the first keep counts
-        ktot = 0;
+    if (active) {
+        bool want[NSL]; int wpos[NSL]; int wtot = 0;
 #pragma unroll
         for (int e = 0; e < NSL; ++e) {
-            if (active) {
-                const bool sel = want[e] && (woff + wpos[e]) < SP_CAP;
-                keep[e] = live[e] && !sel && dd[e] <= far_thr;
-                want[e] = sel;
-                const unsigned long long mk = __ballot(keep[e]);
-                kpos[e] = ktot + __popcll(mk & ((1ull << lane) - 1ull));
-                ktot += __popcll(mk);
-            }
+            want[e] = live[e] && dd[e] <= tau;
+            const unsigned long long mw = __ballot(want[e]);
+            wpos[e] = wtot + __popcll(mw & ((1ull << lane) - 1ull));
+            wtot += __popcll(mw);
         }
-        if (lane == 0 && active) L.ri[SP_RI_KEEP + wv] = ktot;
-        sp_sync();
-        const int kc = (lane < nwav) ? L.ri[SP_RI_KEEP + lane] : 0;
-        const int ks = sp_wave_scan(kc);
-        nkeep = __builtin_amdgcn_readlane(ks, 63);
-        koff = __shfl(ks - kc, wv, 64);
-    }
+        int woff = 0;
+        if (wtot > 0) {
+            if (lane == 0) woff = atomicAdd(&L.ri[SP_RI_CSEL], wtot);
+            woff = __builtin_amdgcn_readfirstlane(woff);
+        }
+        bool keep[NSL]; int kpos[NSL]; int ktot = 0;
 #pragma unroll
-    for (int e = 0; e < NSL; ++e) {
-        if (!have[e]) continue;
-        const int k = kk[e];
-        if (want[e]) {
-            const int spos = woff + wpos[e];
-            L.lcol[spos] = (unsigned short)k; L.lbase[spos] = dd[e]; L.inl[k] = 0;
-        } else if (keep[e]) {
-            dst[koff + kpos[e]] = (unsigned short)k;
-        } else {
-            L.inl[k] = live[e] ? (unsigned char)SP_INL_FAR : (unsigned char)0;
+        for (int e = 0; e < NSL; ++e) {
+            const bool sel = want[e] && (woff + wpos[e]) < SP_CAP;      // the wants past the cap stay pending
+            keep[e] = live[e] && !sel && dd[e] <= far_thr;
+            want[e] = sel;
+            const unsigned long long mk = __ballot(keep[e]);
+            kpos[e] = ktot + __popcll(mk & ((1ull << lane) - 1ull));
+            ktot += __popcll(mk);
+        }
+        int koff = 0;
+        if (ktot > 0) {
+            if (lane == 0) koff = atomicAdd(&L.ri[SP_RI_NPL], ktot);
+            koff = __builtin_amdgcn_readfirstlane(koff);
+        }
+#pragma unroll
+        for (int e = 0; e < NSL; ++e) {
+            if (!have[e]) continue;
+            const int k = kk[e];
+            if (want[e]) {
+                const int spos = woff + wpos[e];
+                L.lcol[spos] = (unsigned short)k; L.lbase[spos] = dd[e]; L.inl[k] = 0;
+            } else if (keep[e]) {
+                dst[koff + kpos[e]] = (unsigned short)k;
+            } else {
+                L.inl[k] = live[e] ? (unsigned char)SP_INL_FAR : (unsigned char)0;
+            }
         }
     }
     if (tid == 0) {
-        L.ri[SP_RI_NS] = nsel < SP_CAP ? nsel : SP_CAP; L.ri[SP_RI_NPL] = nkeep; L.rd[SP_RD_FAR] = far_thr;
+        L.rd[SP_RD_FAR] = far_thr;
 #ifdef SP_PROFILE
         L.ri[125] += npl;
 #endif
     }
-    // adapt the window: aim at 32 .. 64 entries per batch
-    if (nsel > SP_CAP) delta = 0.5 * fmin(delta, dmax - dmin);
-    else if (nsel < SP_CAP / 2 && npend > nsel) delta = fmax(2.0 * delta, (dmax - dmin) * (1.0 / 64.0));
+    // (the caller's barrier follows; nS = min(CSEL, SP_CAP) and the window adaptation are read from LDS after it)
     return delta;
 }
-
+// after the caller's barrier: the scan-list length and the adapted window (every thread computes the same)
+__device__ __forceinline__ double sp_collect_result(const SpL& L, double delta, int* nS) {
+    const int nsel = L.ri[SP_RI_CSEL], npend = L.ri[SP_RI_CNP];
+    const double dmin = L.rd[SP_RD_CMIN], dmax = L.rd[SP_RD_CMAX];
+    *nS = nsel < SP_CAP ? nsel : SP_CAP;
+    // adapt the window: aim at 32 .. 64 entries per batch
+    if (nsel > SP_CAP) delta = 0.5 * fmin(delta, dmax - dmin);
+    else if (nsel < SP_TLO && npend > nsel) delta = fmax(2.0 * delta, (dmax - dmin) * (1.0 / 64.0));
+    return delta;
+}
 // (the near list rarely exceeds 1024 entries: one entry per thread then, without the code of the other three slots)
 __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double dfree, double delta, double far_thr) {
     if (L.ri[SP_RI_NPL] <= SP_T) return sp_collect_n<1>(L, plcur, dfree, delta, far_thr);
@@ -813,7 +822,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
             delta = sp_collect_all(L, plcur, dfree, delta, far_thr);
             sp_sync();
             dfree = L.rd[SP_RD_DFREE];
-            nS = L.ri[SP_RI_NS]; far_thr = L.rd[SP_RD_FAR]; plcur ^= 1; any_dense = false;
+            delta = sp_collect_result(L, delta, &nS); far_thr = L.rd[SP_RD_FAR]; plcur ^= 1; any_dense = false;
             SP_TICK(2);
             if (nS > 0) continue;
             if (L.ri[SP_RI_NPL] > 0) { err = 7; break; }   // tau >= dmin always selects something
@@ -854,7 +863,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                     sp_sync();
                     delta = sp_collect_all(L, plcur, dfree, delta, far_thr);
                     sp_sync();
-                    nS = L.ri[SP_RI_NS]; far_thr = L.rd[SP_RD_FAR]; plcur ^= 1;
+                    delta = sp_collect_result(L, delta, &nS); far_thr = L.rd[SP_RD_FAR]; plcur ^= 1;
                     SP_TICK(2);
                     if (nS > 0) continue;
                     err = 8; break;                          // fmin_ <= far_thr: something must be selected

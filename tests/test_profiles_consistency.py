@@ -12,7 +12,7 @@ PROF = os.path.join(ROOT, "profiles")
 
 
 def _bench():
-    with open(os.path.join(PROF, "r2_bench_default.json")) as fh:
+    with open(os.path.join(PROF, "r3_bench_default.json")) as fh:
         return json.loads(fh.read().strip().splitlines()[-1])
 
 
@@ -35,7 +35,7 @@ def test_roofline_rederivable_from_its_fields_and_the_pmc_passes():
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
     # achieved = algorithmic bytes per launch / average launch duration
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9, rel=1e-6)
-    with open(os.path.join(PROF, "r2_asg_pmc_summary.json")) as fh:
+    with open(os.path.join(PROF, "r3_asg_pmc_summary.json")) as fh:
         pmc = json.load(fh)
     assert r["traffic"] == pytest.approx(pmc["asg_step_hbm_bytes_per_launch"], rel=1e-9)
     assert pmc["asg_step_hbm_bytes_per_launch"] == pytest.approx(
@@ -45,12 +45,31 @@ def test_roofline_rederivable_from_its_fields_and_the_pmc_passes():
 
 
 def test_kernel_statistics_of_the_same_command_are_committed():
-    with open(os.path.join(PROF, "r2_bench_kernel_stats.csv")) as fh:
+    with open(os.path.join(PROF, "r3_bench_kernel_stats.csv")) as fh:
         rows = {row["kernel"]: row for row in csv.DictReader(fh)}
     for k in ("asg_step", "asg_solve", "asg_small"):
         assert k in rows and int(rows[k]["calls"]) > 0, k
     assert any(k.startswith("void gemm_f32_mfma") for k in rows)          # the model step runs on this library's kernels
     assert any(k.startswith("void ode_small_dopri") for k in rows)
-    with open(os.path.join(PROF, "r2_mfma_util.csv")) as fh:
+    # the model step of the timed region: forward, MSE seed, backward, reduction, Adam — kernels of this library only
+    for k in ("mse_grad", "adam_multi", "reduce_splits_multi"):
+        assert k in rows and int(rows[k]["calls"]) > 0, k
+    assert any(k.startswith("void mlp_layer") for k in rows)
+    with open(os.path.join(PROF, "r3_mfma_util.csv")) as fh:
         util = {row["kernel"]: float(row["MfmaUtil_percent"]) for row in csv.DictReader(fh)}
     assert all(0.0 < v <= 100.0 for v in util.values()) and len(util) >= 4
+
+
+def test_parity_and_sinkhorn_traffic_are_in_the_line():
+    d = _bench()
+    par = d["parity"]
+    assert par["c3_index_agreement"] == 1.0 and par["c3_cost_gap_rel"] == 0.0       # the north star's bit-exact plan indices, end to end
+    assert par["c2_index_agreement"] > 0.99 and abs(par["c2_cost_gap_rel"]) < 1e-8
+    with open(os.path.join(PROF, "r3_sk_pmc_summary.json")) as fh:
+        sk = json.load(fh)
+    c5 = d["c5"]["roofline"]
+    assert c5["traffic"] == pytest.approx(sk["C5_streaming_hbm_bytes_per_iteration"], rel=1e-9)
+    assert c5["traffic"] <= 1.05 * c5["bytes_per_iter"]           # two reads of the matrix per iteration and nothing else
+    assert d["c2"]["roofline"]["traffic"] < 0.02 * d["c2"]["roofline"]["bytes_per_iter"]      # variant B moves no matrix bytes
+    aux = d["aux"]
+    assert aux["sde_em_ms"] > 0 and aux["unbalanced_iters_per_s"] > 0 and aux["partial_iters_per_s"] > 0

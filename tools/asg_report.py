@@ -137,9 +137,10 @@ def main():
             lib.cfm_assign_set_params(0, 0, 0, -1, 0, 15, 0)
             lib.cfm_assign_set_mode(0); timing(dev, 1, label="dense only (no list solver)"); lib.cfm_assign_set_mode(1)
         if a.sweep2:
-            for ac in (3, 6, 10):
+            for ac in (8, 10, 12):
                 lib.cfm_assign_set_params(0, 0, 0, -1, 0, ac, 0); timing(dev, 1, label=f"arr_cap {ac}")
             lib.cfm_assign_set_params(0, 0, 0, -1, 0, 10, 0)
+            return
             for el in (1e-5, 1e-4):
                 lib.cfm_assign_set_params(0, 0, el, -1, 0, -1, 0); timing(dev, 1, label=f"eps_last {el} (arr_cap 10)")
             lib.cfm_assign_set_params(0, 0, 1e-6, -1, 0, -1, 0)
