@@ -22,7 +22,7 @@
 //   asg_step   every chip-wide step   UMIN0, INITRED, AUCTION, ARR, CONVERT, UMIN, COLRED, ROOTMIN,
 //                                     SAP, MS_FINISH, CERT       (119 VGPRs, <= 48 KiB LDS at n = 4096)
 //   asg_build  candidate lists        BUILD            (n <= 4096; 8 waves, 128 KiB of row strips)
-//   asg_solve  one-workgroup list solver   SOLVER      (n <= 4096; 143 KiB of solver state)
+//   asg_solve  one-workgroup list solver   SOLVER      (n <= 4096; 152 KiB of solver state: the forest phases run here)
 //
 //   init     Jonker-Volgenant row + column reduction: u_i = min_j c_ij,
 //            p_j = max_i (u_i - c_ij) (every column tight for some row) — the auction
@@ -44,14 +44,16 @@
 //   phase C  shortest augmenting paths for the remaining free rows.  First the free
 //            columns are "column reduced" (their stale auction prices are lowered until
 //            each is tight for some row: a pure dual ascent step).  Then MULTI-SOURCE
-//            rounds: one batched Bellman-Ford label-correcting search is grown from ALL
-//            free rows at once (a shortest-path forest, one tree per free row; every
-//            round relaxes all dirty rows, one lane per column: single writer, no
-//            atomics), and ONE path per tree that reached a free column is augmented
-//            (the trees are vertex disjoint; the dual update with the radius D = the
-//            longest accepted path makes every accepted path tight).  A phase costs the
-//            hop depth of one search but retires many free rows.  The last few (hard)
-//            rows go to the one-workgroup candidate-list solver (n <= 4096).
+//            phases: one batched label-correcting search is grown from ALL free rows at
+//            once (a shortest-path forest, one tree per free row), and ONE path per tree
+//            that reached a free column is augmented (the trees are vertex disjoint; the
+//            dual update with the radius D = the longest accepted path makes every
+//            accepted path tight).  A phase costs the depth of one search but retires many
+//            free rows.  With <= 64 free rows (n <= 4096: always, at the benchmark shapes)
+//            the phases run inside the one-workgroup candidate-list solver (assign_sparse.h);
+//            with more, chip-wide Bellman-Ford rounds on the dense matrix retire rows first
+//            (every round relaxes all dirty rows, one lane per column: single writer, no
+//            atomics).
 //   phase D  fp64 certificate: dual feasibility + complementary slackness over
 //            the whole matrix, total cost.
 //
