@@ -81,7 +81,6 @@ EXTRA_SIGNATURES = {
     "cfm_assign_debug_fallback": (None, [_vp]),
     "cfm_assign_debug_times": (_i, [_vp, _vp]),
     "cfm_assign_set_wide_blocks": (None, [_i]),
-    "cfm_assign_set_ms_quantile": (None, [_d]),
     "cfm_assign_set_stop_early": (None, [_d]),
     "cfm_assign_set_bulk": (None, [_i, _i]),
     "cfm_assign_set_small": (None, [_i]),

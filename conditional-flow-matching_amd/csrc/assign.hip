@@ -123,7 +123,6 @@ extern "C" void cfm_assign_set_handoff(int handoff) {      // at most 64 free ro
     if (handoff >= 0) g_params.handoff = handoff > 64 ? 64 : handoff;
 }
 extern "C" void cfm_assign_set_stop_early(double f) { std::lock_guard<std::mutex> lk(g_params_mu); if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
-extern "C" void cfm_assign_set_ms_quantile(double) {}   // kept for old tuning scripts: the radius is the largest free-column label
 extern "C" void cfm_assign_set_small(int on) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.small = on > 0 ? on : 0; }
 extern "C" void cfm_assign_set_bulk(int bulk, int min_n) {
     std::lock_guard<std::mutex> lk(g_params_mu);

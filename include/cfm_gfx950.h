@@ -18,8 +18,10 @@
  *   - no entry point allocates or frees device memory: scratch comes from the
  *     caller through `ws` (size from cfm_workspace_bytes);
  *   - return value: 0 = ok, <0 = invalid argument (CFM_E*), >0 = hipError_t;
- *   - no exceptions cross the boundary, no global state except a lazily
- *     initialised device-properties cache.
+ *   - no exceptions cross the boundary; no global state except a lazily
+ *     initialised per-device properties cache and the solver-parameter table
+ *     of include/cfm_gfx950_tuning.h (measurement / tuning exports that no
+ *     binding needs; a solve snapshots the table under a mutex when it starts).
  */
 #ifndef CFM_GFX950_H
 #define CFM_GFX950_H

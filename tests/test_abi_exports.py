@@ -55,3 +55,16 @@ def test_code_object_is_gfx950_only(lib_built):
     assert b"gfx950" in blob
     for other in (b"gfx942", b"gfx90a", b"sm_"):
         assert other not in blob
+
+
+def test_tuning_header_lists_every_extra_export(lib_built):
+    """The measurement / tuning exports are declared too (include/cfm_gfx950_tuning.h) — separately: they are not part
+    of the operator ABI — and the binding's EXTRA_SIGNATURES is exactly that list."""
+    src = open(os.path.join(ROOT, "include", "cfm_gfx950_tuning.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(cfm_[a-z0-9_]+)\s*\(", src)))
+    assert names == sorted(lib_built.EXTRA_SIGNATURES)
+    lib = ctypes.CDLL(lib_built.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert not set(names) & set(_declared())
