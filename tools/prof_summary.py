@@ -78,6 +78,35 @@ def asgjson(fetch_csv, write_csv, out):
         json.dump(res, fh, indent=1)
 
 
+def skjson(prof_dir, out):
+    """Sinkhorn HBM traffic per iteration from the per-config counter passes (sk_<CFG>_pmc_{FETCH,WRITE}_SIZE.csv) and the
+    per-iteration kernel time from sk_<CFG>_kernel_stats.csv.  Matrix streaming: sk_col_pass + sk_col_finalize + sk_row_stream;
+    variant B (C2 only): 2 x sk_pts_pass.  FETCH_SIZE x2 (gfx950), WRITE_SIZE x1."""
+    import json, os
+    def load(f, col="mean_per_call"):
+        with open(f) as fh:
+            return {r["kernel"]: float(r[col]) for r in csv.DictReader(fh)}
+    stream = ("sk_col_finalize", "sk_col_pass", "void sk_row_stream<4>")
+    res = {}
+    for cfg in ("C5", "C2"):
+        fe = load(os.path.join(prof_dir, f"sk_{cfg}_pmc_FETCH_SIZE.csv"))
+        wr = load(os.path.join(prof_dir, f"sk_{cfg}_pmc_WRITE_SIZE.csv"))
+        us = load(os.path.join(prof_dir, f"sk_{cfg}_kernel_stats.csv"), "avg_us")
+        res[f"{cfg}_streaming_hbm_bytes_per_iteration"] = sum(2.0 * fe[k] + wr[k] for k in stream) * 1024.0
+        res[f"{cfg}_streaming_FETCH_SIZE_KiB"] = {k: fe[k] for k in stream}
+        res[f"{cfg}_streaming_WRITE_SIZE_KiB"] = {k: wr[k] for k in stream}
+        res[f"{cfg}_streaming_us_per_iteration_kernel_trace"] = sum(us[k] for k in stream)
+        pts = [k for k in fe if k.startswith("void sk_pts_pass")]
+        if pts:
+            res[f"{cfg}_points_hbm_bytes_per_iteration"] = 2.0 * (2.0 * fe[pts[0]] + wr[pts[0]]) * 1024.0
+            res[f"{cfg}_points_us_per_iteration_kernel_trace"] = 2.0 * us[pts[0]]
+    res["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/sk_probe.py (one config per process); per "
+                   "iteration = sk_col_pass + sk_col_finalize + sk_row_stream (matrix streaming) or 2 x sk_pts_pass (variant B); "
+                   "FETCH_SIZE x2 (gfx950 reports half the bytes of wide coalesced reads), WRITE_SIZE x1")
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+
+
 if __name__ == "__main__":
-    fn = {"stats": stats, "pmc": pmc, "util": util, "asgjson": asgjson}[sys.argv[1]]
+    fn = {"stats": stats, "pmc": pmc, "util": util, "asgjson": asgjson, "skjson": skjson}[sys.argv[1]]
     fn(*sys.argv[2:])

@@ -32,6 +32,7 @@ for CFG in C5 C2; do
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/raw/sk_C2_valu -- python tools/sk_probe.py C2 > /dev/null 2>&1
 python tools/prof_summary.py pmc $O/raw/sk_C2_valu $O/sk_C2_pmc_valu.csv
+python tools/prof_summary.py skjson $O $O/sk_pmc_summary.json
 rocprofv3 -L 2>/dev/null | grep -i -E "mfma|FETCH_SIZE|WRITE_SIZE|MfmaUtil" | head -40 > $O/counters_available.txt
 rm -rf $O/raw
 ls -la $O
