@@ -8,9 +8,11 @@ One "step" = one pass of the hot path over one synthetic minibatch already resid
     cost matrix -> exact OT assignment -> plan sampling -> fused gather + xt/ut  (HIP kernels)
     -> MLP(785-512-512-512-784) forward, backward (fp32-MFMA HIP kernels behind an autograd.Function),
        MSE loss (eager elementwise ops), one-launch Adam (HIP)
-Schedule (--pipeline N, default 3): the coupling depends only on the data, so the couplings of
-the next N batches are computed on side streams (background threads, cfm_amd.prefetch) while the
-model steps on batch k, like data-loader workers.  The pipeline starts empty inside the timed
+Schedule (--pipeline N --group G, default 3 x 4): the coupling depends only on the data, so the couplings of
+the next batches are computed on side streams (background threads, cfm_amd.prefetch) while the model steps on
+batch k, like data-loader workers: N prefetch jobs in flight, each coupling G consecutive minibatches together —
+their G assignment problems go through ONE chain of launches (cfm_assign_exact_batch_f32; same kernels and the
+same per-problem state machine as G single solves, bit-equal results).  The pipeline starts empty inside the timed
 region and is drained inside it: K timed steps contain exactly K couplings and K model updates.
 Host RNG draws stay on the main thread, in order.  `value` is that schedule; `value_sequential`
 is the same K steps strictly one after the other (what an unmodified training script gets).
@@ -59,11 +61,13 @@ def synth_batches(B, d, n, seed, dev):
 
 
 # --------------------------------------------------------------------------- the timed loop
-def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, depth=0):
+def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, depth=0, group=1, couple_group=None):
     """`count` steps starting at pool index `first`: every step = one coupling + one model update,
     all of them inside this call (a prefetch pipeline starts empty and is drained).  Returns the
     last (t, xt, ut).  Device agnostic: `couple(x0, x1, drawn)` and `model_step(t, xt, ut)` are the
-    caller's; the CPU multi-process test drives this with CPU stand-ins."""
+    caller's; the CPU multi-process test drives this with CPU stand-ins.
+    group > 1: the couplings of `group` consecutive minibatches are one prefetch job
+    (`couple_group(batches, drawn_list)` -> one result per minibatch), `depth` such jobs in flight."""
     last = None
     if not depth or prefetcher is None:
         for k in range(count):
@@ -72,6 +76,21 @@ def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, dep
             model_step(*last)
         return last
     inflight, submitted = collections.deque(), 0
+    if group > 1 and couple_group is not None:
+        def submit_next():
+            nonlocal submitted
+            k = min(group, count - submitted)
+            batches = [pool[(first + submitted + q) % len(pool)] for q in range(k)]
+            inflight.append(prefetcher.submit_group(batches, couple_group, draw)); submitted += k
+        while submitted < count and len(inflight) < depth:
+            submit_next()
+        while inflight:
+            outs = inflight.popleft().result()
+            if submitted < count:
+                submit_next()
+            for last in outs:
+                model_step(*last)
+        return last
     while submitted < min(depth, count):
         inflight.append(prefetcher.submit(*pool[(first + submitted) % len(pool)], hook=couple, draw=draw)); submitted += 1
     for k in range(count):
@@ -82,13 +101,14 @@ def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, dep
     return last
 
 
-def timed_region(D, sync, pool, warmup, steps, couple, model_step, draw, prefetcher, depth, device=None):
+def timed_region(D, sync, pool, warmup, steps, couple, model_step, draw, prefetcher, depth, device=None, group=1,
+                 couple_group=None):
     """Warm-up, barrier + sync, K steps + ONE all-gather of the final samples, sync + barrier; the
     MAX over ranks of the elapsed time.  Returns (elapsed_s, gathered_final_xt)."""
-    run_steps(pool, 0, warmup, couple, model_step, draw, prefetcher, depth)
+    run_steps(pool, 0, warmup, couple, model_step, draw, prefetcher, depth, group, couple_group)
     D.barrier(); sync()
     t0 = time.perf_counter()
-    last = run_steps(pool, warmup, steps, couple, model_step, draw, prefetcher, depth)
+    last = run_steps(pool, warmup, steps, couple, model_step, draw, prefetcher, depth, group, couple_group)
     gathered = D.all_gather_samples(last[1]) if last is not None else None
     sync(); D.barrier()
     return D.max_over_ranks(time.perf_counter() - t0, device), gathered
@@ -458,6 +478,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=3,
                     help="N > 0: up to N couplings of the next batches in flight on side streams while the "
                          "model steps on batch k (cfm_amd.prefetch); 0: strictly sequential")
+    ap.add_argument("--group", type=int, default=4,
+                    help="G > 1: a prefetch job couples G consecutive minibatches together (the exact solver takes the G "
+                         "assignment problems in one chain of launches); --pipeline such jobs in flight")
     ap.add_argument("--model-step", default="fused", choices=["fused", "eager"],
                     help="fused: cfm_amd.RegressionStep (one C call: forward + MSE + backward, then the one-launch Adam); "
                          "eager: the reference's four lines on the autograd.Function path")
@@ -520,6 +543,17 @@ def main():
         i, j = ot.sample_perm(perm, u, B)
         return fm._sample(x0, x1, t_host.type_as(x0), False, idx=(i, j))
 
+    def couple_group(batches, drawn):
+        """the same for several minibatches at once: the G assignment problems go through ONE chain of launches"""
+        Ms = [ot.cost_matrix(x0, x1) for x0, x1 in batches]
+        perms = ot.assign_exact_batch(Ms)
+        outs = []
+        for (x0, x1), (u_host, t_host), perm in zip(batches, drawn, perms):
+            u = torch.from_numpy(u_host).to(dev)
+            i, j = ot.sample_perm(perm, u, B)
+            outs.append(fm._sample(x0, x1, t_host.type_as(x0), False, idx=(i, j)))
+        return outs
+
     reg = cfm_amd.RegressionStep(model, opt) if args.model_step == "fused" else None
 
     def model_step(t, xt, ut):
@@ -540,7 +574,7 @@ def main():
         from cfm_amd.prefetch import CouplingPrefetcher
         pre = CouplingPrefetcher(fm, dev, workers=args.pipeline)
     elapsed, gathered = timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple, model_step,
-                                     draw, pre, args.pipeline, dev)
+                                     draw, pre, args.pipeline, dev, args.group, couple_group)
     if pre is not None:
         pre.close()
     assert gathered is None or gathered.shape[0] == world * B
@@ -565,8 +599,12 @@ def main():
                                "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd (fp32-MFMA HIP kernels) + fused Adam (HIP)"
                                + ("; one all-gather of the final x_t over RCCL inside the timed region" if world > 1 else ""),
                    "batch_per_gpu": B, "dim": d, "mlp_width": args.width, "mode": args.mode, "model_step": args.model_step,
-                   "schedule": (f"couplings of the next {args.pipeline} batch(es) in flight on side streams during "
-                                "the model step" if args.pipeline else "sequential"),
+                   "schedule": ((f"{args.pipeline} prefetch job(s) in flight on side streams during the model step, "
+                                 f"each coupling {args.group} consecutive minibatch(es)"
+                                 + (" together (their assignment problems share one chain of launches: "
+                                    "cfm_assign_exact_batch_f32)" if args.group > 1 else ""))
+                                if args.pipeline else "sequential"),
+                   "prefetch_jobs": args.pipeline, "prefetch_group": args.group if args.pipeline else 0,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
         "value_sequential": (B / seq_s) if seq_s else None,
         "ms_per_step_sequential": seq_s * 1e3 if seq_s else None,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "cfm_unbalanced_sinkhorn_f64": (_i, [_vp, _i, _i, _d, _d, _i, _d, _vp, _vp, _vp, _vp]),
     "cfm_partial_entropic_f64": (_i, [_vp, _i, _i, _d, _d, _i, _d, _vp, _vp, _vp, _vp]),
     "cfm_assign_exact_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cfm_assign_exact_batch_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_perm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cfm_plan_sample_dense": (_i, [_vp, _i, _i, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_pi_f64": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -3,6 +3,7 @@
 
 extern "C" size_t cfm_sk_ws_bytes_internal(int B0, int B1);
 extern "C" size_t cfm_asg_ws_bytes_internal(int n);
+extern "C" size_t cfm_assign_batch_ws_bytes_internal(int n, int nb);
 extern "C" size_t cfm_sd_ws_bytes_internal(int B0, int B1);
 extern "C" size_t cfm_mlp_ws_bytes_internal(int B, int width);
 extern "C" size_t cfm_ode_ws_bytes_internal(int B, int width, int d);
@@ -16,7 +17,9 @@ extern "C" size_t cfm_workspace_bytes(int op, int B0, int B1, int d) {
     if (B0 < 0 || B1 < 0) return 0;
     switch (op) {
         case CFM_OP_SINKHORN: return cfm_align_up(cfm_sk_ws_bytes_internal(B0, B1), 256);
-        case CFM_OP_ASSIGN: return cfm_align_up(cfm_asg_ws_bytes_internal(B0 > B1 ? B0 : B1), 256);
+        case CFM_OP_ASSIGN:          // d > 1: a batch of d problems (cfm_assign_exact_batch_f32)
+            return d > 1 ? cfm_align_up(cfm_assign_batch_ws_bytes_internal(B0 > B1 ? B0 : B1, d), 256)
+                         : cfm_align_up(cfm_asg_ws_bytes_internal(B0 > B1 ? B0 : B1), 256);
         case CFM_OP_SAMPLE_DENSE: return cfm_align_up(cfm_sd_ws_bytes_internal(B0, B1), 256);
         case CFM_OP_MLP: return cfm_align_up(cfm_mlp_ws_bytes_internal(B0, B1), 256);
         case CFM_OP_ODE: return cfm_align_up(cfm_ode_ws_bytes_internal(B0, B1, d), 256);

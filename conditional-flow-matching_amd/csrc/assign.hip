@@ -237,6 +237,22 @@ __device__ __forceinline__ SList slist(const AsgWs& w, int c) {
     return L;
 }
 
+// Batched solves: problem b of a batch lives in the same carving, `stride` bytes further on.  The kernels receive the
+// carving of problem 0 and the stride; blockIdx.y is the problem (uniform: the adds are scalar).
+__device__ __forceinline__ AsgWs asg_shift(const AsgWs& w0, size_t off) {
+    if (off == 0) return w0;
+    AsgWs w;
+#define ASG_SH(f) w.f = reinterpret_cast<decltype(w.f)>(reinterpret_cast<char*>(w0.f) + off)
+    ASG_SH(st); ASG_SH(arrive_sub); ASG_SH(auc); ASG_SH(p); ASG_SH(bidval); ASG_SH(dist); ASG_SH(key);
+    ASG_SH(a); ASG_SH(owner); ASG_SH(bidcol); ASG_SH(listA); ASG_SH(listF); ASG_SH(listFC); ASG_SH(pred); ASG_SH(tcol);
+    ASG_SH(grp_ticket); ASG_SH(part_d); ASG_SH(part_i); ASG_SH(part_r); ASG_SH(cT);
+    ASG_SH(S[0].col); ASG_SH(S[0].row); ASG_SH(S[0].base); ASG_SH(S[0].rj); ASG_SH(S[0].root);
+    ASG_SH(S[1].col); ASG_SH(S[1].row); ASG_SH(S[1].base); ASG_SH(S[1].rj); ASG_SH(S[1].root);
+    w.cl = w0.cl ? reinterpret_cast<uint2*>(reinterpret_cast<char*>(w0.cl) + off) : nullptr;
+#undef ASG_SH
+    return w;
+}
+
 #ifndef MS_YMAX
 #define MS_YMAX 4
 #endif
@@ -1203,8 +1219,9 @@ __device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode
 // ONE wide kernel for every chip-wide step (modes UMIN0 .. CERT): the host replays it without knowing
 // which step comes next.  LDS (modes are exclusive): bid rounds — prices [n] fp64 + owner rows [n]
 // int; relax — 16 KiB of merge buffers; MS_FINISH — 2 n ints for the path walks; the rest < 8 KiB.
-__global__ __launch_bounds__(WT) void asg_step(AsgWs w, int n_host, int par) {
+__global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, size_t stride) {
     extern __shared__ __attribute__((aligned(16))) char step_lds[];
+    const AsgWs w = asg_shift(w0, stride * blockIdx.y);
     __shared__ int sh[32];
     __shared__ double shd[32];
     __shared__ int shi[32];
@@ -1321,8 +1338,9 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w, int n_host, int par) {
 }
 
 // ---------------------------------------------------------------- build ------
-__global__ __launch_bounds__(SP_BUILD_WAVES * 64) void asg_build(AsgWs w, int n_host) {
+__global__ __launch_bounds__(SP_BUILD_WAVES * 64) void asg_build(AsgWs w0, int n_host, size_t stride) {
     extern __shared__ __attribute__((aligned(16))) char build_lds[];
+    const AsgWs w = asg_shift(w0, stride * blockIdx.y);
     __shared__ int sh_flag[4];
     AsgState* st = w.st;
     const int mode = st->mode;
@@ -1333,8 +1351,9 @@ __global__ __launch_bounds__(SP_BUILD_WAVES * 64) void asg_build(AsgWs w, int n_
 }
 
 // --------------------------------------------------------------- solver ------
-__global__ __launch_bounds__(SP_T) void asg_solve(AsgWs w, int n_host) {
+__global__ __launch_bounds__(SP_T) void asg_solve(AsgWs w0, int n_host, size_t stride) {
     extern __shared__ __attribute__((aligned(16))) char solve_lds[];
+    const AsgWs w = asg_shift(w0, stride * blockIdx.y);
     AsgState* st = w.st;
     const int mode = st->mode;
     gfp M = ASG_GLOBAL(st->Mptr);
@@ -1369,7 +1388,7 @@ __global__ void asg_trivial(const float* M, int n, int* perm, int* certified, do
 //   PRG_CHUNK  `chunk` x asg_step, asg_build, asg_solve, 2 x asg_step   (polled; progresses from any state)
 enum { PRG_CHUNK = 0, PRG_BULK = 1, PRG_COUNT = 2 };
 struct AsgGraph {
-    void* ws = nullptr; int n = 0, chunk = 0, bulk = 0, blocks = 0, sparse = 0;
+    void* ws = nullptr; int n = 0, nb = 0, chunk = 0, bulk = 0, blocks = 0, sparse = 0;
     hipGraphExec_t exec[PRG_COUNT] = {nullptr, nullptr};
     hipStream_t stream = nullptr; int disabled = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1406,44 +1425,67 @@ extern "C" void cfm_assign_debug_fallback(int* out2) { out2[0] = g_fallback[0]; 
 extern "C" void cfm_assign_debug_small(int* out16) { for (int q = 0; q < 16; ++q) out16[q] = g_small_last[q]; }
 
 struct AsgLaunch {
-    AsgWs w; int n, blocks; size_t lds_step, lds_build, lds_solve; int sparse; hipStream_t s;
+    AsgWs w; int n, blocks, nb; size_t stride; size_t lds_step, lds_build, lds_solve; int sparse; hipStream_t s;
     // every program holds an EVEN number of asg_step launches and starts on an even launch count, so the parity
-    // argument (which control record a bid round reads, see AucCtl) is the position inside the program
-    void step(int par) const { hipLaunchKernelGGL(asg_step, dim3(blocks), dim3(WT), lds_step, s, w, n, par & 1); }
+    // argument (which control record a bid round reads, see AucCtl) is the position inside the program.
+    // grid.y = the problems of a batch (one carving each, `stride` bytes apart)
+    void step(int par) const { hipLaunchKernelGGL(asg_step, dim3(blocks, nb), dim3(WT), lds_step, s, w, n, par & 1, stride); }
     void program(int prg, int chunk, int bulk) const {
         int k = 0;
         if (prg == PRG_BULK) { for (int c = 0; c < bulk; ++c) step(k++); return; }
         for (int c = 0; c < chunk; ++c) step(k++);
         if (sparse) {
-            hipLaunchKernelGGL(asg_build, dim3(blocks), dim3(SP_BUILD_WAVES * 64), lds_build, s, w, n);
-            hipLaunchKernelGGL(asg_solve, dim3(1), dim3(SP_T), lds_solve, s, w, n);
+            hipLaunchKernelGGL(asg_build, dim3(blocks, nb), dim3(SP_BUILD_WAVES * 64), lds_build, s, w, n, stride);
+            hipLaunchKernelGGL(asg_solve, dim3(1, nb), dim3(SP_T), lds_solve, s, w, n, stride);
             step(k++); step(k++);      // certificate + whatever the guess missed
         }
     }
     int count(int prg, int chunk, int bulk) const { return prg == PRG_BULK ? bulk : chunk + (sparse ? 4 : 0); }
 };
 
-static int asg_run(const float* M, int B, int* perm, int* certified, double* total_cost, int* stats,
-                   void* ws, void* stream, const AsgParams& P, int use_sparse, int* cert_out) {
-    if (!M || !perm || B < 0 || (B > 1 && !ws)) return CFM_EINVAL;
+// the first 64 bytes of every problem's state block, gathered for ONE copy to the host
+__global__ void asg_collect(const AsgState* st0, size_t stride, int nb, int* out) {
+    const int b = threadIdx.x >> 4, q = threadIdx.x & 15;
+    if (b < nb) out[16 * b + q] = reinterpret_cast<const int*>(reinterpret_cast<const char*>(st0) + stride * b)[q];
+}
+
+struct AsgProblem { const float* M; int* perm; int* certified; double* total_cost; int* stats; };
+#define ASG_BATCH_MAX 16
+#define ASG_PINNED_INTS (2 * ASG_BATCH_MAX * 16)
+
+static int asg_pinned() {
+    if (g_pinned) return 0;
+    return cfm_hip(hipHostMalloc((void**)&g_pinned, ASG_PINNED_INTS * sizeof(int), hipHostMallocDefault));
+}
+
+// Solves nb problems of the same size on one chain of launches (grid.y = problem).  cert_out[b] / err_out[b]: the
+// certificate and the device error code of problem b (0 = none).  nb == 1: the plain solve.
+static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride, void* stream, const AsgParams& P,
+                   int use_sparse, int* cert_out, int* err_out) {
+    if (!pr || nb < 1 || nb > ASG_BATCH_MAX || B < 0 || (B > 1 && !ws)) return CFM_EINVAL;
+    for (int b = 0; b < nb; ++b) if (!pr[b].M || !pr[b].perm) return CFM_EINVAL;
     if (B > (1 << 20)) return CFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    for (int b = 0; b < nb; ++b) { cert_out[b] = 1; err_out[b] = 0; }
     if (B == 0) return 0;
     if (B == 1) {
-        hipLaunchKernelGGL(asg_trivial, dim3(1), dim3(64), 0, s, M, B, perm, certified, total_cost, stats);
+        for (int b = 0; b < nb; ++b)
+            hipLaunchKernelGGL(asg_trivial, dim3(1), dim3(64), 0, s, pr[b].M, B, pr[b].perm, pr[b].certified, pr[b].total_cost, pr[b].stats);
         return cfm_status();
     }
-    if (((uintptr_t)ws & 15) != 0 || ((uintptr_t)M & 15) != 0) return CFM_EALIGN;
+    if (((uintptr_t)ws & 15) != 0 || (stride & 15) != 0) return CFM_EALIGN;
+    for (int b = 0; b < nb; ++b) if (((uintptr_t)pr[b].M & 15) != 0) return CFM_EALIGN;
     const int n = B;
     AsgLaunch L;
-    L.w = asg_carve(ws, n); L.n = n; L.s = s;
-    if (!g_pinned) {
-        int rc = cfm_hip(hipHostMalloc((void**)&g_pinned, 256, hipHostMallocDefault));
-        if (rc) return rc;
-    }
+    L.w = asg_carve(ws, n); L.n = n; L.s = s; L.nb = nb; L.stride = nb > 1 ? stride : 0;
+    int rc = asg_pinned();
+    if (rc) return rc;
     int wide_blocks = (n + 15) / 16;        // one wave per row when everything bids
     if (wide_blocks > 512) wide_blocks = 512;
     if (P.wide_blocks_cap > 0 && wide_blocks > P.wide_blocks_cap) wide_blocks = P.wide_blocks_cap;
+    // a batch shares the chip: 512 resident workgroups in all (every workgroup of a bid round stages the prices whether
+    // its rows bid or not; measured at n = 4096: 8 problems 9.1 ms with 256 workgroups each, 6.5 ms with 64)
+    if (nb > 1 && wide_blocks > 512 / nb) wide_blocks = 512 / nb;
     if (wide_blocks < (n + 63) / 64) wide_blocks = (n + 63) / 64;
     if (wide_blocks < 1) wide_blocks = 1;
     L.blocks = wide_blocks;
@@ -1459,27 +1501,29 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
     L.sparse = (use_sparse && n <= SP_NMAX && (raised & 2)) ? 1 : 0;
     L.lds_build = sp_build_lds_bytes(n); L.lds_solve = sp_solver_lds_bytes(n);
 
-    AsgState h;
-    memset(&h, 0, sizeof(h));
-    h.wide_blocks = wide_blocks;
-    h.mode = MODE_UMIN0; h.n = n; h.Mptr = M;
-    h.out_perm = perm; h.out_cert = certified; h.out_cost = total_cost; h.out_stats = stats;
-    h.eps = P.eps0_frac; h.eps_last = P.eps_last_frac; h.theta = P.theta;
-    h.stop_frac = P.stop_frac; h.round_cap = P.round_cap; h.arr_cap = P.arr_cap;
-    h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
-    h.fr_min = ~0ull; h.fr_max = 0ull;
-    h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early;
-    h.tag = 1;
-    { int rb = 1; while ((1 << rb) <= n) ++rb; h.rb = rb; }     // row ids 0 .. n-1 and the all-ones "none"
-    hipLaunchKernelGGL(asg_init, dim3(1), dim3(64), 0, s, L.w, h);
-    int rc = cfm_status();
+    for (int b = 0; b < nb; ++b) {
+        AsgState h;
+        memset(&h, 0, sizeof(h));
+        h.wide_blocks = wide_blocks;
+        h.mode = MODE_UMIN0; h.n = n; h.Mptr = pr[b].M;
+        h.out_perm = pr[b].perm; h.out_cert = pr[b].certified; h.out_cost = pr[b].total_cost; h.out_stats = pr[b].stats;
+        h.eps = P.eps0_frac; h.eps_last = P.eps_last_frac; h.theta = P.theta;
+        h.stop_frac = P.stop_frac; h.round_cap = P.round_cap; h.arr_cap = P.arr_cap;
+        h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
+        h.fr_min = ~0ull; h.fr_max = 0ull;
+        h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early;
+        h.tag = 1;
+        { int rb = 1; while ((1 << rb) <= n) ++rb; h.rb = rb; }     // row ids 0 .. n-1 and the all-ones "none"
+        hipLaunchKernelGGL(asg_init, dim3(1), dim3(64), 0, s, asg_carve((char*)ws + (size_t)b * L.stride, n), h);
+    }
+    rc = cfm_status();
     if (rc) return rc;
 
     const int chunk = ((P.chunk > 0 ? P.chunk : 10) + 1) & ~1;        // even: see AsgLaunch::step
     const int bulk = ((n >= P.bulk_min_n) ? P.bulk : 0) & ~1;
     AsgGraph& G = g_graph;
     bool use_graph = asg_graph_enabled() && !G.disabled && n >= 256;
-    if (use_graph && !(G.exec[0] && G.ws == ws && G.n == n && G.chunk == chunk && G.bulk == bulk &&
+    if (use_graph && !(G.exec[0] && G.ws == ws && G.n == n && G.nb == nb && G.chunk == chunk && G.bulk == bulk &&
                        G.blocks == wide_blocks && G.sparse == L.sparse && G.stream == s)) {
         for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
         hipError_t e = hipSuccess;
@@ -1500,7 +1544,7 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
             for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
             G.disabled = 1; use_graph = false;     // e.g. the legacy default stream
         } else {
-            G.ws = ws; G.n = n; G.chunk = chunk; G.bulk = bulk; G.blocks = wide_blocks;
+            G.ws = ws; G.n = n; G.nb = nb; G.chunk = chunk; G.bulk = bulk; G.blocks = wide_blocks;
             G.sparse = L.sparse; G.stream = s;
         }
     }
@@ -1516,55 +1560,82 @@ static int asg_run(const float* M, int B, int* perm, int* certified, double* tot
         L.program(prg, chunk, bulk);
         return cfm_status();
     };
-    // The head goes out unpolled (a solve at n = 4096 takes ~180 steps before the list solver); the rest
-    // in chunks that make progress from any state, each followed by a 64-byte copy of the state into
-    // its own pinned slot and an event, with the NEXT chunk already queued when the host waits for a
-    // slot: no idle gap.  A kernel that does not own the current mode is a ~2 us no-op.
+    // The head goes out unpolled (a solve at n = 4096 takes ~100 steps before the list solver); the rest
+    // in chunks that make progress from any state, each followed by a copy of the first 64 bytes of every
+    // problem's state into its own pinned slot and an event, with the NEXT chunk already queued when the host
+    // waits for a slot: no idle gap.  A kernel that does not own the current mode is a ~2 us no-op.
     rc = run(PRG_BULK); if (rc) return rc;
     int cur = 0;
+    int* stage = reinterpret_cast<int*>((char*)ws + (size_t)nb * stride);      // batches: 2 x nb x 64 bytes behind the carvings
     auto issue = [&](int slot) -> int {
         int r2 = run(PRG_CHUNK); if (r2) return r2;
-        r2 = cfm_hip(hipMemcpyAsync(g_pinned + 16 * slot, L.w.st, 64, hipMemcpyDeviceToHost, s)); if (r2) return r2;
+        int* host = g_pinned + 16 * ASG_BATCH_MAX * slot;
+        if (nb == 1) r2 = cfm_hip(hipMemcpyAsync(host, L.w.st, 64, hipMemcpyDeviceToHost, s));
+        else {
+            hipLaunchKernelGGL(asg_collect, dim3(1), dim3(16 * ASG_BATCH_MAX), 0, s, L.w.st, L.stride, nb, stage + 16 * nb * slot);
+            r2 = cfm_status();
+            if (!r2) r2 = cfm_hip(hipMemcpyAsync(host, stage + 16 * nb * slot, 64 * (size_t)nb, hipMemcpyDeviceToHost, s));
+        }
+        if (r2) return r2;
         return cfm_hip(hipEventRecord(G.ev[slot], s));
     };
     rc = issue(0); if (rc) return rc;
+    int result = 0;
     for (;;) {
         rc = issue(cur ^ 1); if (rc) return rc;
         rc = cfm_hip(hipEventSynchronize(G.ev[cur])); if (rc) return rc;
-        const int* hs = g_pinned + 16 * cur;
-        const int mode = hs[0], err = hs[2];
-        if (err) { g_fallback[1] = err; return CFM_ENOCONV; }
-        if (mode == MODE_DONE) { if (cert_out) *cert_out = hs[3]; break; }
-        if (launched >= P.max_launches) return CFM_ETIMEOUT;
+        const int* hs = g_pinned + 16 * ASG_BATCH_MAX * cur;
+        int open_ = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int mode = hs[16 * b + 0], err = hs[16 * b + 2];
+            if (err) err_out[b] = err;                        // this problem stopped (its launches are no-ops now)
+            else if (mode == MODE_DONE) cert_out[b] = hs[16 * b + 3];
+            else ++open_;
+        }
+        if (!open_) break;
+        if (launched >= P.max_launches) { result = CFM_ETIMEOUT; break; }
         cur ^= 1;
     }
     // the look-ahead chunk is still in flight: it is a string of no-ops on a finished state, but the
     // workspace (and the pinned slot it copies into) must not be reused under it
     rc = cfm_hip(hipEventSynchronize(G.ev[cur ^ 1]));
+    return rc ? rc : result;
+}
+
+// one problem through the candidate-list machine, the dense state machine deciding should its certificate ever fail
+static int asg_solve_one(const AsgProblem& pr, int B, void* ws, void* stream, const AsgParams& P, int first_sparse) {
+    int cert = 1, err = 0;
+    int rc = asg_run(&pr, 1, B, ws, 0, stream, P, first_sparse, &cert, &err);
+    if (rc) return rc;
+    if (err) { g_fallback[1] = err; rc = CFM_ENOCONV; }
+    if (first_sparse && B > 1 && B <= SP_NMAX && (rc == CFM_ENOCONV || !cert)) {
+        ++g_fallback[0];
+        if (rc == 0) g_fallback[1] = -1;          // uncertified
+        rc = asg_run(&pr, 1, B, ws, 0, stream, P, 0, &cert, &err);
+        if (rc == 0 && err) { g_fallback[1] = err; rc = CFM_ENOCONV; }
+    }
+    if (rc == 0 && B > 1 && !cert) rc = CFM_ENOCONV;     // never hand back an uncertified permutation silently
     return rc;
 }
 
 extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,
                                     double* total_cost, int* stats, void* ws, void* stream) {
     const AsgParams P = asg_params_snapshot();
-    int cert = 1;
     if (P.small && B >= 2 && B <= SMA_N) {
         // one workgroup, one launch; a solve that hits its round caps or fails its certificate reports it and
         // the chip-wide state machine below takes over
         if (!M || !perm || !ws) return CFM_EINVAL;
         if (((uintptr_t)ws & 15) != 0) return CFM_EALIGN;
         hipStream_t s = (hipStream_t)stream;
-        if (!g_pinned) {
-            int rc0 = cfm_hip(hipHostMalloc((void**)&g_pinned, 256, hipHostMallocDefault));
-            if (rc0) return rc0;
-        }
+        int rc0 = asg_pinned();
+        if (rc0) return rc0;
         SmaParams Q;
         Q.theta = P.theta; Q.eps0_frac = P.eps0_frac; Q.eps_last_frac = P.eps_last_frac;
         Q.stop_frac = P.stop_frac;
         Q.round_cap = P.round_cap; Q.arr_cap = P.arr_cap > 15 ? P.arr_cap : 15; Q.total_cap = 20000;   // (the one-workgroup solver was tuned with 15)
         Q.bid_cap = P.small >= 2 ? P.small - 1 : 1;      // cfm_assign_set_small(k >= 2): k - 1 bids per wave and round
         int* status = (int*)ws;
-        int rc0 = cfm_hip(hipMemsetAsync(status, 0, 64, s));
+        rc0 = cfm_hip(hipMemsetAsync(status, 0, 64, s));
         if (rc0) return rc0;
         if (certified) { rc0 = cfm_hip(hipMemsetAsync(certified, 0, sizeof(int), s)); if (rc0) return rc0; }
         hipLaunchKernelGGL(asg_small, dim3(1), dim3(SMA_T), 0, s, M, B, Q, perm, certified, total_cost, stats, status);
@@ -1577,14 +1648,48 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
         for (int q = 0; q < 16; ++q) g_small_last[q] = g_pinned[q];
         if (g_pinned[0] == 1) return 0;
     }
-    int rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, P, P.sparse, &cert);
-    // The candidate-list path is exact by construction; should its certificate ever fail
-    // (or its solver report an inconsistency) the dense state machine decides.
-    if (P.sparse && B > 1 && B <= SP_NMAX && (rc == CFM_ENOCONV || (rc == 0 && !cert))) {
-        ++g_fallback[0];
-        if (rc == 0) g_fallback[1] = -1;          // uncertified
-        rc = asg_run(M, B, perm, certified, total_cost, stats, ws, stream, P, 0, &cert);
+    if (!M || !perm) return CFM_EINVAL;
+    const AsgProblem pr = {M, perm, certified, total_cost, stats};
+    return asg_solve_one(pr, B, ws, stream, P, P.sparse);
+}
+
+// nb problems of the same size in ONE chain of launches: every launch carries all problems (grid.y), so the
+// latency-bound chain — ~110 launch boundaries, a one-workgroup list solver — is paid once per batch.  A problem
+// whose candidate-list path stops or ends uncertified is redone alone on the dense state machine, like a single solve.
+extern "C" size_t cfm_assign_batch_ws_bytes_internal(int n, int nb) {
+    if (nb > ASG_BATCH_MAX) nb = ASG_BATCH_MAX;       // longer lists go through in groups of ASG_BATCH_MAX
+    return (size_t)nb * cfm_align_up(asg_ws_bytes(n), 256) + 2 * 64 * (size_t)ASG_BATCH_MAX + 256;
+}
+
+extern "C" int cfm_assign_exact_batch_f32(const float* const* M, int nb, int B, int* const* perm, int* certified,
+                                          double* total_cost, int* stats, void* ws, void* stream) {
+    if (!M || !perm || nb < 0) return CFM_EINVAL;
+    if (nb == 0) return 0;
+    const AsgParams P = asg_params_snapshot();
+    const size_t stride = cfm_align_up(asg_ws_bytes(B), 256);
+    int rc = 0;
+    for (int b0 = 0; b0 < nb && rc == 0; b0 += ASG_BATCH_MAX) {
+        const int k = nb - b0 < ASG_BATCH_MAX ? nb - b0 : ASG_BATCH_MAX;
+        AsgProblem pr[ASG_BATCH_MAX];
+        int cert[ASG_BATCH_MAX], err[ASG_BATCH_MAX];
+        for (int b = 0; b < k; ++b) {
+            if (!M[b0 + b] || !perm[b0 + b]) return CFM_EINVAL;
+            pr[b] = {M[b0 + b], perm[b0 + b], certified ? certified + b0 + b : nullptr,
+                     total_cost ? total_cost + b0 + b : nullptr, stats ? stats + 8 * (size_t)(b0 + b) : nullptr};
+        }
+        const bool machine = !(P.small && B >= 2 && B <= SMA_N) && B > 1 && k > 1;
+        if (!machine) {               // single problems and the one-workgroup sizes: one after the other
+            for (int b = 0; b < k && rc == 0; ++b)
+                rc = cfm_assign_exact_f32(pr[b].M, B, pr[b].perm, pr[b].certified, pr[b].total_cost, pr[b].stats, ws, stream);
+            continue;
+        }
+        rc = asg_run(pr, k, B, ws, stride, stream, P, P.sparse, cert, err);
+        for (int b = 0; b < k && rc == 0; ++b) {
+            if (!err[b] && cert[b]) continue;
+            if (!(P.sparse && B <= SP_NMAX)) { rc = CFM_ENOCONV; break; }
+            ++g_fallback[0]; g_fallback[1] = err[b] ? err[b] : -1;
+            rc = asg_solve_one(pr[b], B, (char*)ws + (size_t)b * stride, stream, P, 0);
+        }
     }
-    if (rc == 0 && B > 1 && !cert) rc = CFM_ENOCONV;     // never hand back an uncertified permutation silently
     return rc;
 }

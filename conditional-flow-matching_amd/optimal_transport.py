@@ -99,6 +99,41 @@ def assign_exact(M, return_info=False):
     return (perm, info) if return_info else perm
 
 
+def assign_exact_batch(Ms, return_info=False):
+    """Optimal permutations of several square fp32 cost matrices of the SAME size, solved together: every launch of the
+    latency-bound solve carries all of them (cfm_assign_exact_batch_f32), so nb couplings cost little more than one.
+    `Ms`: a list of [B,B] tensors or one [nb,B,B] tensor.  Returns an int32 [nb,B] tensor (row b = assign_exact(Ms[b]))."""
+    import ctypes
+    lib = _lib.load()
+    Ms = [m for m in Ms]
+    nb = len(Ms)
+    if nb == 0:
+        raise ValueError("assign_exact_batch needs at least one cost matrix")
+    B = Ms[0].shape[0]
+    dev = Ms[0].device
+    for m in Ms:
+        if m.dim() != 2 or m.shape[0] != B or m.shape[1] != B:
+            raise NotImplementedError("assign_exact_batch needs square cost matrices of one size; got "
+                                      f"{[tuple(x.shape) for x in Ms]}")
+        if m.device != dev or m.dtype != torch.float32 or not m.is_contiguous():
+            raise ValueError("assign_exact_batch: contiguous fp32 matrices on one device")
+    perm = torch.empty((nb, B), dtype=torch.int32, device=dev)
+    cert = torch.empty(nb, dtype=torch.int32, device=dev)
+    tot = torch.empty(nb, dtype=torch.float64, device=dev)
+    stats = torch.empty((nb, 8), dtype=torch.int32, device=dev)
+    ws = _lib.workspace(_lib.OP_ASSIGN, B, B, nb, dev)
+    m_ptrs = (ctypes.c_void_p * nb)(*[m.data_ptr() for m in Ms])
+    p_ptrs = (ctypes.c_void_p * nb)(*[perm[b].data_ptr() for b in range(nb)])
+    check(lib.cfm_assign_exact_batch_f32(m_ptrs, nb, B, p_ptrs, ptr(cert), ptr(tot), ptr(stats), ptr(ws),
+                                         stream_ptr()), "cfm_assign_exact_batch_f32")
+    if not return_info:
+        return perm
+    c, st, t = cert.cpu(), stats.cpu(), tot.cpu()
+    if B > 0 and not bool((c == 1).all()):
+        raise CfmBackendError("exact assignment finished without an optimality certificate")
+    return perm, [{"certified": True, "total_cost": float(t[b]), "stats": st[b].tolist()} for b in range(nb)]
+
+
 # largest lcm(B0, B1) the rectangular exact path expands to.  The expanded problem repeats every row L/B0 and every
 # column L/B1 times: it is massively tied, which is the slow regime of every assignment solver (127 x 128 -> L = 16256
 # was measured at ~200 s on MI355X), so the bound is a usability bound, not a memory bound.

@@ -58,6 +58,28 @@ class CouplingPrefetcher:
         drawn = draw() if draw is not None else None
         return _Handle(self._pool.submit(self._work, x0, x1, ready, hook, drawn), self.device)
 
+    def submit_group(self, batches, hook, draw=None):
+        """Several minibatches as ONE job: ``hook(batches, drawn_list)`` couples them together (the exact solver takes a
+        batch of problems in one chain of launches, ``optimal_transport.assign_exact_batch``) and returns one result
+        tuple per minibatch, in order.  ``draw()`` runs once per minibatch, now, on the calling thread."""
+        ready = None
+        if self.device.type == "cuda":
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+        drawn = [draw() if draw is not None else None for _ in batches]
+        return _Handle(self._pool.submit(self._work_group, list(batches), ready, hook, drawn), self.device)
+
+    def _work_group(self, batches, ready, hook, drawn):
+        if self.device.type != "cuda":
+            return hook(batches, drawn), None
+        stream = self._stream()
+        with torch.cuda.stream(stream):
+            stream.wait_event(ready)
+            out = hook(batches, drawn)
+            done = torch.cuda.Event()
+            done.record(stream)
+        return out, done
+
     def close(self):
         self._pool.shutdown(wait=True)
 
@@ -72,7 +94,12 @@ class _Handle:
             return out
         cur = torch.cuda.current_stream(self._device)
         cur.wait_event(done)
-        for t in out:
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                t.record_stream(cur)
+        def mark(o):
+            if isinstance(o, torch.Tensor):
+                if o.is_cuda:
+                    o.record_stream(cur)
+            elif isinstance(o, (list, tuple)):
+                for x in o:
+                    mark(x)
+        mark(out)
         return out

@@ -176,6 +176,18 @@ int cfm_partial_entropic_f64(const float* M, int B0, int B1, double reg, double 
 int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,
                          double* total_cost, int* stats, void* ws, void* stream);
 
+/* K4, batched — nb independent assignment problems of the same size B in ONE chain of launches.
+ * The reference couples one minibatch per call (torchcfm/optimal_transport.py:87, called from
+ * conditional_flow_matching.py:271); the solve is a latency-bound chain (~110 dependent launches and a
+ * one-workgroup list solver), so the couplings of the next nb minibatches of a training loop — they depend on
+ * the data only — cost little more than one when every launch carries all of them (grid.y = problem).
+ * Results are those of nb calls of cfm_assign_exact_f32 (same kernels, same state machine per problem).
+ * M, perm: HOST arrays of nb device pointers ([B,B] fp32 / int32 [B]); certified [nb], total_cost [nb],
+ * stats [nb][8] device arrays (each may be NULL).  nb > 16 is processed in groups of 16.
+ * ws: cfm_workspace_bytes(CFM_OP_ASSIGN,B,B,nb) bytes. */
+int cfm_assign_exact_batch_f32(const float* const* M, int nb, int B, int* const* perm, int* certified,
+                               double* total_cost, int* stats, void* ws, void* stream);
+
 /* K6 (exact path) — draw n index pairs from the permutation plan.
  * Replaces sample_map()                      torchcfm/optimal_transport.py:116-121
  * for pi = P_perm / B:  np.random.choice over the flattened plan consumes n

@@ -1,0 +1,110 @@
+"""GPU: cfm_assign_exact_batch_f32 — several assignment problems of one size in one chain of launches.  Every row of the
+result must be what the single solve returns (same kernels, same per-problem state machine) and SciPy's optimum."""
+import numpy as np
+import pytest
+import torch
+
+import cfm_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _matrices(nb, B, d, seed, dev):
+    import cfm_amd.optimal_transport as ot
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(nb):
+        x0 = torch.randn(B, d, generator=g)
+        x1 = torch.randn(B, d, generator=g) * 0.6 + 0.3
+        out.append(ot.cost_matrix(x0.to(dev), x1.to(dev)))
+    return out
+
+
+@pytest.mark.parametrize("nb,B,d", [(2, 300, 2), (3, 512, 16), (4, 1024, 64), (5, 777, 3), (8, 2048, 32)])
+def test_batch_equals_single_solves_and_scipy(nb, B, d):
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    Ms = _matrices(nb, B, d, 10 * nb + B, dev)
+    perms, infos = ot.assign_exact_batch(Ms, return_info=True)
+    assert perms.shape == (nb, B) and perms.dtype == torch.int32
+    for b in range(nb):
+        single = ot.assign_exact(Ms[b])
+        assert torch.equal(perms[b], single), b
+        p = perms[b].cpu().numpy()
+        ref = oracle.exact_perm(Ms[b].cpu().numpy())
+        assert sorted(p.tolist()) == list(range(B))
+        assert infos[b]["certified"]
+        assert np.isclose(infos[b]["total_cost"], oracle.assignment_cost(Ms[b].cpu().numpy(), ref), rtol=1e-12, atol=0)
+        if not np.array_equal(p, ref):          # ties (d = 2 duplicates do not occur here, but keep the cost statement)
+            assert oracle.assignment_cost(Ms[b].cpu().numpy(), p) == pytest.approx(
+                oracle.assignment_cost(Ms[b].cpu().numpy(), ref), rel=1e-12)
+
+
+def test_batch_of_stacked_tensor_and_more_than_one_group():
+    """A [nb,B,B] tensor is accepted; nb > 16 runs in groups of 16 on the same workspace."""
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    Ms = torch.stack(_matrices(19, 320, 5, 3, dev))
+    perms = ot.assign_exact_batch(Ms)
+    for b in range(19):
+        assert np.array_equal(perms[b].cpu().numpy(), oracle.exact_perm(Ms[b].cpu().numpy())), b
+
+
+def test_batch_small_sizes_and_single_problem():
+    """B <= 256 (the one-workgroup solver) and nb = 1 go one after the other through the single solve."""
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    for nb, B in ((3, 64), (2, 256), (1, 900)):
+        Ms = _matrices(nb, B, 2, B, dev)
+        perms = ot.assign_exact_batch(Ms)
+        for b in range(nb):
+            assert np.array_equal(perms[b].cpu().numpy(), oracle.exact_perm(Ms[b].cpu().numpy())), (nb, B, b)
+
+
+def test_batch_with_tied_and_degenerate_members():
+    """Integer-valued (massively tied) and constant matrices next to a generic one: every member certified, optimal cost;
+    a member that needs the dense state machine does not disturb the others."""
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    B = 384
+    r = np.random.RandomState(5)
+    mats = [r.randint(0, 4, (B, B)).astype(np.float32), np.full((B, B), 2.5, np.float32),
+            r.rand(B, B).astype(np.float32), (r.randint(0, 50, (B, 1)) + r.randint(0, 50, (1, B))).astype(np.float32)]
+    Ms = [torch.from_numpy(m).to(dev) for m in mats]
+    perms, infos = ot.assign_exact_batch(Ms, return_info=True)
+    for b, m in enumerate(mats):
+        p = perms[b].cpu().numpy()
+        assert sorted(p.tolist()) == list(range(B))
+        assert oracle.assignment_cost(m, p) == pytest.approx(oracle.assignment_cost(m, oracle.exact_perm(m)), rel=1e-12, abs=1e-9)
+
+
+def test_batch_c3_full_size_four_problems():
+    """Four C3-sized couplings (B = 4096, d = 784) at once: indices bit-equal to the single solves."""
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    Ms = []
+    for k in range(4):
+        x0, x1 = oracle.config_inputs("C3", rank=k)
+        Ms.append(ot.cost_matrix(x0.to(dev), x1.to(dev)))
+    perms = ot.assign_exact_batch(Ms)
+    for b in range(4):
+        assert torch.equal(perms[b], ot.assign_exact(Ms[b])), b
+    assert not torch.equal(perms[0], perms[1])
+
+
+def test_batch_argument_checks():
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    a = torch.rand(300, 300, device=dev); b = torch.rand(301, 301, device=dev)
+    with pytest.raises(NotImplementedError):
+        ot.assign_exact_batch([a, b])
+    with pytest.raises(ValueError):
+        ot.assign_exact_batch([])
+    with pytest.raises(ValueError):
+        ot.assign_exact_batch([a, a.double()])

@@ -73,3 +73,45 @@ def test_several_in_flight_with_draws_on_the_caller(dev):
     for r, g in zip(ref, got):
         for x, y in zip(r, g):
             assert torch.equal(x, y)
+
+
+def test_grouped_couplings_equal_the_sequential_ones(dev):
+    """submit_group: G minibatches coupled together (assign_exact_batch: one chain of launches for the G assignment
+    problems) give, minibatch by minibatch, exactly what coupling them one after the other gives."""
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd.conditional_flow_matching import ExactOptimalTransportConditionalFlowMatcher
+    from cfm_amd.prefetch import CouplingPrefetcher
+    fm = ExactOptimalTransportConditionalFlowMatcher(sigma=0.0)
+    B = 640
+    data = _batches(10, B, 24, dev)
+
+    def draw():
+        return np.random.random_sample(B), torch.rand(B)
+
+    def couple(x0, x1, drawn):
+        u, t = drawn
+        perm = ot.assign_exact(ot.cost_matrix(x0, x1))
+        i, j = ot.sample_perm(perm, torch.from_numpy(u).to(dev), B)
+        return fm._sample(x0, x1, t.type_as(x0), False, idx=(i, j))
+
+    def couple_group(batches, drawn):
+        perms = ot.assign_exact_batch([ot.cost_matrix(a, b) for a, b in batches])
+        out = []
+        for (a, b), (u, t), perm in zip(batches, drawn, perms):
+            i, j = ot.sample_perm(perm, torch.from_numpy(u).to(dev), B)
+            out.append(fm._sample(a, b, t.type_as(a), False, idx=(i, j)))
+        return out
+
+    torch.manual_seed(5); np.random.seed(5)
+    ref = [couple(a, b, draw()) for a, b in data]
+    torch.manual_seed(5); np.random.seed(5)
+    pre = CouplingPrefetcher(fm, dev, workers=2)
+    handles = [pre.submit_group(data[0:4], couple_group, draw), pre.submit_group(data[4:8], couple_group, draw),
+               pre.submit_group(data[8:10], couple_group, draw)]
+    got = [r for h in handles for r in h.result()]
+    pre.close()
+    torch.cuda.synchronize()
+    assert len(got) == len(ref)
+    for r, g in zip(ref, got):
+        for x, y in zip(r, g):
+            assert torch.equal(x, y)
