@@ -499,19 +499,70 @@ __device__ __forceinline__ void bid_commit(gfp M, const AsgWs& w, Top2 best, int
 
 // One wave per row; a row bids iff it is unmatched.  pre_bc = bidcol of the wave's first row,
 // requested with the keys in the kernel prologue.  Returns the number of bids of this wave.
+#define ASG_BL 64     // entries of a bid list = SP_K: the arrays are the list solver's
+// Bid lists (n <= SP_NMAX; they live in the candidate-list arrays the list solver fills AFTER the rounds): a full row
+// scan leaves, per lane, the best column of the lane's share of the row and its cost, and T = the smallest second-best
+// of any lane — a lower bound of c + p for every column outside the list, and it stays one: prices only rise within a
+// solve.  A later bid of the row reads the 64 entries (512 bytes instead of the 4 n of the row): with b <= T the list's
+// best is the row's best, and min(second in the list, T) is a lower bound of its second best — exact when the second is
+// <= T, otherwise a smaller (still valid: any increment in [eps, second - best + eps] keeps eps-complementary
+// slackness) bid.  b > T: the row is scanned, which refreshes its list.  MODE_UMIN0 sets T = -inf (stale lists of the
+// previous solve).  Measured at C3 (tools/proto/proto22.py): 47.5 k bids, 11.7 k of them full scans.
+__device__ __forceinline__ bool bid_from_list(gfp M, const AsgWs& w, const double* p_lds, bool use_lds, uint2 e, double T,
+                                              int i, int n, double eps, int tag, int rb, int rnd) {
+    if (!(T > -INFINITY)) return false;                  // (uniform: one T per row)
+    const bool okc = e.x < (unsigned)n;
+    const int mb = rb + ASG_RND_BITS;
+    const double pj = okc ? (use_lds ? p_lds[e.x] : asg_price(w.key[e.x], mb)) : 0.0;
+    Top2 lb;
+    lb.b = okc ? (double)__uint_as_float(e.y) + pj : INFINITY;
+    lb.s = T; lb.j = okc ? (int)e.x : 0x7fffffff;
+#ifndef ASG_BL_PARTIAL
+#define ASG_BL_PARTIAL 0
+#endif
+    const double bmin = asg_wave_min_d(lb.b);
+    if (!(bmin <= T)) return false;
+    if (!ASG_BL_PARTIAL) {
+        // exact bids only: the second best of the list must be inside the bound too (min over the lanes but one winner)
+        const int jw = asg_wave_min_i(lb.b == bmin ? lb.j : 0x7fffffff);
+        const double s2 = asg_wave_min_d((lb.b == bmin && lb.j == jw) ? INFINITY : lb.b);
+        if (!(s2 <= T)) return false;
+    }
+    bid_commit(M, w, lb, i, n, eps, p_lds, use_lds, tag, rb, rnd);
+    return true;
+}
+
+// the list a full scan leaves behind (after the bid went out: off the round's critical path)
+__device__ __forceinline__ void bid_list_store(gfp M, const AsgWs& w, const Top2& best, int i, int n) {
+    const double T = asg_wave_min_d(best.s);
+    const bool okc = best.j != 0x7fffffff;
+    const float c = okc ? M[(size_t)i * n + best.j] : 0.f;
+    w.cl[(size_t)i * ASG_BL + (threadIdx.x & 63)] = make_uint2(okc ? (unsigned)best.j : 0xffffffffu, __float_as_uint(c));
+    if ((threadIdx.x & 63) == 0) w.cT[i] = T;
+}
+
 __device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_lds, const int* r_lds,
-                                        int wave_gid, int n_waves, int pre_bc, bool stage_p, int n,
+                                        int wave_gid, int n_waves, int pre_bc, uint2 pre_e, double pre_T, bool stage_p, int n,
                                         double eps, int tag, int rb, int rnd) {
     const int lane = threadIdx.x & 63;
     const bool vec = ((n & 3) == 0);
     const bool fast = stage_p && (n & 4095) == 0;
+#ifndef ASG_BL_ON
+#define ASG_BL_ON 1
+#endif
+    const bool lists = ASG_BL_ON && (w.cl != nullptr);
     const int mb = rb + ASG_RND_BITS;
-    int nbids = 0;
+    int nbids = 0;             // low 16 bits: bids; high bits: those of them that came from the list
     int i = wave_gid;
     if (fast) {
         for (; i < n; i += n_waves) {
             const int bc = (i == wave_gid) ? pre_bc : w.bidcol[i];
             if (bid_matched(w, r_lds, true, bc, tag, i, rb)) continue;
+            if (lists) {
+                const uint2 e = (i == wave_gid) ? pre_e : w.cl[(size_t)i * ASG_BL + lane];
+                const double T = (i == wave_gid) ? pre_T : w.cT[i];
+                if (bid_from_list(M, w, p_lds, true, e, T, i, n, eps, tag, rb, rnd)) { nbids += 0x10001; continue; }
+            }
             Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
             for (int seg = 0; seg < n; seg += 4096) {
                 // the segment's 16 KB in flight at once: 16 float4 per lane
@@ -523,6 +574,7 @@ __device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_l
                 __builtin_amdgcn_sched_barrier(0);     // the next segment's loads stay behind this one's arithmetic
             }
             bid_commit(M, w, best, i, n, eps, p_lds, true, tag, rb, rnd);
+            if (lists) bid_list_store(M, w, best, i, n);
             ++nbids;
         }
         return nbids;
@@ -530,6 +582,11 @@ __device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_l
     for (; i < n; i += n_waves) {
         const int bc = (i == wave_gid) ? pre_bc : w.bidcol[i];
         if (bid_matched(w, r_lds, stage_p, bc, tag, i, rb)) continue;
+        if (lists) {
+            const uint2 e = (i == wave_gid) ? pre_e : w.cl[(size_t)i * ASG_BL + lane];
+            const double T = (i == wave_gid) ? pre_T : w.cT[i];
+            if (bid_from_list(M, w, p_lds, stage_p, e, T, i, n, eps, tag, rb, rnd)) { nbids += 0x10001; continue; }
+        }
         gfp row = M + (size_t)i * n;
         Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
         if (vec && stage_p) {
@@ -562,6 +619,7 @@ __device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_l
             for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + asg_price(w.key[j], mb), j);
         }
         bid_commit(M, w, best, i, n, eps, p_lds, stage_p, tag, rb, rnd);
+        if (lists) bid_list_store(M, w, best, i, n);
         ++nbids;
     }
     return nbids;
@@ -600,7 +658,7 @@ __device__ __forceinline__ void wide_umin0(gfp M, const AsgWs& w, AsgState* st,
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-        if (lane == 0) w.bidval[i] = (double)m;
+        if (lane == 0) { w.bidval[i] = (double)m; if (w.cl != nullptr) w.cT[i] = -INFINITY; }     // (no bid list yet)
         lo = fminf(lo, m);
     }
 #pragma unroll
@@ -903,6 +961,7 @@ __device__ __forceinline__ void wide_cert(gfp M, const AsgWs& w, AsgState* st, i
 }
 
 #include "assign_sparse.h"
+static_assert(SP_K == ASG_BL, "the bid lists use the list solver's arrays");
 #include "assign_small.h"
 static_assert(SP_ROOTS == 64, "the hand-off threshold (cfm_assign_set_handoff) is capped at the solver's root slots");
 
@@ -1243,9 +1302,11 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
         kst3 = *reinterpret_cast<const ulonglong2*>(w.key + (j3 < nn ? j3 : 0));
     }
     int pre_bc = (wave_gid < n_host) ? w.bidcol[wave_gid] : -1;
+    uint2 pre_e = make_uint2(0xffffffffu, 0u); double pre_T = -INFINITY;       // the row's bid list (see bid_from_list)
+    if (w.cl != nullptr && wave_gid < n_host) { pre_e = w.cl[(size_t)wave_gid * ASG_BL + lane]; pre_T = w.cT[wave_gid]; }
     int mode = st->mode;
     gfp M = ASG_GLOBAL(st->Mptr);
-    asm volatile("" : "+v"(pre_bc), "+v"(kst0.x), "+v"(kst1.x), "+v"(kst2.x), "+v"(kst3.x) : "s"(mode) : "memory");   // all of it in flight
+    asm volatile("" : "+v"(pre_bc), "+v"(pre_e.x), "+v"(pre_T), "+v"(kst0.x), "+v"(kst1.x), "+v"(kst2.x), "+v"(kst3.x) : "s"(mode) : "memory");   // all of it in flight
     if (mode > MODE_CERT || st->error) return;
     const int n = n_host;
     unsigned payload = 0;
@@ -1254,7 +1315,14 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
     const bool bidding = (mode == MODE_AUCTION || mode == MODE_ARR);
     if (bidding) {
         C = w.auc->ctl[par & 1];
-        if (C.r > 0) auc_decide(C, st, asg_ld(&w.auc->bidcnt[(C.r - 1) & 3]), n);
+        if (C.r > 0) {
+            // bidders of the previous round in the low 16 bits, those served from their lists above (lists: n <= SP_NMAX)
+            const int raw = asg_ld(&w.auc->bidcnt[(C.r - 1) & 3]);
+            const bool lists = (w.cl != nullptr);
+            const int nl = lists ? (raw >> 16) : 0;
+            auc_decide(C, st, lists ? (raw & 0xffff) : raw, n);
+            C.row_scans -= nl; C.pad[0] += nl;          // row_scans: full row reads; pad[0]: list bids (512 bytes each)
+        }
         mode = C.mode;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             asg_book(st, bidding && C.r > 0 ? (C.mode == MODE_CONVERT ? MODE_ARR : C.mode) : MODE_AUCTION);
@@ -1291,7 +1359,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
                           *reinterpret_cast<int2*>(r_lds + j3) = make_int2(asg_key_row(kst3.x, rb), asg_key_row(kst3.y, rb)); }
         }
         __syncthreads();
-        const int nb = wide_bid(M, w, p_lds, r_lds, wave_gid, n_waves, pre_bc, stage_p, n, eps, tag, rb, rnd);
+        const int nb = wide_bid(M, w, p_lds, r_lds, wave_gid, n_waves, pre_bc, pre_e, pre_T, stage_p, n, eps, tag, rb, rnd);
         if (lane == 0 && nb) atomicAdd(&sh[0], nb);
         __syncthreads();
         // the round's bidders, for the decision the next launch takes (no arrival: nothing of this launch needs it)
@@ -1519,7 +1587,14 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     rc = cfm_status();
     if (rc) return rc;
 
-    const int chunk = ((P.chunk > 0 ? P.chunk : 10) + 1) & ~1;        // even: see AsgLaunch::step
+    int chunk = ((P.chunk > 0 ? P.chunk : 10) + 1) & ~1;        // even: see AsgLaunch::step
+    // A batch pays for every problem that is not yet at its list build when the first build + solver pair comes by: it
+    // is built and solved by the NEXT chunk, behind the others' solver (~1.9 ms at n = 4096).  The steps before the
+    // build vary by ~+-6 between problems: 24 instead of 10 steps in front of the pair (a no-op step costs 3-5 us).
+#ifndef ASG_BATCH_CHUNK
+#define ASG_BATCH_CHUNK 24
+#endif
+    if (nb > 1 && chunk < ASG_BATCH_CHUNK) chunk = ASG_BATCH_CHUNK;
     const int bulk = ((n >= P.bulk_min_n) ? P.bulk : 0) & ~1;
     AsgGraph& G = g_graph;
     bool use_graph = asg_graph_enabled() && !G.disabled && n >= 256;
