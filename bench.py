@@ -363,7 +363,7 @@ def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
     ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
     for M in Ms[:2]:
         ot.assign_exact(M)
-    ev_ms, step_us, steps, scans, solver_us = [], [], [], [], []
+    ev_ms, step_us, steps, scans, solver_us, listed = [], [], [], [], [], []
     for M in Ms:
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -372,8 +372,8 @@ def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
         _lib.check(lib.cfm_assign_debug_times(_lib.ptr(ws), buf), "cfm_assign_debug_times")
         t = np.array(list(buf))
         ev_ms.append(e0.elapsed_time(e1)); step_us.append(float(t[:11].sum())); solver_us.append(float(t[11:13].sum()))
-        steps.append(info["stats"][6]); scans.append(info["stats"][5])
-    steps_m, scans_m = float(np.mean(steps)), float(np.mean(scans))
+        steps.append(info["stats"][6]); scans.append(info["stats"][5]); listed.append(float(t[16]))
+    steps_m, scans_m, listed_m = float(np.mean(steps)), float(np.mean(scans)), float(np.mean(listed))
     bytes_solve = scans_m * 4.0 * B + steps_m * 8.0 * B
     t_step = float(np.mean(step_us)) * 1e-6
     gbs = bytes_solve / t_step / 1e9
@@ -388,10 +388,15 @@ def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
             "traffic": traffic, "kernel": "asg_step (cfm_assign_exact_f32)",
             "launches_per_solve": steps_m, "avg_launch_us": float(np.mean(step_us)) / steps_m,
             "algorithmic_bytes_per_launch": bytes_solve / steps_m, "row_scans_per_solve": scans_m,
+            "row_scans_served_from_bid_lists": listed_m,
+            "bytes_read_per_launch_by_construction": ((scans_m - listed_m) * 4.0 * B + listed_m * 1024.0 + steps_m * 8.0 * B) / steps_m,
             "solve_ms": float(np.mean(ev_ms)), "list_solver_ms": float(np.mean(solver_us)) * 1e-3,
             "note": "latency-bound chain of ~200 dependent launches per solve (each >= 1.6 us of launch boundary): "
                     "the figure of merit is solve_ms; achieved = (4B per row scan + 8B prices per launch) / summed "
-                    "asg_step time of an un-overlapped solve; traffic (if present) = HBM bytes per launch from the "
+                    "asg_step time of an un-overlapped solve (SURVEY 8d's algorithmic figure: a row scan = one row "
+                    "evaluation of the auction / the forest; row_scans_served_from_bid_lists of them read the row's "
+                    "64-entry bid list (512 B + 64 prices) instead of the 4 B x n row, so the bytes actually requested "
+                    "are bytes_read_per_launch_by_construction); traffic (if present) = HBM bytes per launch from the "
                     "committed rocprofv3 --pmc passes (profiles/), FETCH x2 + WRITE"}
 
 

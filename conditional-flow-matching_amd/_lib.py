@@ -14,6 +14,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcfm_gfx950.so")
+if os.environ.get("CFM_LIB_PATH"):      # a variant build for A/B measurements (tools/probe/build_variant.sh); never a fallback
+    LIB_PATH = os.path.abspath(os.environ["CFM_LIB_PATH"])
 _lock = threading.Lock()
 _lib = None
 

@@ -156,7 +156,7 @@ struct AsgState {
     double dfree, cmin, cmax, stop_early;
     int st_auction_rounds, st_arr_rounds, st_free_after_arr, st_sap_batches;
     int st_sap_row_scans, st_total_row_scans, st_steps, st_dense_fallbacks;
-    int st_ms_phases, st_ms_augmented, wide_blocks, pad1;
+    int st_ms_phases, st_ms_augmented, wide_blocks, st_list_bids;    // st_list_bids: bids served from a row's bid list
     long long t_prev;          // time accounting (100 MHz device clock): every control step books the
     long long t_acc[16];       // time since the previous one on the mode that launch ran in
 };
@@ -164,13 +164,15 @@ static_assert(sizeof(AsgState) <= 512, "AsgState has 512 bytes at the head of th
 static_assert(offsetof(AsgState, arrive) == 128 && offsetof(AsgState, nF) == 256, "AsgState layout");
 
 // Tuning aid, not part of the ABI: microseconds the last solve on `ws` spent in each mode (slots
-// 0-15, index = MODE_*; launch + gap to the next launch).  Slots 16-31 are zero.  Blocking.
+// 0-15, index = MODE_*; launch + gap to the next launch).  Slot 16: the bids of the solve that were served from the
+// row's bid list (512 bytes) instead of a row scan — they are part of stats[5].  Slots 17-31 are zero.  Blocking.
 extern "C" int cfm_assign_debug_times(const void* ws, double* us32) {
     if (!ws || !us32) return CFM_EINVAL;
     AsgState h;
     int rc = cfm_hip(hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost));
     if (rc) return rc;
     for (int q = 0; q < 16; ++q) { us32[q] = (double)h.t_acc[q] * 0.01; us32[16 + q] = 0.0; }
+    us32[16] = (double)h.st_list_bids;
     return 0;
 }
 
@@ -497,8 +499,6 @@ __device__ __forceinline__ void bid_commit(gfp M, const AsgWs& w, Top2 best, int
     }
 }
 
-// One wave per row; a row bids iff it is unmatched.  pre_bc = bidcol of the wave's first row,
-// requested with the keys in the kernel prologue.  Returns the number of bids of this wave.
 #define ASG_BL 64     // entries of a bid list = SP_K: the arrays are the list solver's
 // Bid lists (n <= SP_NMAX; they live in the candidate-list arrays the list solver fills AFTER the rounds): a full row
 // scan leaves, per lane, the best column of the lane's share of the row and its cost, and T = the smallest second-best
@@ -541,86 +541,129 @@ __device__ __forceinline__ void bid_list_store(gfp M, const AsgWs& w, const Top2
     if ((threadIdx.x & 63) == 0) w.cT[i] = T;
 }
 
-__device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_lds, const int* r_lds,
-                                        int wave_gid, int n_waves, int pre_bc, uint2 pre_e, double pre_T, bool stage_p, int n,
-                                        double eps, int tag, int rb, int rnd) {
-    const int lane = threadIdx.x & 63;
-    const bool vec = ((n & 3) == 0);
-    const bool fast = stage_p && (n & 4095) == 0;
 #ifndef ASG_BL_ON
 #define ASG_BL_ON 1
 #endif
+// The bid of ONE unmatched row by one wave: from its bid list if that decides it (e / T: the list entry of this lane
+// and the bound), else a scan of the row, which refreshes the list.  Returns 1 (a bid) + 0x10000 if the list served it.
+__device__ __forceinline__ int bid_row(gfp M, const AsgWs& w, const double* p_lds, int i, uint2 e, double T, bool stage_p,
+                                       int n, double eps, int tag, int rb, int rnd) {
+    const int lane = threadIdx.x & 63;
+    const bool vec = ((n & 3) == 0);
+    const bool fast = stage_p && (n & 4095) == 0;
     const bool lists = ASG_BL_ON && (w.cl != nullptr);
     const int mb = rb + ASG_RND_BITS;
-    int nbids = 0;             // low 16 bits: bids; high bits: those of them that came from the list
-    int i = wave_gid;
+    if (lists && bid_from_list(M, w, p_lds, stage_p, e, T, i, n, eps, tag, rb, rnd)) return 0x10001;
+    gfp row = M + (size_t)i * n;
+    Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
     if (fast) {
-        for (; i < n; i += n_waves) {
-            const int bc = (i == wave_gid) ? pre_bc : w.bidcol[i];
-            if (bid_matched(w, r_lds, true, bc, tag, i, rb)) continue;
-            if (lists) {
-                const uint2 e = (i == wave_gid) ? pre_e : w.cl[(size_t)i * ASG_BL + lane];
-                const double T = (i == wave_gid) ? pre_T : w.cT[i];
-                if (bid_from_list(M, w, p_lds, true, e, T, i, n, eps, tag, rb, rnd)) { nbids += 0x10001; continue; }
-            }
-            Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
-            for (int seg = 0; seg < n; seg += 4096) {
-                // the segment's 16 KB in flight at once: 16 float4 per lane
-                float4 c[16];
-                gfp rs = M + (size_t)i * n + seg + lane * 4;
+        for (int seg = 0; seg < n; seg += 4096) {
+            // the segment's 16 KB in flight at once: 16 float4 per lane
+            float4 c[16];
+            gfp rs = row + seg + lane * 4;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) c[k] = asg_ld4(rs + 256 * k);
-                bid_segment(best, c, p_lds + seg + lane * 4, seg + lane * 4);
-                __builtin_amdgcn_sched_barrier(0);     // the next segment's loads stay behind this one's arithmetic
-            }
-            bid_commit(M, w, best, i, n, eps, p_lds, true, tag, rb, rnd);
-            if (lists) bid_list_store(M, w, best, i, n);
-            ++nbids;
+            for (int k = 0; k < 16; ++k) c[k] = asg_ld4(rs + 256 * k);
+            bid_segment(best, c, p_lds + seg + lane * 4, seg + lane * 4);
+            __builtin_amdgcn_sched_barrier(0);     // the next segment's loads stay behind this one's arithmetic
         }
-        return nbids;
+    } else if (vec && stage_p) {
+        for (int j0 = lane * 4; j0 < n; j0 += 1024) {
+            // 4 float4 in flight per lane per trip
+            float4 c4[4]; double2 pa[4], pb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 256 * k;
+                if (j < n) {
+                    c4[k] = asg_ld4(row + j);
+                    pa[k] = *reinterpret_cast<const double2*>(p_lds + j);
+                    pb[k] = *reinterpret_cast<const double2*>(p_lds + j + 2);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 256 * k;
+                if (j < n) {
+                    top2_push(best, (double)c4[k].x + pa[k].x, j + 0);
+                    top2_push(best, (double)c4[k].y + pa[k].y, j + 1);
+                    top2_push(best, (double)c4[k].z + pb[k].x, j + 2);
+                    top2_push(best, (double)c4[k].w + pb[k].y, j + 3);
+                }
+            }
+        }
+    } else if (stage_p) {
+        for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + p_lds[j], j);
+    } else if (vec) {
+        // no price snapshot in LDS (n > WIDE_PLDS_MAX): the keys come with the costs, 4 + 4 per request
+        for (int j0 = lane * 4; j0 < n; j0 += 1024) {
+            float4 c4[4]; ulonglong2 ka[4], kb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 256 * k;
+                if (j < n) {
+                    c4[k] = asg_ld4(row + j);
+                    ka[k] = *reinterpret_cast<const ulonglong2*>(w.key + j);
+                    kb[k] = *reinterpret_cast<const ulonglong2*>(w.key + j + 2);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 256 * k;
+                if (j < n) {
+                    top2_push(best, (double)c4[k].x + asg_price(ka[k].x, mb), j + 0);
+                    top2_push(best, (double)c4[k].y + asg_price(ka[k].y, mb), j + 1);
+                    top2_push(best, (double)c4[k].z + asg_price(kb[k].x, mb), j + 2);
+                    top2_push(best, (double)c4[k].w + asg_price(kb[k].y, mb), j + 3);
+                }
+            }
+        }
+    } else {
+        for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + asg_price(w.key[j], mb), j);
     }
-    for (; i < n; i += n_waves) {
-        const int bc = (i == wave_gid) ? pre_bc : w.bidcol[i];
+    bid_commit(M, w, best, i, n, eps, p_lds, stage_p, tag, rb, rnd);
+    if (lists) bid_list_store(M, w, best, i, n);
+    return 1;
+}
+
+// One wave per row; a row bids iff it is unmatched.  pre_bc4 = bidcol of the wave's first four rows, pre_e / pre_T the
+// bid list of its first row, requested with the keys in the kernel prologue.  Returns the number of bids of this wave
+// (low 16 bits) and how many of them the lists served (high bits).
+__device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_lds, const int* r_lds,
+                                        int wave_gid, int n_waves, int4 pre_bc4, uint2 pre_e, double pre_T, bool stage_p, int n,
+                                        double eps, int tag, int rb, int rnd) {
+    const int lane = threadIdx.x & 63;
+    const bool lists = ASG_BL_ON && (w.cl != nullptr);
+    int nbids = 0;
+    int i = wave_gid;
+    for (int k = 0; i < n; i += n_waves, ++k) {
+        const int bc = k == 0 ? pre_bc4.x : k == 1 ? pre_bc4.y : k == 2 ? pre_bc4.z : k == 3 ? pre_bc4.w : w.bidcol[i];
         if (bid_matched(w, r_lds, stage_p, bc, tag, i, rb)) continue;
-        if (lists) {
-            const uint2 e = (i == wave_gid) ? pre_e : w.cl[(size_t)i * ASG_BL + lane];
-            const double T = (i == wave_gid) ? pre_T : w.cT[i];
-            if (bid_from_list(M, w, p_lds, stage_p, e, T, i, n, eps, tag, rb, rnd)) { nbids += 0x10001; continue; }
-        }
-        gfp row = M + (size_t)i * n;
-        Top2 best; best.b = INFINITY; best.s = INFINITY; best.j = 0x7fffffff;
-        if (vec && stage_p) {
-            for (int j0 = lane * 4; j0 < n; j0 += 1024) {
-                // 4 float4 in flight per lane per trip
-                float4 c4[4]; double2 pa[4], pb[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int j = j0 + 256 * k;
-                    if (j < n) {
-                        c4[k] = asg_ld4(row + j);
-                        pa[k] = *reinterpret_cast<const double2*>(p_lds + j);
-                        pb[k] = *reinterpret_cast<const double2*>(p_lds + j + 2);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int j = j0 + 256 * k;
-                    if (j < n) {
-                        top2_push(best, (double)c4[k].x + pa[k].x, j + 0);
-                        top2_push(best, (double)c4[k].y + pa[k].y, j + 1);
-                        top2_push(best, (double)c4[k].z + pb[k].x, j + 2);
-                        top2_push(best, (double)c4[k].w + pb[k].y, j + 3);
-                    }
-                }
-            }
-        } else if (stage_p) {
-            for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + p_lds[j], j);
-        } else {
-            for (int j = lane; j < n; j += 64) top2_push(best, (double)row[j] + asg_price(w.key[j], mb), j);
-        }
-        bid_commit(M, w, best, i, n, eps, p_lds, stage_p, tag, rb, rnd);
-        if (lists) bid_list_store(M, w, best, i, n);
-        ++nbids;
+        uint2 e = pre_e; double T = pre_T;
+        if (lists && k > 0) { e = w.cl[(size_t)i * ASG_BL + lane]; T = w.cT[i]; }
+        nbids += bid_row(M, w, p_lds, i, e, T, stage_p, n, eps, tag, rb, rnd);
+    }
+    return nbids;
+}
+
+// The same round when the grid gives a workgroup MORE rows than it has waves (batches of problems share the chip;
+// n > 8192): a wave that walked its rows one after the other would pay a dependent round trip per row, though only a
+// few per cent of the rows bid in a typical round.  Thread t checks the workgroup's row t (its last bid arrived with the
+// prologue, the owner rows are in LDS), the unmatched rows go into a queue in LDS, and the waves take them from there.
+#define ASG_BQ 256                    // rows per workgroup this path takes (the grid is chosen accordingly)
+__device__ __forceinline__ int wide_bid_queue(gfp M, const AsgWs& w, const double* p_lds, const int* r_lds, int* bq, int* bq_cnt,
+                                              int my_bc, bool stage_p, int n, double eps, int tag, int rb, int rnd) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool lists = ASG_BL_ON && (w.cl != nullptr);
+    const int i_chk = blockIdx.x + gridDim.x * threadIdx.x;             // row t of this workgroup
+    if (i_chk < n && threadIdx.x < ASG_BQ && !bid_matched(w, r_lds, stage_p, my_bc, tag, i_chk, rb))
+        bq[atomicAdd(bq_cnt, 1)] = i_chk;
+    __syncthreads();
+    const int m = *bq_cnt;
+    int nbids = 0;
+    for (int k = wv; k < m; k += WT / 64) {
+        const int i = bq[k];
+        uint2 e = make_uint2(0xffffffffu, 0u); double T = -INFINITY;
+        if (lists) { e = w.cl[(size_t)i * ASG_BL + lane]; T = w.cT[i]; }
+        nbids += bid_row(M, w, p_lds, i, e, T, stage_p, n, eps, tag, rb, rnd);
     }
     return nbids;
 }
@@ -1301,12 +1344,22 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
         kst2 = *reinterpret_cast<const ulonglong2*>(w.key + (j2 < nn ? j2 : 0));
         kst3 = *reinterpret_cast<const ulonglong2*>(w.key + (j3 < nn ? j3 : 0));
     }
+    // (a grid smaller than one wave per row — batches, n > 8192 — gives a wave several rows: their last bids are requested
+    //  together, or every further row would add a dependent round trip to the round)
     int pre_bc = (wave_gid < n_host) ? w.bidcol[wave_gid] : -1;
+    int pre_bc1 = (wave_gid + n_waves < n_host) ? w.bidcol[wave_gid + n_waves] : -1;
+    int pre_bc2 = (wave_gid + 2 * n_waves < n_host) ? w.bidcol[wave_gid + 2 * n_waves] : -1;
+    int pre_bc3 = (wave_gid + 3 * n_waves < n_host) ? w.bidcol[wave_gid + 3 * n_waves] : -1;
+    // more rows per workgroup than waves: the queue form of the round (wide_bid_queue), thread t looks at row t
+    const bool queue = (n_host > (int)gridDim.x * (WT / 64)) && (n_host <= (int)gridDim.x * ASG_BQ);
+    int my_bc = -1;
+    if (queue && threadIdx.x < ASG_BQ && (int)(blockIdx.x + gridDim.x * threadIdx.x) < n_host)
+        my_bc = w.bidcol[blockIdx.x + gridDim.x * threadIdx.x];
     uint2 pre_e = make_uint2(0xffffffffu, 0u); double pre_T = -INFINITY;       // the row's bid list (see bid_from_list)
     if (w.cl != nullptr && wave_gid < n_host) { pre_e = w.cl[(size_t)wave_gid * ASG_BL + lane]; pre_T = w.cT[wave_gid]; }
     int mode = st->mode;
     gfp M = ASG_GLOBAL(st->Mptr);
-    asm volatile("" : "+v"(pre_bc), "+v"(pre_e.x), "+v"(pre_T), "+v"(kst0.x), "+v"(kst1.x), "+v"(kst2.x), "+v"(kst3.x) : "s"(mode) : "memory");   // all of it in flight
+    asm volatile("" : "+v"(pre_bc), "+v"(pre_bc1), "+v"(pre_bc2), "+v"(pre_bc3), "+v"(my_bc), "+v"(pre_e.x), "+v"(pre_T), "+v"(kst0.x), "+v"(kst1.x), "+v"(kst2.x), "+v"(kst3.x) : "s"(mode) : "memory");   // all of it in flight
     if (mode > MODE_CERT || st->error) return;
     const int n = n_host;
     unsigned payload = 0;
@@ -1321,7 +1374,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
             const bool lists = (w.cl != nullptr);
             const int nl = lists ? (raw >> 16) : 0;
             auc_decide(C, st, lists ? (raw & 0xffff) : raw, n);
-            C.row_scans -= nl; C.pad[0] += nl;          // row_scans: full row reads; pad[0]: list bids (512 bytes each)
+            C.pad[0] += nl;          // row_scans: the bids (row evaluations); pad[0]: those served from the list (512 bytes each)
         }
         mode = C.mode;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1330,7 +1383,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
                 // the rounds are over: their results go back into the state block, this launch is the CONVERT step
                 st->tag = C.tag; st->eps = C.eps; st->phase = C.phase; st->round = C.round; st->arr_round = C.arr_round;
                 st->st_auction_rounds = C.auction_rounds; st->st_arr_rounds = C.arr_rounds;
-                st->st_total_row_scans += C.row_scans;
+                st->st_total_row_scans += C.row_scans; st->st_list_bids = C.pad[0];
             } else {
                 AucCtl N2 = C; N2.r = C.r + 1;
                 w.auc->ctl[(par & 1) ^ 1] = N2;
@@ -1344,7 +1397,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
         int* r_lds = reinterpret_cast<int*>(step_lds + (size_t)((n + 1) & ~1) * sizeof(double));
         const double eps = C.eps; const int tag = C.tag, rb = st->rb;
         const int rnd = (mode == MODE_ARR) ? min(C.arr_round + 1, (1 << ASG_RND_BITS) - 1) : 0;
-        if (threadIdx.x == 0) sh[0] = 0;
+        if (threadIdx.x == 0) { sh[0] = 0; sh[1] = 0; }
         if (stage_p) {
             const int mb = rb + ASG_RND_BITS;
             const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
@@ -1359,7 +1412,9 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
                           *reinterpret_cast<int2*>(r_lds + j3) = make_int2(asg_key_row(kst3.x, rb), asg_key_row(kst3.y, rb)); }
         }
         __syncthreads();
-        const int nb = wide_bid(M, w, p_lds, r_lds, wave_gid, n_waves, pre_bc, pre_e, pre_T, stage_p, n, eps, tag, rb, rnd);
+        __shared__ int bq[ASG_BQ];
+        const int nb = queue ? wide_bid_queue(M, w, p_lds, r_lds, bq, &sh[1], my_bc, stage_p, n, eps, tag, rb, rnd)
+                             : wide_bid(M, w, p_lds, r_lds, wave_gid, n_waves, make_int4(pre_bc, pre_bc1, pre_bc2, pre_bc3), pre_e, pre_T, stage_p, n, eps, tag, rb, rnd);
         if (lane == 0 && nb) atomicAdd(&sh[0], nb);
         __syncthreads();
         // the round's bidders, for the decision the next launch takes (no arrival: nothing of this launch needs it)
@@ -1493,7 +1548,7 @@ extern "C" void cfm_assign_debug_fallback(int* out2) { out2[0] = g_fallback[0]; 
 extern "C" void cfm_assign_debug_small(int* out16) { for (int q = 0; q < 16; ++q) out16[q] = g_small_last[q]; }
 
 struct AsgLaunch {
-    AsgWs w; int n, blocks, nb; size_t stride; size_t lds_step, lds_build, lds_solve; int sparse; hipStream_t s;
+    AsgWs w; int n, blocks, blocks_build, nb; size_t stride; size_t lds_step, lds_build, lds_solve; int sparse; hipStream_t s;
     // every program holds an EVEN number of asg_step launches and starts on an even launch count, so the parity
     // argument (which control record a bid round reads, see AucCtl) is the position inside the program.
     // grid.y = the problems of a batch (one carving each, `stride` bytes apart)
@@ -1503,7 +1558,7 @@ struct AsgLaunch {
         if (prg == PRG_BULK) { for (int c = 0; c < bulk; ++c) step(k++); return; }
         for (int c = 0; c < chunk; ++c) step(k++);
         if (sparse) {
-            hipLaunchKernelGGL(asg_build, dim3(blocks, nb), dim3(SP_BUILD_WAVES * 64), lds_build, s, w, n, stride);
+            hipLaunchKernelGGL(asg_build, dim3(blocks_build, nb), dim3(SP_BUILD_WAVES * 64), lds_build, s, w, n, stride);
             hipLaunchKernelGGL(asg_solve, dim3(1, nb), dim3(SP_T), lds_solve, s, w, n, stride);
             step(k++); step(k++);      // certificate + whatever the guess missed
         }
@@ -1551,15 +1606,21 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     int wide_blocks = (n + 15) / 16;        // one wave per row when everything bids
     if (wide_blocks > 512) wide_blocks = 512;
     if (P.wide_blocks_cap > 0 && wide_blocks > P.wide_blocks_cap) wide_blocks = P.wide_blocks_cap;
-    // a batch shares the chip: 512 resident workgroups in all (every workgroup of a bid round stages the prices whether
-    // its rows bid or not; measured at n = 4096: 8 problems 9.1 ms with 256 workgroups each, 6.5 ms with 64)
-    if (nb > 1 && wide_blocks > 512 / nb) wide_blocks = 512 / nb;
-    if (wide_blocks < (n + 63) / 64) wide_blocks = (n + 63) / 64;
+    L.blocks_build = wide_blocks < (n + 63) / 64 ? (n + 63) / 64 : wide_blocks;     // the list build streams the matrix once: its own grid
+    // a batch shares the chip: ASG_BATCH_WGS workgroups in all (every workgroup of a bid round stages the prices whether
+    // its rows bid or not; measured at n = 4096: 8 problems 9.1 ms with 256 workgroups each, 6.5 ms with 64); the rounds
+    // then take the queue form (wide_bid_queue)
+    const int floor_blocks = nb > 1 ? (n + ASG_BQ - 1) / ASG_BQ : (n + 63) / 64;
+#ifndef ASG_BATCH_WGS
+#define ASG_BATCH_WGS 256
+#endif
+    if (nb > 1 && wide_blocks > ASG_BATCH_WGS / nb) wide_blocks = ASG_BATCH_WGS / nb;
+    if (wide_blocks < floor_blocks) wide_blocks = floor_blocks;      // (the queue form takes ASG_BQ rows per workgroup)
     if (wide_blocks < 1) wide_blocks = 1;
     L.blocks = wide_blocks;
     const int raised = asg_raise_lds();
     L.lds_step = sizeof(double) * WT + 2 * sizeof(int) * WT;                      // relax merge buffers
-    if (n <= WIDE_PLDS_MAX) {                                                       // bid rounds: prices + owner rows
+    if (n <= WIDE_PLDS_MAX) {                                            // bid rounds: prices + owner rows
         const size_t need = (size_t)((n + 1) & ~1) * sizeof(double) + (size_t)(n + 2) * sizeof(int);
         if (need > L.lds_step) L.lds_step = need;
     }

@@ -108,3 +108,23 @@ def test_batch_argument_checks():
         ot.assign_exact_batch([])
     with pytest.raises(ValueError):
         ot.assign_exact_batch([a, a.double()])
+
+
+@pytest.mark.parametrize("B,check_scipy", [(8448, True), (8197, False)])
+def test_sizes_beyond_the_lds_price_snapshot(B, check_scipy):
+    """n > 8192: the bid rounds have no price snapshot in LDS (keys read with the costs; 8448: the 16-byte form,
+    8197: the scalar form).  Certified permutation; for 8448 the cost equals SciPy's optimum."""
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    g = torch.Generator().manual_seed(B)
+    x0 = torch.randn(B, 3, generator=g); x1 = torch.randn(B, 3, generator=g) * 0.8 + 0.2
+    M = ot.cost_matrix(x0.to(dev), x1.to(dev))
+    perm, info = ot.assign_exact(M, return_info=True)
+    p = perm.cpu().numpy()
+    assert sorted(p.tolist()) == list(range(B)) and info["certified"]
+    Mh = M.cpu().numpy()
+    assert info["total_cost"] == pytest.approx(oracle.assignment_cost(Mh, p), rel=1e-12)
+    if check_scipy:
+        ref = oracle.exact_perm(Mh)
+        assert oracle.assignment_cost(Mh, p) == pytest.approx(oracle.assignment_cost(Mh, ref), rel=1e-12)
