@@ -508,6 +508,8 @@ def main():
     lib_ = _lib.load()
     if os.environ.get("CFM_ASG_BLOCKS"):     # experiment knob: grid cap of the assignment's wide kernel
         lib_.cfm_assign_set_wide_blocks(int(os.environ["CFM_ASG_BLOCKS"]))
+    if os.environ.get("CFM_ASG_ARR"):        # experiment knob: number of epsilon = 0 rounds
+        lib_.cfm_assign_set_params(0, 0, 0, -1, 0, int(os.environ["CFM_ASG_ARR"]), 0)
     if os.environ.get("CFM_ASG_DENSE"):      # experiment knob: no candidate-list solver
         lib_.cfm_assign_set_mode(0)
     if not torch.cuda.is_available():
@@ -578,6 +580,16 @@ def main():
     if args.pipeline:
         from cfm_amd.prefetch import CouplingPrefetcher
         pre = CouplingPrefetcher(fm, dev, workers=args.pipeline)
+        # one-time costs per worker thread (stream, workspaces, the solver's captured launch programs for each job shape
+        # the loops are going to submit) are paid before the warm-up steps, on every worker
+        rs_np, rs_t = np.random.get_state(), torch.get_rng_state()
+        shapes = {args.group} | {args.steps % args.group, args.warmup % args.group} if args.group > 1 else {1}
+        for k in sorted(shapes - {0}, reverse=True):
+            if args.group > 1:
+                pre.prime(lambda k=k: couple_group([pool[q % len(pool)] for q in range(k)], [draw() for _ in range(k)]))
+            else:
+                pre.prime(lambda: couple(*pool[0], draw()))
+        np.random.set_state(rs_np); torch.set_rng_state(rs_t)
     elapsed, gathered = timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple, model_step,
                                      draw, pre, args.pipeline, dev, args.group, couple_group)
     if pre is not None:

@@ -1516,7 +1516,25 @@ struct AsgGraph {
     hipStream_t stream = nullptr; int disabled = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
-static thread_local AsgGraph g_graph;
+// A host thread keeps the programs of its last few (workspace, size, batch, stream) combinations: a training loop
+// alternates between a few of them (groups of couplings and a shorter last group, single solves), and capturing +
+// instantiating the two programs costs milliseconds.
+#define ASG_GRAPH_SLOTS 4
+static thread_local AsgGraph g_graphs[ASG_GRAPH_SLOTS];
+static thread_local unsigned g_graph_use[ASG_GRAPH_SLOTS];
+static thread_local unsigned g_graph_clock = 0;
+static thread_local int g_graph_off = 0;      // this thread's streams cannot be captured: plain launches from now on
+static AsgGraph& asg_graph_slot(void* ws, int n, int nb, hipStream_t s) {
+    int hit = -1, lru = 0;
+    for (int q = 0; q < ASG_GRAPH_SLOTS; ++q) {
+        const AsgGraph& G = g_graphs[q];
+        if (G.exec[0] && G.ws == ws && G.n == n && G.nb == nb && G.stream == s) hit = q;
+        if (g_graph_use[q] < g_graph_use[lru]) lru = q;
+    }
+    const int q = hit >= 0 ? hit : lru;
+    g_graph_use[q] = ++g_graph_clock;
+    return g_graphs[q];
+}
 
 static int asg_graph_enabled() {
     static const int v = [] { const char* e = getenv("CFM_ASG_GRAPH"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -1657,8 +1675,8 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
 #endif
     if (nb > 1 && chunk < ASG_BATCH_CHUNK) chunk = ASG_BATCH_CHUNK;
     const int bulk = ((n >= P.bulk_min_n) ? P.bulk : 0) & ~1;
-    AsgGraph& G = g_graph;
-    bool use_graph = asg_graph_enabled() && !G.disabled && n >= 256;
+    AsgGraph& G = asg_graph_slot(ws, n, nb, s);
+    bool use_graph = asg_graph_enabled() && !g_graph_off && n >= 256;
     if (use_graph && !(G.exec[0] && G.ws == ws && G.n == n && G.nb == nb && G.chunk == chunk && G.bulk == bulk &&
                        G.blocks == wide_blocks && G.sparse == L.sparse && G.stream == s)) {
         for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
@@ -1678,7 +1696,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
         if (e != hipSuccess) {
             (void)hipGetLastError();
             for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
-            G.disabled = 1; use_graph = false;     // e.g. the legacy default stream
+            g_graph_off = 1; use_graph = false;     // e.g. the legacy default stream
         } else {
             G.ws = ws; G.n = n; G.nb = nb; G.chunk = chunk; G.bulk = bulk; G.blocks = wide_blocks;
             G.sparse = L.sparse; G.stream = s;

@@ -80,6 +80,25 @@ class CouplingPrefetcher:
             done.record(stream)
         return out, done
 
+    def prime(self, fn):
+        """Run ``fn()`` once on EVERY worker thread, on that worker's stream (all workers at the same time), and wait.
+        One-time costs are per worker — its stream, its workspaces, the solver's launch programs (hipGraphs are
+        captured per host thread) — so a loop that wants none of them inside its first steps primes the workers with a
+        throw-away job of the shape it is going to submit."""
+        n = self._pool._max_workers
+        gate = threading.Barrier(n)
+
+        def job():
+            gate.wait()                     # n jobs, n threads: nobody takes two
+            if self.device.type != "cuda":
+                fn(); return
+            stream = self._stream()
+            with torch.cuda.stream(stream):
+                fn()
+            stream.synchronize()
+        for f in [self._pool.submit(job) for _ in range(n)]:
+            f.result()
+
     def close(self):
         self._pool.shutdown(wait=True)
 

@@ -65,3 +65,13 @@ def test_group_of_one_and_no_prefetcher_fall_back_to_the_plain_loops():
     bench.run_steps(pool, 0, 5, couple, model_step, draw, pre, 2, 1, couple_group)
     pre.close()
     assert log["groups"] == [] and len(log["stepped"]) == 10
+
+
+def test_prime_runs_once_on_every_worker():
+    import threading
+    from cfm_amd.prefetch import CouplingPrefetcher
+    pre = CouplingPrefetcher(None, torch.device("cpu"), workers=3)
+    seen = []
+    pre.prime(lambda: seen.append(threading.get_ident()))
+    pre.close()
+    assert len(seen) == 3 and len(set(seen)) == 3
