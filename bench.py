@@ -6,8 +6,8 @@
 One "step" = one pass of the hot path over one synthetic minibatch already resident in HBM
 (config C3: x0 ~ N(0,I) in R^784, x1 MNIST-like, B = 4096 per GPU):
     cost matrix -> exact OT assignment -> plan sampling -> fused gather + xt/ut  (HIP kernels)
-    -> MLP(785-512-512-512-784) forward, backward (fp32-MFMA HIP kernels behind an autograd.Function),
-       MSE loss (eager elementwise ops), one-launch Adam (HIP)
+    -> MLP(785-512-512-512-784) forward, MSE, backward as ONE library call (cfm_amd.RegressionStep: fp32-MFMA HIP
+       kernels, no eager op), one-launch Adam (HIP)
 Schedule (--pipeline N --group G, default 3 x 4): the coupling depends only on the data, so the couplings of
 the next batches are computed on side streams (background threads, cfm_amd.prefetch) while the model steps on
 batch k, like data-loader workers: N prefetch jobs in flight, each coupling G consecutive minibatches together —
