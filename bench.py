@@ -453,9 +453,14 @@ def cpu_standin_main(args):
         torch.mean((model(torch.cat([xt, t[:, None]], dim=-1)) - ut) ** 2).backward()
         opt.step()
 
+    def couple_group(batches, drawn):
+        return [couple(x0, x1, dr) for (x0, x1), dr in zip(batches, drawn)]
+
     pre = CouplingPrefetcher(None, torch.device("cpu"), workers=args.pipeline) if args.pipeline else None
+    if pre is not None:
+        pre.prime(lambda: None)
     elapsed, gathered = timed_region(D, lambda: None, pool, args.warmup, args.steps, couple, model_step, draw, pre,
-                                     args.pipeline, torch.device("cpu"))
+                                     args.pipeline, torch.device("cpu"), args.group, couple_group)
     if pre is not None:
         pre.close()
     assert gathered.shape[0] == world * B
