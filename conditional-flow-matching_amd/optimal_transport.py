@@ -531,14 +531,23 @@ class OTPlanSampler:
         )
 
     def _solve_many(self, pairs, workers=3):
-        """Solve independent couplings concurrently: one host thread + one HIP stream per worker
-        (the exact solver is a chain of small latency-bound kernels; three in flight double the
-        throughput).  Returns the ``_solve`` results in order, usable on the caller's stream."""
+        """Solve independent couplings together: exact couplings of one square size as ONE batch of the solver
+        (``assign_exact_batch``), everything else concurrently with one host thread + one HIP stream per worker.
+        Returns the ``_solve`` results in order, usable on the caller's stream."""
         import concurrent.futures as cf
         import threading
         dev = _lib.require_gpu()
         if len(pairs) <= 1 or workers <= 1:
             return [self._solve(a, b) for a, b in pairs]
+        if self.method == "exact":
+            # equal, square sizes beyond the one-workgroup solver: the assignment problems share ONE chain of launches
+            prep = [self._prepare(a, b) for a, b in pairs]
+            Ms = [m for _, m, _, _ in prep]
+            n0 = Ms[0].shape[0]
+            if n0 > 256 and all(m.shape[0] == n0 and m.shape[1] == n0 for m in Ms):
+                perms = assign_exact_batch(Ms)
+                self._last = {"certified": True}
+                return [("perm", perms[k], Ms[k]) for k in range(len(Ms))]
         tls = threading.local()
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))

@@ -124,3 +124,22 @@ def test_sample_trajectory_sinkhorn_matches_host_chain():
     ref = np.stack([X[:, t].numpy()[idx[t]] for t in range(4)], axis=1)
     assert out.shape == (64, 4, 3)
     assert np.array_equal(out, ref)
+
+
+def test_sample_trajectory_exact_batched_solves():
+    """Sizes beyond the one-workgroup solver: the times - 1 exact couplings go through ONE batched solve
+    (assign_exact_batch); every slice still is the oracle's optimal permutation chained in time order."""
+    from cfm_amd.optimal_transport import OTPlanSampler
+    import cfm_oracle as oracle
+    g = torch.Generator().manual_seed(7)
+    n, times = 320, 5
+    X = torch.randn(n, times, 6, generator=g) + torch.arange(times)[None, :, None] * 0.3
+    s = OTPlanSampler(method="exact")
+    np.random.seed(0)
+    out = s.sample_trajectory(X)
+    assert out.shape == (n, times, 6)
+    idx = np.arange(n)
+    for t in range(times - 1):
+        perm = oracle.exact_perm(oracle.ref_cost_f32(X[:, t], X[:, t + 1]))
+        idx = perm[idx]
+        assert np.array_equal(out[:, t + 1], X[:, t + 1].numpy()[idx]), t
