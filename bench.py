@@ -410,7 +410,7 @@ def self_launch(args, argv):
     if not args.cpu_standin:
         if not torch.cuda.is_available():
             raise SystemExit(f"bench.py --gpus {args.gpus}: no GPU visible (the bench measures the HIP path; no CPU fallback)")
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and not os.environ.get("CFM_BENCH_SHARE_GPU"):
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this box; "
                              f"one rank per GPU is required (refusing to oversubscribe or to run fewer ranks)")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -523,7 +523,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus} (launch with --nproc-per-node {args.gpus}, "
                          f"or run `python bench.py --gpus {args.gpus}` and let it start the ranks)")
-    if world > torch.cuda.device_count():
+    # CFM_BENCH_SHARE_GPU=1 (with CFM_DIST_BACKEND=gloo): a test of the N > 1 code path on a one-GPU box, several ranks on
+    # the same device — the line it prints is marked "valid": false, it is no measurement
+    shared = bool(os.environ.get("CFM_BENCH_SHARE_GPU")) and world > torch.cuda.device_count()
+    if world > torch.cuda.device_count() and not shared:
         raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible: one rank per GPU")
     dev_index = local % torch.cuda.device_count()     # one rank per GPU on a real node (identity there)
     dev = torch.device("cuda", dev_index)
@@ -628,6 +631,8 @@ def main():
                                 if args.pipeline else "sequential"),
                    "prefetch_jobs": args.pipeline, "prefetch_group": args.group if args.pipeline else 0,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
+        **({"valid": False, "data": "synthetic; ranks SHARE one GPU (CFM_BENCH_SHARE_GPU): code-path test, NOT a measurement"}
+           if shared else {}),
         "value_sequential": (B / seq_s) if seq_s else None,
         "ms_per_step_sequential": seq_s * 1e3 if seq_s else None,
     }

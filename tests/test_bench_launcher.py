@@ -54,3 +54,21 @@ def test_gpus_2_on_a_one_gpu_box_fails_loudly():
         pytest.skip("box has >= 2 GPUs")
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert p.returncode != 0 and "GPU(s) visible" in p.stderr
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharing_the_gpu_run_the_real_loop():
+    """The N > 1 code path with the real HIP kernels on a one-GPU box: two ranks on the same device, collectives over
+    gloo (CFM_BENCH_SHARE_GPU + CFM_DIST_BACKEND): per-rank pools, grouped prefetch workers, the fused regression step
+    with its gradient all-reduce, the all-gather of the final samples, max-over-ranks timing, ONE line from rank 0 —
+    marked invalid as a measurement."""
+    env = dict(os.environ, CFM_BENCH_SHARE_GPU="1", CFM_DIST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4",
+                        "--batch", "1024", "--no-legs", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["valid"] is False and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2"
