@@ -117,6 +117,8 @@ def assign_exact_batch(Ms, return_info=False):
                                       f"{[tuple(x.shape) for x in Ms]}")
         if m.device != dev or m.dtype != torch.float32 or not m.is_contiguous():
             raise ValueError("assign_exact_batch: contiguous fp32 matrices on one device")
+    # (slices of a stacked [nb,B,B] tensor with odd B start off the 16-byte grid the kernels load on: those are copied)
+    Ms = [m if m.data_ptr() % 16 == 0 else m.clone() for m in Ms]
     perm = torch.empty((nb, B), dtype=torch.int32, device=dev)
     cert = torch.empty(nb, dtype=torch.int32, device=dev)
     tot = torch.empty(nb, dtype=torch.float64, device=dev)

@@ -50,6 +50,10 @@ def test_batch_of_stacked_tensor_and_more_than_one_group():
     perms = ot.assign_exact_batch(Ms)
     for b in range(19):
         assert np.array_equal(perms[b].cpu().numpy(), oracle.exact_perm(Ms[b].cpu().numpy())), b
+    odd = torch.stack(_matrices(3, 301, 4, 9, dev))          # odd size: slices 1, 2 are not 16-byte aligned
+    perms = ot.assign_exact_batch(odd)
+    for b in range(3):
+        assert np.array_equal(perms[b].cpu().numpy(), oracle.exact_perm(odd[b].cpu().numpy())), b
 
 
 def test_batch_small_sizes_and_single_problem():
