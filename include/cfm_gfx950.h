@@ -11,15 +11,17 @@
  *   - every pointer is a DEVICE pointer owned by the caller (contiguous,
  *     row-major) unless the parameter is documented "host";
  *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the
- *     call returns without synchronising, EXCEPT cfm_assign_exact_f32 and
- *     cfm_ode_*_mlp_f32 whose control flow is data dependent: they pump their
+ *     call returns without synchronising, EXCEPT cfm_assign_exact_f32,
+ *     cfm_assign_exact_batch_f32 and cfm_ode_*_mlp_f32 whose control flow is data dependent: they pump their
  *     step kernels on `stream` and poll a few bytes of device state, so they
  *     return only when the result is resident in the output buffers;
  *   - no entry point allocates or frees device memory: scratch comes from the
  *     caller through `ws` (size from cfm_workspace_bytes);
  *   - return value: 0 = ok, <0 = invalid argument (CFM_E*), >0 = hipError_t;
  *   - no exceptions cross the boundary; no global state except a lazily
- *     initialised per-device properties cache and the solver-parameter table
+ *     initialised per-device properties cache, per HOST THREAD the captured launch
+ *     programs (hipGraphs) of the exact solver's last four (workspace, size, batch,
+ *     stream) combinations + 2 KiB of pinned memory, and the solver-parameter table
  *     of include/cfm_gfx950_tuning.h (measurement / tuning exports that no
  *     binding needs; a solve snapshots the table under a mutex when it starts).
  */
