@@ -20,7 +20,7 @@
 // profile (no scratch, no oversized LDS reservation):
 //
 //   asg_step   every chip-wide step   UMIN0, INITRED, AUCTION, ARR, CONVERT, UMIN, COLRED, ROOTMIN,
-//                                     SAP, MS_FINISH, CERT       (119 VGPRs, <= 48 KiB LDS at n = 4096)
+//                                     SAP, MS_FINISH, CERT       (125 VGPRs, <= 48 KiB LDS at n = 4096)
 //   asg_build  candidate lists        BUILD            (n <= 4096; 8 waves, 128 KiB of row strips)
 //   asg_solve  one-workgroup list solver   SOLVER      (n <= 4096; 152 KiB of solver state: the forest phases run here)
 //
@@ -56,6 +56,13 @@
 //            atomics).
 //   phase D  fp64 certificate: dual feasibility + complementary slackness over
 //            the whole matrix, total cost.
+//
+//   bid lists  (n <= 4096) a row scan of phase A / B leaves the per-lane best column + cost and a bound behind;
+//            later bids of the row read those 512 bytes instead of the row while the bound decides the bid
+//            (bid_from_list / bid_list_store): half of the ~80 k row evaluations of a C3 solve.
+//   batches  cfm_assign_exact_batch_f32: nb problems of one size in ONE chain of launches — every kernel takes the
+//            carving of problem 0 and a byte stride, blockIdx.y is the problem (asg_shift), every problem runs its own
+//            state machine; 256 workgroups per launch in all, the bid rounds in their queue form (wide_bid_queue).
 //
 // Exactness comes from phases B-D (fp64 on exactly the fp32 costs the caller
 // passed); phase A is a heuristic warm start.
