@@ -222,6 +222,23 @@ class _OTMixin:
         i, j = self.ot_sampler._sample_indices(x0, x1)
         return self._sample(x0, x1, t, return_noise, idx=(i, j))
 
+    def sample_location_and_conditional_flow_group(self, batches, return_noise=False):
+        """Several minibatches at once (not in the reference: its loop couples one minibatch per step, ref:271-272).
+
+        ``batches``: ``[(x0, x1), ...]``.  Returns what one ``sample_location_and_conditional_flow`` call per pair
+        returns, pair by pair, with the host RNG consumed in the same order (per pair: the plan-sampling uniforms, then
+        ``t``, then the noise) — but the couplings are solved TOGETHER first: exact couplings of one square size share
+        one chain of launches (``assign_exact_batch``), which costs little more than one solve.  The couplings of the
+        next steps of a training loop depend on the data only, so a loop can ask for a few steps ahead
+        (``cfm_amd.prefetch.CouplingPrefetcher.submit_group`` does it on a side stream)."""
+        batches = list(batches)
+        sols = self.ot_sampler._solve_many(batches)
+        out = []
+        for (x0, x1), sol in zip(batches, sols):
+            i, j = self.ot_sampler._indices_from_solution(x0, x1, sol)
+            out.append(self._sample(x0, x1, None, return_noise, idx=(i, j)))
+        return out
+
     def guided_sample_location_and_conditional_flow(
         self, x0, x1, y0=None, y1=None, t=None, return_noise=False
     ):

@@ -450,7 +450,12 @@ class OTPlanSampler:
             i, j = self.sample_map(pi, n, replace=False)
             dev = _lib.require_gpu()
             return torch.from_numpy(i).to(dev), torch.from_numpy(j).to(dev)
-        kind, sol, M = self._solve(x0, x1)
+        return self._indices_from_solution(x0, x1, self._solve(x0, x1))
+
+    def _indices_from_solution(self, x0, x1, solution):
+        """The draw of ``_sample_indices`` for an already solved coupling (``_solve`` / ``_solve_many`` result)."""
+        n = x0.shape[0]
+        kind, sol, M = solution
         dev = M.device
         if kind == "plan":
             # get_map's diagnostics (ref:88-96) on the device plan, then sample_map (ref:116-121)

@@ -115,3 +115,21 @@ def test_grouped_couplings_equal_the_sequential_ones(dev):
     for r, g in zip(ref, got):
         for x, y in zip(r, g):
             assert torch.equal(x, y)
+
+
+def test_group_method_of_the_flow_matcher_equals_one_call_per_pair(dev):
+    """FM.sample_location_and_conditional_flow_group: same tensors, same host-RNG consumption as one
+    sample_location_and_conditional_flow call per pair (exact and entropic couplings)."""
+    from cfm_amd.conditional_flow_matching import (ExactOptimalTransportConditionalFlowMatcher,
+                                                   SchrodingerBridgeConditionalFlowMatcher)
+    data = _batches(5, 384, 8, dev)
+    for fm in (ExactOptimalTransportConditionalFlowMatcher(sigma=0.1),
+               SchrodingerBridgeConditionalFlowMatcher(sigma=1.0, ot_method="sinkhorn")):
+        torch.manual_seed(11); np.random.seed(11); torch.cuda.manual_seed(11)
+        ref = [fm.sample_location_and_conditional_flow(a, b) for a, b in data]
+        torch.manual_seed(11); np.random.seed(11); torch.cuda.manual_seed(11)
+        got = fm.sample_location_and_conditional_flow_group(data)
+        assert len(got) == len(ref)
+        for r, g in zip(ref, got):
+            for x, y in zip(r, g):
+                assert torch.equal(x, y)
