@@ -58,6 +58,7 @@ SIGNATURES = {
     "cfm_partial_entropic_f64": (_i, [_vp, _i, _i, _d, _d, _i, _d, _vp, _vp, _vp, _vp]),
     "cfm_assign_exact_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfm_assign_exact_batch_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cfm_transport_exact_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_perm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cfm_plan_sample_dense": (_i, [_vp, _i, _i, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_pi_f64": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $CFM_EXTRA_FLAGS"
 mkdir -p "$HERE/obj"
 objs=""
-for f in abi cost sinkhorn sinkhorn_pts assign sample elem mlp mlp_train ode unbalanced; do
+for f in abi cost sinkhorn sinkhorn_pts assign transport sample elem mlp mlp_train ode unbalanced; do
   src="$HERE/$f.hip"; obj="$HERE/obj/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/cfm_common.h" -nt "$obj" ] || [ "$HERE/gemm_core.h" -nt "$obj" ] || [ "$HERE/assign_sparse.h" -nt "$obj" ] || [ "$HERE/assign_small.h" -nt "$obj" ] || [ "$HERE/../../include/cfm_gfx950.h" -nt "$obj" ]; then
     "$HIPCC" $FLAGS -c "$src" -o "$obj" &

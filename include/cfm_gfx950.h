@@ -190,6 +190,17 @@ int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certified,
 int cfm_assign_exact_batch_f32(const float* const* M, int nb, int B, int* const* perm, int* certified,
                                double* total_cost, int* stats, void* ws, void* stream);
 
+/* K4r — exact OT between uniform marginals of DIFFERENT sizes (masses 1/B0 on the rows, 1/B1 on the columns).
+ * Replaces  pot.emd(a, b, M)  for x0.shape[0] != x1.shape[0]   torchcfm/optimal_transport.py:49,79,87
+ * Successive shortest augmenting paths on the B0 x B1 matrix itself (every row supplies B1/g units, every column
+ * takes B0/g, g = gcd; no lcm x lcm expansion), one wavefront, all state in LDS.  B0 + B1 <= 2048 (CFM_EINVAL beyond).
+ * plan [B0,B1] fp64 (written whole: zero off the support, units / lcm on it); *total_cost = <plan, M>;
+ * info (device int32[8]): {status (1 = optimal and certified in fp64: reduced costs >= -1e-10 max|M|, zero on the
+ * support, marginals exact; < 0 = failed, nothing certified), searches, row relaxations, support size, violations,
+ * units per row, units per column, matrix staged in LDS}.  Asynchronous on `stream`; the caller reads info[0]. */
+int cfm_transport_exact_f32(const float* M, int B0, int B1, double* plan, double* total_cost, int* info,
+                            void* stream);
+
 /* K6 (exact path) — draw n index pairs from the permutation plan.
  * Replaces sample_map()                      torchcfm/optimal_transport.py:116-121
  * for pi = P_perm / B:  np.random.choice over the flattened plan consumes n
