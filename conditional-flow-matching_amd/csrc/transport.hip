@@ -295,7 +295,7 @@ extern "C" int cfm_transport_exact_f32(const float* M, int B0, int B1, double* p
     const size_t budget = 158 * 1024;
     if (state > budget) return CFM_EINVAL;
     A.stage_m = (state + mbytes + 16 <= budget) ? 1 : 0;
-    A.scan_cap = 60000000LL;      // (1024 x 1000 needs ~10 M row relaxations; a cap, not a budget)
+    A.scan_cap = 4000000LL;       // status -7 beyond (1000 x 1024, d = 8: 2.0 M row relaxations, 25 s): bounds the run time of a single-wave kernel
     const size_t lds = state + (A.stage_m ? mbytes + 16 : 0);
     int rc = cfm_hip(hipMemsetAsync(plan, 0, sizeof(double) * (size_t)B0 * B1, s));
     if (rc) return rc;
