@@ -15,19 +15,21 @@
 //            on the scanned columns; the path takes min(supply left, demand left, smallest flow on its backward
 //            entries) units.  Repeated until the row is empty, row after row.
 //   finish   fp64 certificate (c - u - v >= -tol everywhere, = 0 on the support), plan = units / lcm, cost.
-// The support is kept as a flat edge list (a basic solution has < B0 + B1 entries; capacity 2 (B0 + B1), compacted
-// when full, error if that does not help): "the support rows of column j" and "the entry (i, j)" are one pass of the
-// wave over the list.
+// The support is kept as an edge list (a basic solution has < B0 + B1 entries; capacity 2 (B0 + B1), compacted when
+// full, error if that does not help) whose entries are chained per column: "the support rows of column j" and "the
+// entry (i, j)" are a walk down that column's chain (a pass of the wave over the whole list per path hop was most of
+// the first version's time).
 //
 // MI355X shape: ONE wavefront.  The method is a chain of dependent steps (a search step = pick the nearest
 // unscanned column, walk its support, relax one row); all state lives in LDS (<= 112 KiB for B0 + B1 <= 2048), the
 // matrix too when it fits, and a single wave needs no barrier between steps.  Measured (tools/transport_bench.py):
-// 127 x 128 (d = 2) 155 ms — 914 searches, 55 k row relaxations at 2.8 us: a lone wave exposes every LDS round trip
-// (~100 cycles, four per pass over the columns) — 255 x 256 1.3 s, 200 x 333 (d = 16) 0.6 s, 512 x 500 2.7 s (d = 64)
-// to 10.9 s (d = 2), 1000 x 1024 25 s.  Nearly equal sizes cascade partial flows down long chains (tools/proto/
-// proto20.py has the counts, proto24.py the same finding for an auction), so this is the EXACT path for the sizes of
-// the reference's tutorials and tests — the Python side sends B0 + B1 <= 512 here — not a fast one, and not for
-// 4096 vs 4000.  (POT's network simplex on the host: about a millisecond at 127 x 128.)
+// 127 x 128 (d = 2) 89 ms — 914 searches, 55 k row relaxations at 1.6 us: a lone wave exposes every LDS round trip
+// (~100 cycles, four per pass over the columns) — 255 x 256 0.66 s, 200 x 333 (d = 16) 0.30 s; the first version
+// (whole-list passes instead of the column chains, shuffle reductions: 155 ms / 1.3 s / 0.59 s) took 2.7 s (d = 64) to
+// 10.9 s (d = 2) at 512 x 500 and 25 s at 1000 x 1024.  Nearly equal sizes cascade partial flows down long chains
+// (tools/proto/proto20.py has the counts, proto24.py the same finding for an auction), so this is the EXACT path for the
+// sizes of the reference's tutorials and tests — the Python side sends B0 + B1 <= 512 here — not a fast one, and not
+// for 4096 vs 4000.  (POT's network simplex on the host: about a millisecond at 127 x 128.)
 #include "cfm_common.h"
 #include <mutex>
 
@@ -40,23 +42,48 @@ struct TpArgs {
     int stage_m; int ecap; long long scan_cap;
 };
 
+// wave64 DPP reductions (row_shr within 16-lane rows, then row_bcast 15 / 31; the result is read from lane 63): the
+// shuffle form costs 18 dependent LDS-crossbar round trips per arg-min, and a lone wave hides none of them
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int tp_dpp_i(int oldv, int v) { return __builtin_amdgcn_update_dpp(oldv, v, CTRL, ROWMASK, 0xf, false); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double tp_dpp_d(double oldv, double v) {
+    const int lo = tp_dpp_i<CTRL, ROWMASK>(__double2loint(oldv), __double2loint(v));
+    const int hi = tp_dpp_i<CTRL, ROWMASK>(__double2hiint(oldv), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double tp_wave_min_d(double v) {
+    v = fmin(v, tp_dpp_d<0x111, 0xf>(INFINITY, v));
+    v = fmin(v, tp_dpp_d<0x112, 0xf>(INFINITY, v));
+    v = fmin(v, tp_dpp_d<0x114, 0xf>(INFINITY, v));
+    v = fmin(v, tp_dpp_d<0x118, 0xf>(INFINITY, v));
+    v = fmin(v, tp_dpp_d<0x142, 0xa>(INFINITY, v));
+    v = fmin(v, tp_dpp_d<0x143, 0xc>(INFINITY, v));
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int tp_wave_min_i(int v) {
+    v = min(v, tp_dpp_i<0x111, 0xf>(0x7fffffff, v));
+    v = min(v, tp_dpp_i<0x112, 0xf>(0x7fffffff, v));
+    v = min(v, tp_dpp_i<0x114, 0xf>(0x7fffffff, v));
+    v = min(v, tp_dpp_i<0x118, 0xf>(0x7fffffff, v));
+    v = min(v, tp_dpp_i<0x142, 0xa>(0x7fffffff, v));
+    v = min(v, tp_dpp_i<0x143, 0xc>(0x7fffffff, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ void tp_argmin(double& d, int& j) {          // wave arg-min, ties to the smaller index; uniform
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double d2 = __shfl_xor(d, o, 64);
-        const int j2 = __shfl_xor(j, o, 64);
-        if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; }
-    }
+    const double dm = tp_wave_min_d(d);
+    j = tp_wave_min_i(d == dm ? j : 0x7fffffff);
+    d = dm;
 }
 
-// index of the entry (i, j) in the edge list, or -1 (uniform result)
-__device__ __forceinline__ int tp_find(const int* er, const int* ec, int ne, int i, int j) {
-    const int lane = threadIdx.x;
-    for (int e0 = 0; e0 < ne; e0 += 64) {
-        const int e = e0 + lane;
-        const bool hit = e < ne && er[e] == i && ec[e] == j;
-        const unsigned long long m = __ballot(hit);
-        if (m) return e0 + __ffsll((long long)m) - 1;
+// index of the entry (i, j) — a walk down column j's list (every lane reads the same words) — or -1
+__device__ __forceinline__ int tp_find(const int* er, const int* enext, const int* chead, int cap, int i, int j) {
+    int e = chead[j];
+    for (int w = 0; e >= 0 && w <= cap; ++w) {
+        if (er[e] == i) return e;
+        e = enext[e];
     }
     return -1;
 }
@@ -81,6 +108,8 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
     int* er = (int*)z; z += 4 * (size_t)ecap;
     int* ec = (int*)z; z += 4 * (size_t)ecap;
     int* eu = (int*)z; z += 4 * (size_t)ecap;
+    int* enext = (int*)z; z += 4 * (size_t)ecap;     // entries of one column are chained: chead[j] -> ... -> -1
+    int* chead = (int*)z; z += 4 * (size_t)B1;
     z = (char*)(((uintptr_t)z + 15) & ~(uintptr_t)15);
     const float* Mx = A.M;
     if (A.stage_m) {
@@ -91,7 +120,7 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
     int ne = 0, status = 1;
     long long scans = 0; int searches = 0;
     float cmax_abs = 0.f;
-    for (int j = lane; j < B1; j += 64) { v[j] = 0.0; rd[j] = q; scn[j] = 0; }
+    for (int j = lane; j < B1; j += 64) { v[j] = 0.0; rd[j] = q; scn[j] = 0; chead[j] = -1; }
     for (int i = lane; i < B0; i += 64) { intree[i] = 0; rs[i] = p; }
     __syncthreads();
     // ---- start: row minima, greedy push into the cheapest column
@@ -107,7 +136,7 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
         __syncthreads();
         if (lane == 0) {
             u[i] = bd;
-            if (dlt > 0) { er[ne] = i; ec[ne] = bj; eu[ne] = dlt; rs[i] = p - dlt; rd[bj] -= dlt; }
+            if (dlt > 0) { er[ne] = i; ec[ne] = bj; eu[ne] = dlt; enext[ne] = chead[bj]; chead[bj] = ne; rs[i] = p - dlt; rd[bj] -= dlt; }
         }
         if (dlt > 0) ++ne;
         __syncthreads();
@@ -142,15 +171,11 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
                 __syncthreads();
                 if (lane == 0) scn[bj] = 1;
                 // the support rows of column bj join the tree at label D and relax every column
-                for (int e0 = 0; e0 < ne; e0 += 64) {
-                    const int e = e0 + lane;
-                    int row = -1;
-                    if (e < ne && ec[e] == bj && eu[e] > 0) row = er[e];
-                    bool hit = row >= 0 && !intree[row];
-                    unsigned long long m = __ballot(hit);
-                    while (m) {
-                        const int b = __ffsll((long long)m) - 1; m &= m - 1;
-                        const int i = __shfl(row, b, 64);
+                __syncthreads();
+                int e = chead[bj];
+                for (int w = 0; e >= 0 && w <= ecap; ++w) {
+                    const int i = er[e], units = eu[e], nx = enext[e];
+                    if (units > 0 && !intree[i]) {
                         __syncthreads();
                         if (lane == 0) { intree[i] = 1; dr[i] = D; par[i] = bj; tlist[nt] = i; }
                         ++nt; ++scans;
@@ -162,6 +187,7 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
                         }
                         __syncthreads();
                     }
+                    e = nx;
                 }
                 __syncthreads();
                 if (scans > A.scan_cap) { status = -7; break; }
@@ -180,7 +206,7 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
                 for (int hop = 0; hop <= B0; ++hop) {
                     const int i = pred[j], pj = par[i];
                     if (pj < 0) break;
-                    const int e = tp_find(er, ec, ne, i, pj);
+                    const int e = tp_find(er, enext, chead, ecap, i, pj);
                     if (e < 0) { status = -8; break; }
                     dlt = min(dlt, eu[e]);
                     j = pj;
@@ -193,7 +219,7 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
                 int j = jsink;
                 for (int hop = 0; hop <= B0 && status == 1; ++hop) {
                     const int i = pred[j], pj = par[i];
-                    int e = tp_find(er, ec, ne, i, j);
+                    int e = tp_find(er, enext, chead, ecap, i, j);
                     __syncthreads();
                     if (e >= 0) { if (lane == 0) eu[e] += dlt; }
                     else {
@@ -202,6 +228,8 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
                             if (lane == 0) {
                                 int w = 0;
                                 for (int k = 0; k < ne; ++k) if (eu[k] > 0) { er[w] = er[k]; ec[w] = ec[k]; eu[w] = eu[k]; ++w; }
+                                for (int k = 0; k < B1; ++k) chead[k] = -1;
+                                for (int k = 0; k < w; ++k) { enext[k] = chead[ec[k]]; chead[ec[k]] = k; }
                                 dist[0] = (double)w;      // (dist is dead here: hand the count to the wave)
                             }
                             __syncthreads();
@@ -209,12 +237,12 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
                             __syncthreads();
                             if (ne >= ecap) { status = -10; break; }
                         }
-                        if (lane == 0) { er[ne] = i; ec[ne] = j; eu[ne] = dlt; }
+                        if (lane == 0) { er[ne] = i; ec[ne] = j; eu[ne] = dlt; enext[ne] = chead[j]; chead[j] = ne; }
                         ++ne;
                     }
                     __syncthreads();
                     if (pj < 0) break;
-                    e = tp_find(er, ec, ne, i, pj);
+                    e = tp_find(er, enext, chead, ecap, i, pj);
                     if (e < 0) { status = -8; break; }
                     __syncthreads();
                     if (lane == 0) eu[e] -= dlt;
@@ -265,7 +293,7 @@ __global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
 }
 
 static size_t tp_lds_state(int B0, int B1, int ecap) {
-    return (size_t)B1 * (8 + 8 + 4 + 4 + 4) + (size_t)B0 * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)ecap * 12 + 32;
+    return (size_t)B1 * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)B0 * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)ecap * 16 + 32;
 }
 
 static int tp_gcd(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
