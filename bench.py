@@ -257,6 +257,18 @@ def aux_legs(dev):
             out[f"{name}_iters_per_s"] = 1e3 / per
             out[f"{name}_gbs"] = 2 * 8.0 * Bn * Bn / (per * 1e-3) / 1e9
         out[f"{name}_iters_timed"] = [ia, ib]
+    # exact OT between batches of DIFFERENT sizes beyond the lcm expansion (127 vs 128): the transportation solver
+    try:
+        g = torch.Generator().manual_seed(0)
+        xa = torch.randn(127, 2, generator=g).to(dev); xb = (torch.randn(128, 2, generator=g) * 0.7 + 0.5).to(dev)
+        Mr = ot.cost_matrix(xa, xb)
+        ot.transport_exact(Mr)
+        tt = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); ot.transport_exact(Mr); tt.append((time.perf_counter() - t0) * 1e3)
+        out["transport_127x128_ms"] = float(np.median(tt))
+    except Exception as exc:  # noqa: BLE001 — a side leg must not take the line down
+        out["transport_127x128_ms"] = None; out["transport_error"] = repr(exc)
     out["ot_kernel_space_config"] = "C2 clouds, B=4096, reg=5.0 (reg_m=1 / m=1): per-iteration rate from the 45- vs 5-iteration difference, fastest of five each (iteration counts read back)"
     return out
 
