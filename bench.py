@@ -506,6 +506,14 @@ def main():
     ap.add_argument("--model-step", default="fused", choices=["fused", "eager"],
                     help="fused: cfm_amd.RegressionStep (one C call: forward + MSE + backward, then the one-launch Adam); "
                          "eager: the reference's four lines on the autograd.Function path")
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="the timed region (warm-up, barrier, K steps, barrier) is repeated this many times, each on a fresh "
+                         "empty pipeline; `value` is the MEDIAN region, every region's ms/step is in the line")
+    ap.add_argument("--partition", type=int, default=int(os.environ.get("CFM_BENCH_PARTITION", "0")),
+                    help="K > 0: chip partition (cfm_amd.streams.ChipPartition): K CUs of every XCD for the exact solver's "
+                         "streams, the rest for the dense products (cost matrix, model step); 0: every stream on all CUs")
+    ap.add_argument("--priority", type=int, default=int(os.environ.get("CFM_BENCH_PRIORITY", "0")),
+                    help="HIP priority of the coupling workers' streams when no partition is used (-1: high)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the C1 / C2 / C5 / roofline legs")
     ap.add_argument("--cpu-standin", action="store_true",
@@ -597,9 +605,15 @@ def main():
         opt.step()
 
     pre = None
+    part, main_stream = None, None
+    if args.pipeline and args.partition > 0:
+        from cfm_amd.streams import ChipPartition
+        part = ChipPartition(dev, solver_cus_per_xcd=args.partition)
+        main_stream = part.dense_stream()
+        torch.cuda.set_stream(main_stream)          # the model step of the pipelined loop runs on the dense CU subset
     if args.pipeline:
         from cfm_amd.prefetch import CouplingPrefetcher
-        pre = CouplingPrefetcher(fm, dev, workers=args.pipeline)
+        pre = CouplingPrefetcher(fm, dev, workers=args.pipeline, partition=part, priority=args.priority)
         # one-time costs per worker thread (stream, workspaces, the solver's captured launch programs for each job shape
         # the loops are going to submit) are paid before the warm-up steps, on every worker
         rs_np, rs_t = np.random.get_state(), torch.get_rng_state()
@@ -610,19 +624,33 @@ def main():
             else:
                 pre.prime(lambda: couple(*pool[0], draw()))
         np.random.set_state(rs_np); torch.set_rng_state(rs_t)
-    elapsed, gathered = timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple, model_step,
-                                     draw, pre, args.pipeline, dev, args.group, couple_group)
+    # the timed region, `repeats` times (each: warm-up, barrier + sync, EXACTLY K steps on a pipeline that starts empty
+    # and is drained, all-gather, sync + barrier; max over ranks) — `value` is the median region (one
+    # 27 ms window is a sample, not a measurement)
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        el, gathered = timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple, model_step,
+                                    draw, pre, args.pipeline, dev, args.group, couple_group)
+        assert gathered is None or gathered.shape[0] == world * B
+        regions.append(el)
+    elapsed = float(np.median(regions))
     if pre is not None:
         pre.close()
-    assert gathered is None or gathered.shape[0] == world * B
+    if main_stream is not None:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
     # the same K steps strictly one after the other (no overlap at all): what an unmodified script gets
-    seq_s = None
+    seq_s, seq_all = None, []
     if args.pipeline and world == 1:
         n_seq = min(20, args.steps)
         run_steps(pool, 0, 2, couple, model_step, draw)
-        torch.cuda.synchronize(); ts = time.perf_counter()
-        run_steps(pool, args.warmup, n_seq, couple, model_step, draw)
-        torch.cuda.synchronize(); seq_s = (time.perf_counter() - ts) / n_seq
+        for _ in range(max(1, args.repeats)):
+            torch.cuda.synchronize(); ts = time.perf_counter()
+            run_steps(pool, args.warmup, n_seq, couple, model_step, draw)
+            torch.cuda.synchronize(); seq_all.append((time.perf_counter() - ts) / n_seq)
+        seq_s = float(np.median(seq_all))
+    if part is not None:
+        part.close()
 
     if rank != 0:
         return
@@ -632,6 +660,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "repeats": len(regions), "ms_per_step_all": [round(r / args.steps * 1e3, 4) for r in regions],
+        "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
+        "spread_rel": (max(regions) - min(regions)) / elapsed,
         "config": {"workload": "C3: MNIST-shaped d=784, B=4096 per GPU, ExactOptimalTransportConditionalFlowMatcher "
                                "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd (fp32-MFMA HIP kernels) + fused Adam (HIP)"
                                + ("; one all-gather of the final x_t over RCCL inside the timed region" if world > 1 else ""),
@@ -642,11 +673,16 @@ def main():
                                     "cfm_assign_exact_batch_f32)" if args.group > 1 else ""))
                                 if args.pipeline else "sequential"),
                    "prefetch_jobs": args.pipeline, "prefetch_group": args.group if args.pipeline else 0,
+                   "chip_partition": ({"solver_cus": part.solver_cus, "dense_cus": part.dense_cus,
+                                       "note": "CU-masked streams: the exact solver's launches on solver_cus, cost matrix "
+                                               "/ sampling / model step on dense_cus"} if part is not None else None),
+                   "worker_stream_priority": args.priority,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
         **({"valid": False, "data": "synthetic; ranks SHARE one GPU (CFM_BENCH_SHARE_GPU): code-path test, NOT a measurement"}
            if shared else {}),
         "value_sequential": (B / seq_s) if seq_s else None,
         "ms_per_step_sequential": seq_s * 1e3 if seq_s else None,
+        "ms_per_step_sequential_all": [round(x * 1e3, 4) for x in seq_all],
     }
     if world == 1 and not args.no_legs:
         with torch.cuda.stream(torch.cuda.Stream()):

@@ -19,6 +19,8 @@ if os.environ.get("CFM_LIB_PATH"):      # a variant build for A/B measurements (
 _lock = threading.Lock()
 _lib = None
 
+ABI_VERSION = 2      # CFM_ABI_VERSION of include/cfm_gfx950.h
+
 # ops (include/cfm_gfx950.h)
 OP_SINKHORN, OP_ASSIGN, OP_SAMPLE_DENSE, OP_MLP, OP_ODE, OP_UNBALANCED, OP_COST, OP_MLP_TRAIN = 1, 2, 3, 4, 5, 6, 7, 8
 VARIANT_ICFM, VARIANT_SB, VARIANT_TARGET, VARIANT_VP = 0, 1, 2, 3
@@ -45,6 +47,8 @@ _d = ctypes.c_double
 SIGNATURES = {
     "cfm_abi_version": (_i, []),
     "cfm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "cfm_stream_create_cu_mask": (_i, [_vp, _i, _vp]),
+    "cfm_stream_destroy": (_i, [_vp]),
     "cfm_sqeuclid_cost_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "cfm_sqeuclid_cost_ws_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "cfm_scale_inv_f32": (_i, [_vp, _sz, _vp, _vp]),
@@ -121,12 +125,22 @@ def load():
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback."
             )
         lib = ctypes.CDLL(LIB_PATH)
+        # version first: a stale build (or a CFM_LIB_PATH variant of another round) must say so, not die on getattr
+        try:
+            lib.cfm_abi_version.restype = _i
+            have = lib.cfm_abi_version()
+        except AttributeError:
+            have = None
+        if have != ABI_VERSION:
+            raise CfmBackendError(f"{LIB_PATH}: ABI version {have}, this binding needs {ABI_VERSION} — rebuild "
+                                  "(python -c 'import __graft_entry__ as g; g.build()')")
         for name, (res, args) in list(SIGNATURES.items()) + list(EXTRA_SIGNATURES.items()):
-            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                raise CfmBackendError(f"{LIB_PATH} does not export {name}: stale build, rebuild it") from None
             fn.restype = res
             fn.argtypes = args
-        if lib.cfm_abi_version() != 1:
-            raise CfmBackendError("libcfm_gfx950.so ABI version mismatch")
         _lib = lib
     return _lib
 

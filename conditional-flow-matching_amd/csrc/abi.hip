@@ -29,3 +29,25 @@ extern "C" size_t cfm_workspace_bytes(int op, int B0, int B1, int d) {
         default: return 0;
     }
 }
+
+// ---- runtime: CU-partitioned streams (hipExtStreamCreateWithCUMask) ----
+extern "C" int cfm_stream_create_cu_mask(const uint32_t* cu_mask, int n_words, void** stream) {
+    if (!cu_mask || !stream || n_words < 1 || n_words > 32) return CFM_EINVAL;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CFM_EINVAL;
+    const int ncu = prop.multiProcessorCount, nx = 8;
+    int per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ncu && i < 32 * n_words; ++i)
+        if (cu_mask[i >> 5] >> (i & 31) & 1u) per_xcd[i % nx]++;
+    for (int x = 0; x < nx && x < ncu; ++x)
+        if (per_xcd[x] == 0) return CFM_EINVAL;           // an XCD without CUs: its share of every grid would never run
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask);
+    if (e != hipSuccess) return (int)e;
+    *stream = (void*)s;
+    return 0;
+}
+extern "C" int cfm_stream_destroy(void* stream) {
+    if (!stream) return CFM_EINVAL;
+    return cfm_hip(hipStreamDestroy((hipStream_t)stream));
+}

@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import streams as _streams
 from ._lib import CfmBackendError, check, ptr, stream_ptr
 
 _SINKHORN_MAX_ITER = 1000      # POT ot.sinkhorn default numItermax
@@ -71,7 +72,12 @@ def cost_matrix(x0, x1, squared=True, normalize=False, matrix_cores=True):
 
 
 def assign_exact(M, return_info=False):
-    """Optimal permutation of a square fp32 cost matrix on the GPU (int32 [B])."""
+    """Optimal permutation of a square fp32 cost matrix on the GPU (int32 [B]).  Runs on the calling thread's solver
+    stream when one is set (``cfm_amd.streams.solver_stream``: the CU subset a ``ChipPartition`` reserves for it)."""
+    return _streams.run_on_solver_stream(_assign_exact, M, return_info)
+
+
+def _assign_exact(M, return_info=False):
     lib = _lib.load()
     B = M.shape[0]
     if M.shape[1] != B:
@@ -102,7 +108,12 @@ def assign_exact(M, return_info=False):
 def assign_exact_batch(Ms, return_info=False):
     """Optimal permutations of several square fp32 cost matrices of the SAME size, solved together: every launch of the
     latency-bound solve carries all of them (cfm_assign_exact_batch_f32), so nb couplings cost little more than one.
-    `Ms`: a list of [B,B] tensors or one [nb,B,B] tensor.  Returns an int32 [nb,B] tensor (row b = assign_exact(Ms[b]))."""
+    `Ms`: a list of [B,B] tensors or one [nb,B,B] tensor.  Returns an int32 [nb,B] tensor (row b = assign_exact(Ms[b])).
+    Runs on the calling thread's solver stream when one is set (``cfm_amd.streams.solver_stream``)."""
+    return _streams.run_on_solver_stream(_assign_exact_batch, [m for m in Ms], return_info)
+
+
+def _assign_exact_batch(Ms, return_info=False):
     import ctypes
     lib = _lib.load()
     Ms = [m for m in Ms]

@@ -15,30 +15,47 @@ import threading
 
 import torch
 
+from . import streams as _streams
+
 
 class CouplingPrefetcher:
     """``submit(x0, x1)`` -> handle; ``handle.result()`` -> the tensors, ready for the caller's
     current stream.  ``workers`` couplings can be in flight at once."""
 
-    def __init__(self, flow_matcher, device=None, workers=1):
+    def __init__(self, flow_matcher, device=None, workers=1, partition=None, priority=0):
+        """partition: a ``cfm_amd.streams.ChipPartition`` — every worker then owns TWO streams: one on the partition's
+        dense CU subset (cost matrix, sampling, x_t / u_t) and one on its solver subset, onto which the exact
+        solver's launches are redirected (``streams.solver_stream``); run the model step on
+        ``partition.dense_stream()`` too and the solver's rounds no longer wait for slots the dense products hold.
+        priority: HIP stream priority of the workers' streams when no partition is given (-1 = high)."""
         self.fm = flow_matcher
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.partition, self.priority = partition, int(priority)
+        self.workers = max(1, int(workers))
         self._tls = threading.local()
-        self._pool = _cf.ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="cfm-coupling")
+        self._pool = _cf.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="cfm-coupling")
 
     def _stream(self):
         s = getattr(self._tls, "stream", None)
         if s is None:
             torch.cuda.set_device(self.device)
-            s = self._tls.stream = torch.cuda.Stream(device=self.device)
+            if self.partition is not None:
+                s = self._tls.stream = self.partition.dense_stream()
+                self._tls.solver = self.partition.solver_stream()
+            else:
+                s = self._tls.stream = torch.cuda.Stream(device=self.device, priority=self.priority)
+                self._tls.solver = None
         return s
+
+    def _solver_ctx(self):
+        return _streams.solver_stream(getattr(self._tls, "solver", None))
 
     def _work(self, x0, x1, ready, hook, drawn):
         if self.device.type != "cuda":           # host tensors (the CPU multi-process tests): plain worker thread
             return (hook(x0, x1, drawn) if hook is not None
                     else self.fm.sample_location_and_conditional_flow(x0, x1)), None
         stream = self._stream()
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(stream), self._solver_ctx():
             stream.wait_event(ready)                  # x0 / x1 were produced on the caller's stream
             if hook is not None:
                 out = hook(x0, x1, drawn)
@@ -73,7 +90,7 @@ class CouplingPrefetcher:
         if self.device.type != "cuda":
             return hook(batches, drawn), None
         stream = self._stream()
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(stream), self._solver_ctx():
             stream.wait_event(ready)
             out = hook(batches, drawn)
             done = torch.cuda.Event()
@@ -85,17 +102,23 @@ class CouplingPrefetcher:
         One-time costs are per worker — its stream, its workspaces, the solver's launch programs (hipGraphs are
         captured per host thread) — so a loop that wants none of them inside its first steps primes the workers with a
         throw-away job of the shape it is going to submit."""
-        n = self._pool._max_workers
+        n = self.workers
         gate = threading.Barrier(n)
 
         def job():
-            gate.wait()                     # n jobs, n threads: nobody takes two
+            try:
+                gate.wait(timeout=120.0)    # n jobs, n threads: nobody takes two
+            except threading.BrokenBarrierError:
+                raise RuntimeError(f"CouplingPrefetcher.prime: {n} worker threads did not all start within 120 s "
+                                   "(is the pool busy with unfinished jobs?)") from None
             if self.device.type != "cuda":
                 fn(); return
             stream = self._stream()
-            with torch.cuda.stream(stream):
+            with torch.cuda.stream(stream), self._solver_ctx():
                 fn()
             stream.synchronize()
+            if getattr(self._tls, "solver", None) is not None:
+                self._tls.solver.synchronize()
         for f in [self._pool.submit(job) for _ in range(n)]:
             f.result()
 

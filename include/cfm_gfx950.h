@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CFM_ABI_VERSION 1
+#define CFM_ABI_VERSION 2
 
 /* error codes (negative) */
 #define CFM_EINVAL   (-1)  /* bad shape / null pointer / unsupported size      */
@@ -63,6 +63,18 @@ int cfm_abi_version(void);
 
 /* Bytes of device scratch an op needs for the given problem (0 on bad op). */
 size_t cfm_workspace_bytes(int op, int B0, int B1, int d);
+
+/* Runtime — a HIP stream restricted to a subset of the chip's compute units (hipExtStreamCreateWithCUMask).
+ * The reference overlaps nothing: its coupling runs on the host between two model steps
+ * (torchcfm/conditional_flow_matching.py:271-272, examples/images/cifar10/train_cifar10.py:141-151).  Here the
+ * couplings of the next minibatches run beside the model step (cfm_amd.prefetch); the latency-bound rounds of the
+ * exact solver and the dense fp32-MFMA products then fight for workgroup slots on every CU unless the chip is
+ * PARTITIONED: solver streams on one CU subset, dense streams on the complement.
+ * cu_mask: HOST array of n_words 32-bit words; bit i = logical CU i of the current device (gfx950 in SPX mode:
+ * XCD i % 8, CU i / 8 of that XCD); every XCD must keep at least one CU (CFM_EINVAL otherwise: a queue without
+ * CUs on one XCD never drains).  *stream receives a hipStream_t the caller owns (cfm_stream_destroy). */
+int cfm_stream_create_cu_mask(const uint32_t* cu_mask, int n_words, void** stream);
+int cfm_stream_destroy(void* stream);
 
 /* K1 — squared-Euclidean cost matrix  M[i,j] = sum_k (x0[i,k]-x1[j,k])^2.
  * Replaces  torch.cdist(x0, x1) ** 2       torchcfm/optimal_transport.py:84
