@@ -73,8 +73,8 @@ SIGNATURES = {
     "cfm_mlp_forward_train_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "cfm_mlp_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfm_sde_em_mlp_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, ctypes.c_ulonglong, _vp, _vp, _vp]),
-    "cfm_mlp_regression_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "cfm_adam_step_f32": (_i, [_vp, _i, _d, _d, _d, _d, _d, _i, _vp]),
+    "cfm_mlp_regression_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cfm_adam_step_f32": (_i, [_vp, _i, _d, _d, _d, _d, _d, _i, _d, _vp]),
     "cfm_sde_em_step_f32": (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _sz, _vp]),
     "cfm_rbf_mix_sum_f32": (_i, [_vp, _sz, _vp, _i, _vp, _vp]),
     "cfm_ode_euler_mlp_f32": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -199,7 +199,7 @@ static int launch_gemm(const float* A, int lda, const float* Bm, int ldb, float*
 static int mlp_backward_impl(const float* const* acts, const float* const* preact, const float* const* W,
                              const int* dims, int n_layers, int B, const float* dout, float* const* dW,
                              float* const* db, float* dx, void* ws, hipStream_t s, const float* tvec,
-                             const ReduceJob* extra) {
+                             const ReduceJob* extra, void* const* layer_done = nullptr) {
     int maxw = 0; size_t maxp = 0;
     for (int l = 0; l <= n_layers; ++l) maxw = dims[l] > maxw ? dims[l] : maxw;
     for (int l = 0; l < n_layers; ++l) { const size_t p = (size_t)dims[l] * dims[l + 1]; maxp = p > maxp ? p : maxp; }
@@ -229,6 +229,15 @@ static int mlp_backward_impl(const float* const* acts, const float* const* preac
         T.job[T.count++] = ReduceJob{part, dW[l], np, np, S, split_t ? K : 0, Kfull, 0};
         T.job[T.count++] = ReduceJob{bpart, db[l], (unsigned long long)N, (unsigned long long)N, S, 0, 0, 0};
         if (split_t) T.job[T.count++] = ReduceJob{tpart, dW[l] + K, (unsigned long long)N, (unsigned long long)N, S, 1, Kfull, 0};
+        if (layer_done) {
+            // bucketed form (data parallel): this layer's gradients are final as soon as its own reduction has run —
+            // the caller's communication stream waits for layer_done[l] and all-reduces them while the remaining
+            // layers' products run.  Same jobs, same order of the partial sums: bit-equal to the one-reduction form.
+            if (l == 0 && extra) T.job[T.count++] = *extra;
+            hipLaunchKernelGGL(reduce_splits_multi, dim3(256, T.count), dim3(256), 0, s, T);
+            T.count = 0;
+            if (layer_done[l]) { const hipError_t e = hipEventRecord((hipEvent_t)layer_done[l], s); if (e != hipSuccess) return (int)e; }
+        }
         // dgrad: dz_prev[B,K] = (dz[B,N] . W[N,K]) * selu'(z_prev)
         if (l > 0) {
             float* dst = gbuf[l & 1];
@@ -240,6 +249,7 @@ static int mlp_backward_impl(const float* const* acts, const float* const* preac
             if (rc) return rc;
         }
     }
+    if (layer_done) return cfm_status();
     if (extra) T.job[T.count++] = *extra;
     hipLaunchKernelGGL(reduce_splits_multi, dim3(256, T.count), dim3(256), 0, s, T);
     return cfm_status();
@@ -290,7 +300,8 @@ __global__ __launch_bounds__(256) void mse_grad(float* __restrict__ v, const flo
 extern "C" int cfm_mlp_regression_step_f32(const float* xt, const float* t, const float* ut,
                                            const float* const* W, const float* const* b, const int* dims, int n_layers,
                                            int B, float* const* hidden, float* const* preact, float* g,
-                                           float* const* dW, float* const* db, float* loss, void* ws, void* stream) {
+                                           float* const* dW, float* const* db, float* loss, void* const* layer_done,
+                                           void* ws, void* stream) {
     if (!xt || !ut || !W || !b || !dims || !g || !dW || !db || !loss || !ws || n_layers < 1 || n_layers > MLP_MAX_LAYERS - 1 || B < 1)
         return CFM_EINVAL;
     if (n_layers > 1 && (!hidden || !preact)) return CFM_EINVAL;
@@ -324,7 +335,7 @@ extern "C" int cfm_mlp_regression_step_f32(const float* xt, const float* t, cons
     acts[0] = xt; zs[0] = nullptr;
     for (int l = 1; l < n_layers; ++l) { acts[l] = hidden[l - 1]; zs[l] = preact[l - 1]; }
     const ReduceJob lj = ReduceJob{lpart, loss, 1ull, 1ull, MSE_BLOCKS, 0, 0, 0};
-    return mlp_backward_impl(acts, zs, W, dims, n_layers, B, g, dW, db, nullptr, ws, s, has_t ? t : nullptr, &lj);
+    return mlp_backward_impl(acts, zs, W, dims, n_layers, B, g, dW, db, nullptr, ws, s, has_t ? t : nullptr, &lj, layer_done);
 }
 
 // ------------------------------------------------------------------- Adam ----
@@ -341,11 +352,15 @@ struct AdamTable { float* p; const float* g; float* m; float* v; unsigned long l
 //  torch 2.10, found by probing the alternatives: tools/probe/adam_probe.py)
 __global__ __launch_bounds__(256) void adam_multi(const AdamTable* __restrict__ tab, int n_tensors,
                                                   float w1, float beta2, float w2, float bc2_sqrt, float eps,
-                                                  float step_size, float weight_decay) {
+                                                  float step_size, float weight_decay, float grad_scale) {
     for (int q = blockIdx.y; q < n_tensors; q += gridDim.y) {
         const AdamTable T = tab[q];
         for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < T.n; e += (size_t)gridDim.x * 256) {
             float g = T.g[e];
+            if (grad_scale != 1.f) {              // data parallel: the all-reduced SUM -> the mean (`grad.mul_(1 / world)`),
+                g = __fmul_rn(g, grad_scale);     // folded into this launch; .grad is left holding the mean, as DDP leaves it
+                const_cast<float*>(T.g)[e] = g;
+            }
             const float p = T.p[e];
             if (weight_decay != 0.f) g = fmaf(weight_decay, p, g);
             float m = T.m[e], v = T.v[e];
@@ -360,13 +375,13 @@ __global__ __launch_bounds__(256) void adam_multi(const AdamTable* __restrict__ 
 
 // table: device array of n_tensors AdamTable records {param, grad, exp_avg, exp_avg_sq, numel}
 extern "C" int cfm_adam_step_f32(const void* table, int n_tensors, double lr, double beta1, double beta2, double eps,
-                                 double weight_decay, int step, void* stream) {
-    if (!table || n_tensors < 0 || step < 1) return CFM_EINVAL;
+                                 double weight_decay, int step, double grad_scale, void* stream) {
+    if (!table || n_tensors < 0 || step < 1 || !(grad_scale > 0.0)) return CFM_EINVAL;
     if (n_tensors == 0) return 0;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     const double step_size = lr / bc1, bc2_sqrt = sqrt(bc2);
     hipLaunchKernelGGL(adam_multi, dim3(256, n_tensors < 16 ? n_tensors : 16), dim3(256), 0, (hipStream_t)stream,
                        (const AdamTable*)table, n_tensors, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)bc2_sqrt, (float)eps, (float)step_size, (float)weight_decay);
+                       (float)bc2_sqrt, (float)eps, (float)step_size, (float)weight_decay, (float)grad_scale);
     return cfm_status();
 }

@@ -832,6 +832,8 @@ __global__ __launch_bounds__(256) void ode_small_em(SmArgs F, SmArgs S, int has_
             const SmTile v = sm_field(x, st.te, F, d, Ab0, Ab1, WlF, blF, wtF, wv, lane);
             SmTile sc;
             if (has_s) sc = sm_field(x, st.te, S, d, Ab0, Ab1, WlS, blS, wtS, wv, lane);
+            static_assert(SM_V == 4, "ode_small_em draws ONE Philox block of 4 normals per lane and step: with SM_MB > 1 "
+                                     "elements i and i + 4 would share a normal (draw SM_V / 4 blocks, counter word + (i >> 2))");
             float z[4] = {0.f, 0.f, 0.f, 0.f};
             if (!xi && st.gs != 0.f) philox_normal4(seed, (unsigned)k, (unsigned long long)(row0 / SM_ROWS) * 256 + tid, z);
 #pragma unroll

@@ -36,7 +36,9 @@ class FusedAdam(torch.optim.Optimizer):
         return cached[1]
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale=1.0):
+        """grad_scale: every gradient is multiplied by it first, inside the same launch, and left scaled in ``.grad``
+        (data parallel: the all-reduced sum -> the mean; ``RegressionStep`` passes 1 / world size)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -65,7 +67,7 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             check(lib.cfm_adam_step_f32(ctypes.c_void_p(table.data_ptr()), len(ps), float(group["lr"]), float(b1),
                                         float(b2), float(group["eps"]), float(group["weight_decay"]), step,
-                                        stream_ptr()), "cfm_adam_step_f32")
+                                        float(grad_scale), stream_ptr()), "cfm_adam_step_f32")
             for s in states:
                 s["step"] = step
         return loss

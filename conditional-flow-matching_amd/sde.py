@@ -93,6 +93,12 @@ def sdeint(sde, y0, ts, method="euler", dt=1e-3, generator=None, noise="philox",
         dev = _lib.require_gpu()
         y = _lib.to_dev_f32(y0, dev).clone()
         fields = _fused_fields(sde) if (y.shape[1] <= 64 and fused is not False) else None
+        if fields is not None and y.shape[1] != fields[2][4]:
+            # the one-launch kernel reads y0 with the fields' output width as its pitch: a state of another width
+            # must not reach it (the stepping path below raises the layer's shape error instead)
+            if fused is True:
+                raise ValueError(f"sdeint(fused=True): y0 has {y.shape[1]} columns, the fields map {fields[2][4]}")
+            fields = None
         if fused is True and fields is None:
             raise ValueError("sdeint(fused=True): needs two 4-layer time-varying cfm_amd.MLP fields of widths <= 64")
         if fields is not None:

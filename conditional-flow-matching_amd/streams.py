@@ -23,6 +23,7 @@ from ._lib import check
 
 _tls = threading.local()
 N_XCD = 8
+_pool, _pool_lock = {}, threading.Lock()      # (device, mask words) -> parked CU-masked streams (see ChipPartition.close)
 
 
 def _mask_words(bits, ncu):
@@ -61,15 +62,20 @@ class ChipPartition:
         return len(self.dense_bits)
 
     def _create(self, bits):
-        lib = _lib.load()
-        words = _mask_words(bits, self.ncu)
-        arr = (ctypes.c_uint32 * len(words))(*words)
-        out = ctypes.c_void_p(0)
-        with torch.cuda.device(self.device):
-            check(lib.cfm_stream_create_cu_mask(arr, len(words), ctypes.byref(out)), "cfm_stream_create_cu_mask")
-        s = torch.cuda.ExternalStream(out.value, device=self.device)
+        words = tuple(_mask_words(bits, self.ncu))
+        key = (str(self.device), words)
+        with _pool_lock:
+            free = _pool.setdefault(key, [])
+            s = free.pop() if free else None
+        if s is None:
+            lib = _lib.load()
+            arr = (ctypes.c_uint32 * len(words))(*words)
+            out = ctypes.c_void_p(0)
+            with torch.cuda.device(self.device):
+                check(lib.cfm_stream_create_cu_mask(arr, len(words), ctypes.byref(out)), "cfm_stream_create_cu_mask")
+            s = torch.cuda.ExternalStream(out.value, device=self.device)
         with self._lock:
-            self._streams.append((out.value, s))
+            self._streams.append((key, s))
         return s
 
     def solver_stream(self):
@@ -79,12 +85,16 @@ class ChipPartition:
         return self._create(self.dense_bits)
 
     def close(self):
-        lib = _lib.load()
+        """Synchronise this partition's streams and park them for the next partition with the same masks.  They are NOT
+        destroyed: torch's caching allocator keeps referring to every stream a tensor was ever recorded on
+        (``record_stream`` -> an event recorded on that stream when the block is freed), so a destroyed handle would be
+        used after free; ``cfm_stream_destroy`` is for callers that own the whole lifetime of what ran on the stream."""
         with self._lock:
             streams, self._streams = self._streams, []
-        for handle, s in streams:
+        for key, s in streams:
             s.synchronize()
-            lib.cfm_stream_destroy(ctypes.c_void_p(handle))
+            with _pool_lock:
+                _pool.setdefault(key, []).append(s)
 
 
 @contextlib.contextmanager

@@ -16,8 +16,11 @@ epilogue, MSE + its gradient seed, dgrad / wgrad, one fixed-order reduction) fol
 launches of this library's kernels and no eager PyTorch op in between (the eager form spends ~10 extra
 ``at::native`` launches on cat / sub / pow / mean / fill per step).  Same arithmetic as the autograd path
 (same kernels); gradients land in persistent ``.grad`` buffers, so the optimizer's pointer table is built once.
-With ``torch.distributed`` initialised (one process per GPU, rank-local coupling) the flat gradient buffer is
-averaged with ONE all-reduce between the two calls — the DDP contract of train_cifar10_ddp.py:167-180.
+With ``torch.distributed`` initialised (one process per GPU, rank-local coupling) the gradients are averaged the way
+the reference's DDP wrapper does it (train_cifar10_ddp.py:92,167-180): one bucket per layer, all-reduced on a
+communication stream as soon as that layer's gradient is final (``layer_done`` events recorded by the C call between
+its launches) while the remaining layers' products still run; the compute stream waits for the buckets, and the
+``1 / world`` of the mean is a factor inside the Adam launch (``grad_scale``) — no eager op in the step for N > 1 either.
 """
 import ctypes
 
@@ -53,6 +56,12 @@ class RegressionStep:
                 p.grad = v
                 views.append(v)
         self._gviews = views
+        # per-layer buckets of the flat buffer ([W_l, b_l] are adjacent) + one event per layer for the data-parallel form
+        self._buckets, off = [], 0
+        for l in self.lins:
+            nl = l.weight.numel() + l.bias.numel()
+            self._buckets.append(self.flat_grad[off:off + nl]); off += nl
+        self._events = self._comm = self._evp = None
         self._B = None
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
 
@@ -69,8 +78,20 @@ class RegressionStep:
             self.cd = (ctypes.c_int * (n + 1))(*d)
             self._B = B
 
-    def backward_only(self, t, xt, ut):
-        """forward + loss + backward; returns the loss (0-dim device tensor, overwritten by the next call)."""
+    def _dp_setup(self):
+        """events (created by a first record: torch makes the HIP event lazily) and the communication stream"""
+        if self._events is None:
+            cur = torch.cuda.current_stream(self.dev)
+            self._events = [torch.cuda.Event() for _ in range(self.n)]
+            for e in self._events:
+                e.record(cur)
+            self._evp = (ctypes.c_void_p * self.n)(*[e.cuda_event for e in self._events])
+            self._comm = torch.cuda.Stream(device=self.dev)
+        return self._evp
+
+    def backward_only(self, t, xt, ut, layer_events=None):
+        """forward + loss + backward; returns the loss (0-dim device tensor, overwritten by the next call).
+        layer_events: ctypes array of n hipEvent_t (see ``cfm_mlp_regression_step_f32``: ``layer_done``) or None."""
         lib = _lib.load()
         xt = xt.detach().reshape(xt.shape[0], -1)
         ut = ut.detach().reshape(ut.shape[0], -1)
@@ -94,15 +115,26 @@ class RegressionStep:
         dWp = (ctypes.c_void_p * n)(*[self._gviews[2 * l].data_ptr() for l in range(n)])
         dbp = (ctypes.c_void_p * n)(*[self._gviews[2 * l + 1].data_ptr() for l in range(n)])
         check(lib.cfm_mlp_regression_step_f32(ptr(xt), ptr(tt), ptr(ut), Wp, bp, self.cd, n, B, self.hp, self.zp,
-                                              ptr(self.g), dWp, dbp, ptr(self.loss), ptr(self.ws), stream_ptr()),
+                                              ptr(self.g), dWp, dbp, ptr(self.loss), layer_events, ptr(self.ws),
+                                              stream_ptr()),
               "cfm_mlp_regression_step_f32")
         return self.loss
 
     def __call__(self, t, xt, ut):
-        loss = self.backward_only(t, xt, ut)
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_grad)
-            self.flat_grad.mul_(1.0 / dist.get_world_size())
-        self.opt.step()
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world <= 1:
+            loss = self.backward_only(t, xt, ut)
+            self.opt.step()
+            return loss
+        evp = self._dp_setup()
+        loss = self.backward_only(t, xt, ut, layer_events=evp)       # asynchronous: the backward is still running
+        works = []
+        with torch.cuda.stream(self._comm):
+            for l in range(self.n - 1, -1, -1):                      # the order the gradients become final in
+                self._comm.wait_event(self._events[l])
+                works.append(dist.all_reduce(self._buckets[l], async_op=True))
+        for w in works:
+            w.wait()                                                 # the compute stream waits for the buckets
+        self.opt.step(grad_scale=1.0 / world)                        # sum -> mean inside the Adam launch
         return loss

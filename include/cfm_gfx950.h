@@ -307,17 +307,26 @@ int cfm_mlp_backward_f32(const float* const* acts, const float* const* preact, c
  * xt [B, dims[0] - 1] and t [B] when the net is time varying (the time column is never materialised), or
  * xt [B, dims[0]] and t = NULL.  hidden / preact as in cfm_mlp_forward_train_f32; g [B, dims[n_layers]] receives
  * d loss / d v; dW[l] [dims[l+1], dims[l]], db[l]; loss: device float.  Deterministic (fixed-order reductions).
+ * layer_done (HOST array of n_layers hipEvent_t, or NULL): the data-parallel form of the reference's DDP wrapper
+ * (examples/images/cifar10/train_cifar10_ddp.py:92 — gradient buckets all-reduced while the backward still runs):
+ * layer l's split partials are reduced right after its weight-gradient product (one small launch per layer instead of
+ * one at the end; same sums in the same order, bit-equal gradients) and layer_done[l] is recorded on `stream`, so the
+ * caller's communication stream can all-reduce dW[l], db[l] under the remaining layers' products.
  * ws: cfm_workspace_bytes(CFM_OP_MLP_TRAIN, B, widest layer incl. input/output, largest dims[l]*dims[l+1]). */
 int cfm_mlp_regression_step_f32(const float* xt, const float* t, const float* ut,
                                 const float* const* W, const float* const* b, const int* dims, int n_layers,
                                 int B, float* const* hidden, float* const* preact, float* g,
-                                float* const* dW, float* const* db, float* loss, void* ws, void* stream);
+                                float* const* dW, float* const* db, float* loss, void* const* layer_done,
+                                void* ws, void* stream);
 /* One torch.optim.Adam step (amsgrad=False, maximize=False) on n_tensors fp32 tensors in ONE launch.
  * table: DEVICE array of n_tensors records {float* param; const float* grad; float* exp_avg;
  * float* exp_avg_sq; uint64 numel} (40 bytes each).  step >= 1 is the step count AFTER this update
- * (bias corrections 1 - beta^step are formed in double on the host, as torch does). */
+ * (bias corrections 1 - beta^step are formed in double on the host, as torch does).
+ * grad_scale (> 0): 1.0, or 1 / world size for a data-parallel run whose gradient buffers hold the all-reduced SUM:
+ * the gradient is multiplied first (one fp32 rounding, what `grad.mul_(1 / world)` does) and written back, so .grad
+ * holds the mean afterwards as under DDP (train_cifar10_ddp.py:92) — no separate elementwise launch. */
 int cfm_adam_step_f32(const void* table, int n_tensors, double lr, double beta1, double beta2, double eps,
-                      double weight_decay, int step, void* stream);
+                      double weight_decay, int step, double grad_scale, void* stream);
 
 /* SF2M sampling — one Euler-Maruyama step  y <- y + dt (v + score_sign * s) + g sqrt(|dt|) xi,  in place.
  * Replaces the step torchsde.sdeint(sde, x0, ts, method="euler") takes for the reference's SDE

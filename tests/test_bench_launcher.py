@@ -28,6 +28,20 @@ def test_gpus_2_self_launches_two_ranks_on_cpu_standins():
     assert out["value"] > 0 and out["scaling"] == "weak"
 
 
+def test_gpus_8_standin_eight_ranks_three_workers_each():
+    """The shape of the driver's 8-GPU run on this box's host cores: 8 gloo ranks, each with 3 coupling
+    worker threads and groups of 4, finish and rank 0 prints ONE line with n_gpus 8 (host-side oversubscription —
+    8 x (1 + 3) threads — must not deadlock the barrier / all-gather / max-over-ranks plumbing)."""
+    p = _run(["--gpus", "8", "--steps", "6", "--warmup", "2", "--pipeline", "3", "--group", "4", "--repeats", "2",
+              "--cpu-standin"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 6 and out["config"]["parallelism"] == "dp8"
+    assert out["valid"] is False and out["value"] > 0 and out["repeats"] == 2 and len(out["ms_per_step_all"]) == 2
+
+
 def test_gpus_1_standin_does_not_spawn():
     p = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--pipeline", "0", "--cpu-standin"])
     assert p.returncode == 0, p.stderr[-2000:]

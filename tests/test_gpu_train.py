@@ -287,3 +287,41 @@ def test_regression_step_without_time_column(dev):
     assert abs(float(le) - loss) <= 1e-6 * abs(loss)
     for a, p in zip(g, net.parameters()):
         assert (a - p.grad).abs().max() <= 1e-5 * p.grad.abs().max()
+
+
+def test_bucketed_backward_and_scaled_adam_equal_the_single_gpu_forms(dev):
+    """The data-parallel form of the step: per-layer reductions + layer_done events give bit-equal
+    gradients and loss; Adam with grad_scale = 1/4 equals `grad.mul_(0.25)` followed by the unscaled launch, bit for
+    bit, and leaves the scaled gradient in .grad (the mean, as DDP leaves it: train_cifar10_ddp.py:92)."""
+    import copy
+    import cfm_amd
+    torch.manual_seed(9)
+    B, d, w = 1024, 50, 64
+    net = cfm_amd.MLP(dim=d, time_varying=True, w=w).to(dev)
+    ref = copy.deepcopy(net)
+    t = torch.rand(B, device=dev); xt = torch.randn(B, d, device=dev); ut = torch.randn(B, d, device=dev)
+    ra = cfm_amd.RegressionStep(net, cfm_amd.FusedAdam(net.parameters(), lr=1e-3))
+    rb = cfm_amd.RegressionStep(ref, cfm_amd.FusedAdam(ref.parameters(), lr=1e-3))
+    la = float(ra.backward_only(t, xt, ut))
+    evp = rb._dp_setup()
+    lb = float(rb.backward_only(t, xt, ut, layer_events=evp))
+    for e in rb._events:
+        e.synchronize()
+    assert la == lb
+    assert torch.equal(ra.flat_grad, rb.flat_grad)
+    # the events order a second stream behind each layer's gradient
+    with torch.cuda.stream(rb._comm):
+        for l in range(rb.n - 1, -1, -1):
+            rb._comm.wait_event(rb._events[l])
+        s = rb.flat_grad.clone()
+    torch.cuda.synchronize()
+    assert torch.equal(s, ra.flat_grad)
+    # Adam: scale folded into the launch vs an eager mul_ in front of it
+    ra.flat_grad.mul_(0.25); ra.opt.step()
+    rb.opt.step(grad_scale=0.25)
+    torch.cuda.synchronize()
+    assert torch.equal(ra.flat_grad, rb.flat_grad)
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(p, q)
+    with pytest.raises(Exception):
+        rb.opt.step(grad_scale=0.0)
