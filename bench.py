@@ -163,6 +163,35 @@ def sinkhorn_leg(dev, cfg, reg, iters=200):
                          "bytes_per_iter": per_iter_bytes, "note": note}}
 
 
+def sinkhorn_extra_legs(dev, iters=200):
+    """The Sinkhorn variants no line carried so far: variant B (cost recomputed from the coordinates)
+    at its largest dimension d = 8, and the matrix-streaming solver on a d = 50 cloud at B = 4096 (the C5 data at the
+    C2 batch size: a 64 MiB matrix, Infinity-Cache resident).  Fixed iteration counts (stop_thr = 0)."""
+    import cfm_amd.optimal_transport as ot
+    import cfm_oracle as oracle
+    out = {}
+
+    def timed(fn):
+        fn(20); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(iters); e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    g = torch.Generator().manual_seed(8)
+    a = torch.randn(4096, 8, generator=g).to(dev); b = (torch.randn(4096, 8, generator=g) * 0.8 + 0.5).to(dev)
+    M = ot.cost_matrix(a, b)
+    ms = timed(lambda n: ot.sinkhorn_log_points(a, b, M, 0.5, max_iter=n, stop_thr=0.0))
+    ms_s = timed(lambda n: ot.sinkhorn_log(M, 0.5, max_iter=n, stop_thr=0.0))
+    out["points_d8_iters_per_s"] = iters / (ms * 1e-3)
+    out["points_d8_matrix_streaming_iters_per_s"] = iters / (ms_s * 1e-3)
+    x0, x1 = oracle.config_inputs("C5", B=4096)
+    M50 = ot.cost_matrix(x0.to(dev), x1.to(dev))
+    ms50 = timed(lambda n: ot.sinkhorn_log(M50, 0.1, max_iter=n, stop_thr=0.0))
+    out["d50_B4096_iters_per_s"] = iters / (ms50 * 1e-3)
+    out["d50_B4096_gbs"] = (2 * 4.0 * 4096 * 4096 + 16 * 4096) * iters / (ms50 * 1e-3) / 1e9
+    out["extra_config"] = "B=4096: d=8 Gaussian clouds (variant B and the streaming solver, eps=0.5); d=50 C5-shaped clouds (streaming, eps=0.1)"
+    return out
+
+
 def c5_ode_leg(dev):
     """C5 sampling: dopri5 (atol = rtol = 1e-4, t_span = linspace(0, 1, 100)) through the 51-64-64-64-50
     SELU MLP field on B = 8192 points (single-cell_example.ipynb cells 5-9 shape)."""
@@ -306,22 +335,65 @@ def cpu_baseline(B, d, budget_s=25.0):
     torch.set_num_threads(threads_max)
     med = np.median(runs, axis=0)
     total = float(med.sum())
-    # CPU Sinkhorn iterations/s: the C restatement of POT's log-domain loop (oracle/sinkhorn_oracle.c,
-    # float64, OpenMP), a fixed 10 iterations on the C2 matrix (B = 4096, d = 2, eps = 0.05)
+    # CPU Sinkhorn iterations/s ("time a fixed 100 iterations of the float64 two-mat-vec loop"): POT's
+    # sinkhorn_knopp iteration as the reference runs it (optimal_transport.py:51,87): K = exp(M / -reg) in float64,
+    # v = b / (K^T u), u = 1 / (Kp v) — two dense mat-vecs over B^2 doubles per iteration (NumPy / the host BLAS, all
+    # cores).  A FIXED number of iterations: at the reference's reg the loop would stop on its numerical-error check at
+    # once (K underflows), which changes nothing about what an iteration costs.  C2 (B = 4096): 100 iterations; C5
+    # (B = 8192, 512 MiB of K): 30.  Next to it the float64 log-domain loop in C (oracle/sinkhorn_oracle.c, OpenMP),
+    # the form the GPU solver computes, 20 iterations at C2.
+    def knopp_rate(cfg, reg, iters):
+        a0, a1 = oracle.config_inputs(cfg)
+        Mc = oracle.ref_cost_f32(a0, a1).astype(np.float64)
+        K = np.exp(Mc / (-reg)); del Mc
+        n, m = K.shape
+        Kp = K * float(n)                                   # (1 / a) K with a = 1 / n
+        u = np.full(n, 1.0 / n); v = np.full(m, 1.0 / m); b = np.full(m, 1.0 / m)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            KtU = K.T @ u; v = b / KtU; u = 1.0 / (Kp @ v)     # warm-up
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                KtU = K.T @ u
+                v = b / KtU
+                u = 1.0 / (Kp @ v)
+            dt = time.perf_counter() - t0
+        return {"config": f"{cfg}: B={n}, eps={reg}", "iters_per_s": iters / dt, "iters_timed": iters,
+                "gbs": 2 * 8.0 * n * m * iters / dt / 1e9, "cores": os.cpu_count(), "kind": "port",
+                "sample": f"{iters} iterations of the float64 two-mat-vec Knopp loop (NumPy / host BLAS)"}
     sk_cpu = None
     try:
+        sk_cpu = {"c2_knopp": knopp_rate("C2", 0.05, 100), "c5_knopp": knopp_rate("C5", 0.1, 30)}
         import sinkhorn_c
         a0, a1 = oracle.config_inputs("C2")
         Mc = oracle.ref_cost_f32(a0, a1)
         sinkhorn_c.sinkhorn_log(Mc, 0.05, numItermax=1, stopThr=0.0)          # warm-up (loads / builds the library)
-        t0 = time.perf_counter(); sinkhorn_c.sinkhorn_log(Mc, 0.05, numItermax=10, stopThr=0.0); dt = time.perf_counter() - t0
+        t0 = time.perf_counter(); sinkhorn_c.sinkhorn_log(Mc, 0.05, numItermax=20, stopThr=0.0); dt = time.perf_counter() - t0
         nth = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-        sk_cpu = {"config": "C2: B=4096, d=2, eps=0.05", "iters_per_s": 10.0 / dt, "cores": nth, "kind": "port",
-                  "sample": f"10 iterations of the float64 log-domain loop in C (oracle/sinkhorn_oracle.c), OpenMP over rows / "
-                            f"columns, {nth} threads"}
+        sk_cpu["c2_log_domain_c"] = {"config": "C2: B=4096, d=2, eps=0.05", "iters_per_s": 20.0 / dt, "cores": nth, "kind": "port",
+                                     "sample": f"20 iterations of the float64 log-domain loop in C (oracle/sinkhorn_oracle.c), "
+                                               f"OpenMP over rows / columns, {nth} threads"}
+        sk_cpu["iters_per_s"] = sk_cpu["c2_knopp"]["iters_per_s"]
     except Exception as e:                                                        # noqa: BLE001  (no C compiler on the box)
-        sk_cpu = {"error": str(e)[:120]}
-    return {"value": B / total, "unit": "samples/s", "cores": 1, "kind": "port", "sinkhorn_cpu": sk_cpu,
+        sk_cpu = dict(sk_cpu or {}, error=str(e)[:160])
+    # C1 (BASELINE configs[0] IS the reference's CPU path: Flow_matching_tutorial.ipynb cell 16): the exact coupling of
+    # one B = 256, d = 2 minibatch on the host — cdist^2, LSAP, the dense-plan np.random.choice — median of 20
+    c1_cpu = None
+    try:
+        b0, b1 = oracle.config_inputs("C1")
+        ts = []
+        for _ in range(21):
+            t0 = time.perf_counter()
+            Mq = oracle.ref_cost_f32(b0, b1); t1 = time.perf_counter()
+            pq = oracle.exact_perm(Mq); t2 = time.perf_counter()
+            oracle.sample_map_reference(oracle.perm_plan(pq), 256)
+            ts.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
+        med = np.median(np.array(ts[1:]), axis=0) * 1e3
+        c1_cpu = {"cpu_ms": float(med.sum()), "cpu_solve_ms": float(med[1]), "cpu_cdist_ms": float(med[0]),
+                  "cpu_sample_map_ms": float(med[2]), "cores": 1, "kind": "port",
+                  "sample": "20 couplings of B=256, d=2 (cdist**2 + SciPy LSAP + dense-plan np.random.choice), per-stage medians"}
+    except Exception as e:                                                        # noqa: BLE001
+        c1_cpu = {"error": str(e)[:160]}
+    return {"value": B / total, "unit": "samples/s", "cores": 1, "kind": "port", "sinkhorn_cpu": sk_cpu, "c1": c1_cpu,
             "s_per_step_median": total, "s_per_step_min": float(runs.sum(1).min()), "runs": int(nrun),
             "breakdown_s": {"cdist2": float(med[0]), "exact_solve_scipy_lsap": float(med[1]),
                             "sample_map_dense_choice": float(med[2]), "gather_xt_ut": float(med[3])},
@@ -517,6 +589,9 @@ def main():
     ap.add_argument("--partition", type=int, default=int(os.environ.get("CFM_BENCH_PARTITION", "0")),
                     help="K > 0: chip partition (cfm_amd.streams.ChipPartition): K CUs of every XCD for the exact solver's "
                          "streams, the rest for the dense products (cost matrix, model step); 0: every stream on all CUs")
+    ap.add_argument("--solver-all", action="store_true", default=bool(os.environ.get("CFM_BENCH_SOLVER_ALL")),
+                    help="with --partition K: only the DENSE streams are masked (they leave K CUs per XCD free); the solver's "
+                         "streams may use every CU")
     ap.add_argument("--priority", type=int, default=int(os.environ.get("CFM_BENCH_PRIORITY", "0")),
                     help="HIP priority of the coupling workers' streams when no partition is used (-1: high)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -613,7 +688,7 @@ def main():
     part, main_stream = None, None
     if args.pipeline and args.partition > 0:
         from cfm_amd.streams import ChipPartition
-        part = ChipPartition(dev, solver_cus_per_xcd=args.partition)
+        part = ChipPartition(dev, solver_cus_per_xcd=args.partition, solver_all=args.solver_all)
         main_stream = part.dense_stream()
         torch.cuda.set_stream(main_stream)          # the model step of the pipelined loop runs on the dense CU subset
     if args.pipeline:
@@ -694,6 +769,7 @@ def main():
             out["roofline"] = assign_roofline(dev, pool, lib_, _lib, ot, B)
             out["c1"] = c1_latency(dev)
         c2 = sinkhorn_leg(dev, "C2", 0.05)
+        c2.update(sinkhorn_extra_legs(dev))
         out["c2"] = c2
         out["sinkhorn_iters_per_s"] = c2["sinkhorn_iters_per_s"]
         out["roofline_sinkhorn"] = c2["roofline"]
@@ -705,7 +781,16 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                            "traffic": None, "note": "reported at N = 1 only"}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(B, d)
+        cb = cpu_baseline(B, d)
+        out["cpu_baseline"] = cb
+        # the per-config CPU figures next to the GPU ones they belong to
+        if isinstance(cb.get("c1"), dict) and "c1" in out:
+            out["c1"].update({k: v for k, v in cb["c1"].items() if k.startswith("cpu_")})
+        skc = cb.get("sinkhorn_cpu") or {}
+        if "c2" in out and isinstance(skc.get("c2_knopp"), dict):
+            out["c2"]["cpu_iters_per_s"] = skc["c2_knopp"]["iters_per_s"]
+        if "c5" in out and isinstance(skc.get("c5_knopp"), dict):
+            out["c5"]["cpu_iters_per_s"] = skc["c5_knopp"]["iters_per_s"]
         out["parity"] = parity_leg(dev, ot)
     print(json.dumps(out))
 

@@ -77,20 +77,21 @@ struct GcOperand {
 
     // optional per-k offset (cost_gemm subtracts the common centre mu[k] on the way in): the offsets of the fetched
     // k slice are loaded here and applied at stash time
-    float4 off4; float off1; bool has_off = false;
+    // (out-of-range offsets are zeroed when they are CONSUMED, like the operand itself: a select right behind the load
+    //  made the wave wait for it — one L2 round trip per K step with no MFMA issued: round 4, tools/isa_report.py)
+    float4 off4; float off1; bool has_off = false, off_in = true;
     __device__ __forceinline__ void sub_k(const float* __restrict__ mu, int k0, int kend) {
         const int tid = threadIdx.x;
         has_off = true;
         if (VEC) {
             static_assert(!KMAJOR, "sub_k: K-contiguous operands only");
             const int gk = k0 + 4 * (tid % (BK / 4));
-            const bool in = gk < kend;                   // kend % 4 == 0 (VEC precondition)
-            off4 = *reinterpret_cast<const float4*>(mu + (in ? gk : 0));
-            if (!in) off4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            off_in = gk < kend;                          // kend % 4 == 0 (VEC precondition)
+            off4 = *reinterpret_cast<const float4*>(mu + (off_in ? gk : 0));
         } else {
             const int gk = k0 + tid % BK;
-            off1 = mu[gk < kend ? gk : 0];
-            if (!(gk < kend)) off1 = 0.f;
+            off_in = gk < kend;
+            off1 = mu[off_in ? gk : 0];
         }
     }
 
@@ -100,7 +101,7 @@ struct GcOperand {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 float4 x = v[q];
-                if (has_off) { x.x -= off4.x; x.y -= off4.y; x.z -= off4.z; x.w -= off4.w; }
+                if (has_off && off_in) { x.x -= off4.x; x.y -= off4.y; x.z -= off4.z; x.w -= off4.w; }
                 if (!((okm >> q) & 1u)) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!KMAJOR) {
                     const int k = 4 * (tid % (BK / 4)), r = tid / (BK / 4) + q * (1024 / BK);
@@ -118,7 +119,7 @@ struct GcOperand {
                 if (!KMAJOR) { k = tid % BK; r = tid / BK + q * (256 / BK); }
                 else { r = tid % ROWS; k = tid / ROWS + q * (256 / ROWS); }
                 float x = s[q];
-                if (has_off) x -= off1;
+                if (has_off && off_in) x -= off1;
                 T[k * LD + r] = ((okm >> q) & 1u) ? x : 0.f;
             }
         }
@@ -260,21 +261,27 @@ struct GemmCore {
         __syncthreads();
         int st = 0;
         if (k_begin + BK < k_end) { oa.fetch(A, lda, row0, M, k_begin + BK, k_end); ob.fetch(B, ldb, col0, N, k_begin + BK, k_end); pre(oa, ob, k_begin + BK); }
-        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        // ONE body in the loop, the last K step peeled behind it: with both step<> forms inside the loop (round 3) the
+        // accumulators were loop-carried through a phi the register allocator resolved with a full copy of the
+        // accumulator file on entry AND exit of every K step (64 + 64 v_accvgpr moves per step at 128 x 128:
+        // tools/isa_report.py), a quarter of the step's issue slots with the matrix pipe idle behind them.
+        int k0 = k_begin;
+        for (; k0 + BK < k_end; k0 += BK) {
             float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
             post(Ac, k0);
-            if (k0 + BK < k_end) {
-                step<true>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob, [&]() {
-                    if (k0 + 2 * BK < k_end) {
-                        oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end);
-                        pre(oa, ob, k0 + 2 * BK);
-                    }
-                });
-                __syncthreads();
-                st ^= 1;
-            } else {
-                step<false>(Ac, Bc, nullptr, nullptr, oa, ob, []() {});
-            }
+            step<true>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob, [&]() {
+                if (k0 + 2 * BK < k_end) {
+                    oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end);
+                    pre(oa, ob, k0 + 2 * BK);
+                }
+            });
+            __syncthreads();
+            st ^= 1;
+        }
+        {
+            float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
+            post(Ac, k0);
+            step<false>(Ac, Bc, nullptr, nullptr, oa, ob, []() {});
         }
     }
 

@@ -37,10 +37,10 @@ class ChipPartition:
     """``solver_cus_per_xcd`` CUs of each XCD for the exact solver's streams, the rest for the dense products.
 
     ``solver_stream()`` / ``dense_stream()`` create a NEW stream on that subset each call (a worker thread keeps its
-    own); ``close()`` destroys them.  The streams are ``torch.cuda.ExternalStream`` objects: usable with
+    own); ``close()`` synchronises and parks them for reuse.  The streams are ``torch.cuda.ExternalStream`` objects: usable with
     ``torch.cuda.stream(...)``, events and ``record_stream`` like any other."""
 
-    def __init__(self, device=None, solver_cus_per_xcd=4, dense_all=False):
+    def __init__(self, device=None, solver_cus_per_xcd=4, dense_all=False, solver_all=False):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
         per = ncu // N_XCD
@@ -48,7 +48,7 @@ class ChipPartition:
         if not 1 <= k < per:
             raise ValueError(f"solver_cus_per_xcd must be in 1..{per - 1} (the device has {per} CUs per XCD)")
         self.ncu, self.k = ncu, k
-        self.solver_bits = list(range(0, N_XCD * k))
+        self.solver_bits = list(range(0, N_XCD * (per if solver_all else k)))
         self.dense_bits = list(range(0 if dense_all else N_XCD * k, N_XCD * per))
         self._streams = []
         self._lock = threading.Lock()
