@@ -66,6 +66,8 @@ SIGNATURES = {
     "cfm_plan_sample_perm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cfm_plan_sample_dense": (_i, [_vp, _i, _i, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_pi_f64": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "cfm_plan_sample_rows_dense": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "cfm_plan_sample_rows_pi_f64": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "cfm_sample_xt_ut_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i,
                                   _vp, _vp, _vp, _vp, _vp]),
     "cfm_gather_rows": (_i, [_vp, _vp, _i, _sz, _vp, _vp]),

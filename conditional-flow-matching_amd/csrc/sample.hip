@@ -205,6 +205,92 @@ extern "C" int cfm_plan_sample_pi_f64(const double* pi, int B0, int B1, const do
     return sd_run(plan, B0, B1, u01, n, i, j, ws, (hipStream_t)stream);
 }
 
+// ------------------------------------------------- per-row draws (sample_trajectory) ----
+// Replaces the inner loop of OTPlanSampler.sample_trajectory (torchcfm/optimal_transport.py:237-246):
+//     for i in indices[-1]:  j.append(np.random.choice(pi.shape[1], p=pi[i] / pi[i].sum()))
+// one draw per entry of `rows` from the CONDITIONAL distribution of that plan row: np.random.choice builds
+// cdf = cumsum(p), cdf /= cdf[-1] and returns searchsorted(cdf, u, side="right") — the first column whose running sum
+// exceeds u x (row total).  One wave per draw, reading the plan row where it lies (potentials + cost row, or an fp64
+// plan): no [m, B1] sub-plan, no row-normalised copy, and the chain of slices keeps its indices on the device.
+template <class P>
+__global__ __launch_bounds__(256) void sd_sample_rows(P plan, int B0, int B1, const int64_t* __restrict__ rows,
+                                                      const double* __restrict__ u01, int n,
+                                                      int64_t* __restrict__ oj) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    long long r = rows[k];
+    if (r < 0) r = 0;
+    if (r > B0 - 1) r = B0 - 1;
+    const int i = (int)r;
+    const int L = (B1 + 63) / 64;
+    const int jb = lane * L, je = min(B1, jb + L);
+    double seg = 0.0;
+    for (int j = jb; j < je; ++j) seg += plan(i, j);
+    double inc = seg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    const double T = __shfl(inc, 63, 64);                 // the row total, as the scan sees it
+    const double target = u01[k] * T;
+    const bool hit = inc > target;
+    const unsigned long long mask = __ballot(hit);
+    int jout = B1 - 1;
+    if (mask != 0ull) {
+        const int src = __ffsll((long long)mask) - 1;
+        if (lane == src) {
+            double run = inc - seg;
+            int jj = je - 1;
+            for (int j = jb; j < je; ++j) {
+                run += plan(i, j);
+                if (run > target) { jj = j; break; }
+            }
+            jout = jj;
+        }
+        jout = __shfl(jout, src, 64);
+    } else {
+        // (a row without mass, or a NaN total: numpy raises there; return the last column carrying mass)
+        int jl = -1;
+        for (int j = je - 1; j >= jb; --j) if (plan(i, j) > 0.0) { jl = j; break; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) jl = max(jl, __shfl_xor(jl, o, 64));
+        jout = jl >= 0 ? jl : B1 - 1;
+    }
+    if (lane == 0) oj[k] = jout;
+}
+
+extern "C" int cfm_plan_sample_rows_dense(const float* M, int B0, int B1, double reg, const void* sk_ws,
+                                          const int64_t* rows, const double* u01, int n, int64_t* j, void* ws,
+                                          void* stream) {
+    if (!M || !sk_ws || !ws || B0 <= 0 || B1 <= 0 || n < 0 || !(reg > 0.0)) return CFM_EINVAL;
+    if (n == 0) return 0;
+    if (!rows || !u01 || !j) return CFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    double* vsel = (double*)ws + ((size_t)B0 + 8);        // same carving as cfm_plan_sample_dense
+    const char* q = (const char*)sk_ws;
+    const SkStateView* st = (const SkStateView*)q;
+    const double* u = (const double*)(q + 256);
+    const double* v0 = u + B0;
+    const double* v1 = v0 + B1;
+    hipLaunchKernelGGL(sd_pick_v, dim3((B1 + 255) / 256), dim3(256), 0, s, st, v0, v1, B1, vsel);
+    PlanFromPotentials plan{M, u, vsel, 1.0 / reg, B1};
+    hipLaunchKernelGGL(sd_sample_rows<PlanFromPotentials>, dim3((n + 3) / 4), dim3(256), 0, s, plan, B0, B1, rows, u01, n, j);
+    return cfm_status();
+}
+
+extern "C" int cfm_plan_sample_rows_pi_f64(const double* pi, int B0, int B1, const int64_t* rows, const double* u01,
+                                           int n, int64_t* j, void* stream) {
+    if (!pi || B0 <= 0 || B1 <= 0 || n < 0) return CFM_EINVAL;
+    if (n == 0) return 0;
+    if (!rows || !u01 || !j) return CFM_EINVAL;
+    PlanFromPi plan{pi, B1};
+    hipLaunchKernelGGL(sd_sample_rows<PlanFromPi>, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, plan, B0, B1,
+                       rows, u01, n, j);
+    return cfm_status();
+}
+
 // zero entries of a flat fp64 plan (replace=False bookkeeping of np.random.choice)
 __global__ void zero_flat_kernel(double* pi, const int64_t* flat, int n) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

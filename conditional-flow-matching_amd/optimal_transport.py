@@ -333,6 +333,31 @@ def sample_pi(pi_dev, u01):
     return i, j
 
 
+def sample_rows_dense(r, rows, u01):
+    """One column per entry of `rows` drawn from that row of the entropic plan (ref:244: np.random.choice(B, p=pi[i] /
+    pi[i].sum())): device int64 [n].  The plan is never materialised (potentials + cost row)."""
+    lib = _lib.load()
+    B0, B1 = r.M.shape
+    n = rows.numel()
+    dev = r.M.device
+    j = torch.empty(n, dtype=torch.int64, device=dev)
+    ws = _lib.workspace(_lib.OP_SAMPLE_DENSE, B0, B1, 0, dev)
+    check(lib.cfm_plan_sample_rows_dense(ptr(r.M), B0, B1, r.reg, ptr(r.ws), ptr(rows), ptr(u01), n, ptr(j), ptr(ws),
+                                         stream_ptr()), "cfm_plan_sample_rows_dense")
+    return j
+
+
+def sample_rows_pi(pi_dev, rows, u01):
+    """The same draw from an explicit device fp64 plan (unbalanced / partial / rectangular exact plans)."""
+    lib = _lib.load()
+    B0, B1 = pi_dev.shape
+    n = rows.numel()
+    j = torch.empty(n, dtype=torch.int64, device=pi_dev.device)
+    check(lib.cfm_plan_sample_rows_pi_f64(ptr(pi_dev), B0, B1, ptr(rows), ptr(u01), n, ptr(j), stream_ptr()),
+          "cfm_plan_sample_rows_pi_f64")
+    return j
+
+
 def take_rows(x, idx):
     """x[idx] for device index vectors: the byte-copy kernel, unless x carries an autograd graph
     (a learned encoder in front of the coupling, ref:145 keeps x0[i] differentiable) — then a plain
@@ -583,15 +608,14 @@ class OTPlanSampler:
         dev = _lib.require_gpu()
         if len(pairs) <= 1 or workers <= 1:
             return [self._solve(a, b) for a, b in pairs]
-        if self.method == "exact":
+        n0 = pairs[0][0].shape[0]
+        if self.method == "exact" and n0 > 256 and all(a.shape[0] == n0 and b.shape[0] == n0 for a, b in pairs):
             # equal, square sizes beyond the one-workgroup solver: the assignment problems share ONE chain of launches
-            prep = [self._prepare(a, b) for a, b in pairs]
-            Ms = [m for _, m, _, _ in prep]
-            n0 = Ms[0].shape[0]
-            if n0 > 256 and all(m.shape[0] == n0 and m.shape[1] == n0 for m in Ms):
-                perms = assign_exact_batch(Ms)
-                self._last = {"certified": True}
-                return [("perm", perms[k], Ms[k]) for k in range(len(Ms))]
+            # (decided from the shapes: the other cases build their cost matrices inside the workers, once)
+            Ms = [self._prepare(a, b)[1] for a, b in pairs]
+            perms = assign_exact_batch(Ms)
+            self._last = {"certified": True}
+            return [("perm", perms[k], Ms[k]) for k in range(len(Ms))]
         tls = threading.local()
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
@@ -631,26 +655,26 @@ class OTPlanSampler:
         dev = _lib.require_gpu()
         n = X.shape[0]
         sols = self._solve_many([(X[:, t], X[:, t + 1]) for t in range(times - 1)])
-        indices = [np.arange(n)]
+        # The chain of per-row draws stays on the device: one kernel per slice reads the plan row where it lies
+        # (cfm_plan_sample_rows_*), the indices of a slice feed the next one directly, and the host sees them once,
+        # at the end.  The host RNG is consumed exactly as the reference's loop consumes it: one uniform per row and
+        # slice, in row order (np.random.choice draws one double per call, ref:244).
+        rows = torch.arange(n, dtype=torch.int64, device=dev)
+        chain = [rows]
         for kind, sol, M in sols:
-            rows = torch.from_numpy(np.ascontiguousarray(indices[-1])).to(dev)
-            u = np.random.random_sample(len(indices[-1]))
+            u = _u01_to_device(np.random.random_sample(n), dev)
             if kind == "perm":
                 # a permutation plan: row i has the single nonzero pi[i, perm[i]] (the draw is consumed)
                 j = sol.long()[rows]
+            elif kind == "dense":
+                j = sample_rows_dense(sol, rows, u)
             else:
-                plan = sinkhorn_plan(sol) if kind == "dense" else sol
-                sub = plan[rows]
-                sub = sub / sub.sum(dim=1, keepdim=True)
-                # flattened cdf trick: row r occupies [r, r+1) / len after scaling by 1 / len
-                m = sub.shape[0]
-                flat_u = (np.arange(m) + u) / m
-                _, j = sample_pi((sub / m).contiguous(), _u01_to_device(flat_u, dev))
-            indices.append(j.cpu().numpy())
-        to_return = []
-        for t in range(times):
-            to_return.append(np.asarray(X[:, t].cpu())[indices[t]])
-        return np.stack(to_return, axis=1)
+                j = sample_rows_pi(sol.contiguous(), rows, u)
+            chain.append(j)
+            rows = j
+        idx = torch.stack(chain).cpu().numpy()              # [times, n]: the ONE device-to-host copy of the indices
+        Xh = np.asarray(X.detach().cpu() if isinstance(X, torch.Tensor) else X)
+        return np.stack([Xh[:, t][idx[t]] for t in range(times)], axis=1)
 
 
 def wasserstein(

@@ -238,6 +238,20 @@ int cfm_plan_sample_dense(const float* M, int B0, int B1, double reg, const void
 int cfm_plan_sample_pi_f64(const double* pi, int B0, int B1, const double* u01, int n,
                            int64_t* i, int64_t* j, void* ws, void* stream);
 
+/* K6 (trajectories) — one draw per entry of `rows` from the CONDITIONAL distribution of that plan row.
+ * Replaces the inner loop of sample_trajectory()   torchcfm/optimal_transport.py:237-246
+ *     for i in indices[-1]:  j.append(np.random.choice(pi.shape[1], p=pi[i] / pi[i].sum()))
+ * np.random.choice consumes one uniform per call (u01[q], drawn by the caller in order) and returns the first column
+ * whose running sum of the row exceeds u x (row total).  rows: device int64[n] (clamped to [0, B0)); j: device
+ * int64[n].  _dense reads the entropic plan from the potentials in `sk_ws` and the cost row (never materialised;
+ * ws: cfm_workspace_bytes(CFM_OP_SAMPLE_DENSE,B0,B1,0)); _pi_f64 reads an explicit fp64 plan.  The indices of a chain
+ * of time slices stay on the device (the reference moves every B x B plan to the host and loops in Python). */
+int cfm_plan_sample_rows_dense(const float* M, int B0, int B1, double reg, const void* sk_ws,
+                               const int64_t* rows, const double* u01, int n, int64_t* j, void* ws,
+                               void* stream);
+int cfm_plan_sample_rows_pi_f64(const double* pi, int B0, int B1, const int64_t* rows, const double* u01,
+                                int n, int64_t* j, void* stream);
+
 /* K7+K8 — fused gather + probability-path sample + conditional flow.
  * Replaces x0[i], x1[j]                      torchcfm/optimal_transport.py:145
  * and the eager chain of                     torchcfm/conditional_flow_matching.py
