@@ -558,7 +558,10 @@ __device__ __forceinline__ void bid_list_store(gfp M, const AsgWs& w, const Top2
 // and the bound), else a scan of the row, which refreshes the list.  Returns 1 (a bid) + 0x10000 if the list served it.
 __device__ __forceinline__ int bid_row(gfp M, const AsgWs& w, const double* p_lds, int i, uint2 e, double T, bool stage_p,
                                        int n, double eps, int tag, int rb, int rnd) {
-    const int lane = threadIdx.x & 63;
+    // (an OPAQUE copy of the lane: every per-lane address of a row's bid — keys, prices, the row itself — is then
+    //  formed inside the row loop.  Hoisted to the kernel's top as loop invariants they pushed asg_step one value past
+    //  its 128 registers: 12 bytes of scratch and a reload on the round's critical path in round 3.)
+    int lane = threadIdx.x & 63; asm volatile("" : "+v"(lane));
     const bool vec = ((n & 3) == 0);
     const bool fast = stage_p && (n & 4095) == 0;
     const bool lists = ASG_BL_ON && (w.cl != nullptr);
@@ -672,7 +675,10 @@ __device__ __forceinline__ int wide_bid_queue(gfp M, const AsgWs& w, const doubl
     for (int k = wv; k < m; k += WT / 64) {
         const int i = bq[k];
         uint2 e = make_uint2(0xffffffffu, 0u); double T = -INFINITY;
-        if (lists) { e = w.cl[(size_t)i * ASG_BL + lane]; T = w.cT[i]; }
+        // (the lane's list address is formed per row from an opaque copy of the lane: hoisted out of the loop it was
+        //  the one value the register allocator spilled — 8 bytes of scratch and a reload on the round's critical path)
+        int ln = lane; asm volatile("" : "+v"(ln));
+        if (lists) { e = w.cl[(size_t)i * ASG_BL + ln]; T = w.cT[i]; }
         nbids += bid_row(M, w, p_lds, i, e, T, stage_p, n, eps, tag, rb, rnd);
     }
     return nbids;

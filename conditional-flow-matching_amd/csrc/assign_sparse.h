@@ -886,7 +886,8 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                     const double d = L.dist[k];
                     if (d < dfree) {
                         const int i = L.owner[k];
-                        const double rj = (double)M[(size_t)i * n + k] + L.p[k];
+                        int kq = k; asm volatile("" : "+v"(kq));     // (M + k hoisted to the kernel's top was spilled: 0 scratch)
+                        const double rj = (double)M[(size_t)i * n + kq] + L.p[k];
                         if (!(d + (w.cT[i] - rj) >= dfree)) { sel[e] = true; dk[e] = d; }
                     }
                 }

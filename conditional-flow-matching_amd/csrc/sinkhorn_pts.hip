@@ -40,6 +40,11 @@ extern "C" size_t cfm_sk_ws_bytes_internal(int B0, int B1);
 #define PTS_U 8              // other points per trip and lane
 #endif
 #define PTS_STRIDE (PTS_NW * 4)   // lane-groups (wave, sub) interleave the other side's points
+// other points per trip and lane, by dimension: a trip keeps U x D coordinates + 2 U doubles in registers, and the
+// 1024-thread workgroup leaves 128 per lane — at U = 8, d = 6 / 7 / 8 spilled 48 / 100 / 248 bytes per lane (round 3);
+// trips of 4 for d >= 6 fit (tools/isa_report.py: 0 bytes of scratch for every d).  The staged chunk stays padded to
+// whole trips of PTS_U = 8, which is a whole number of the shorter trips too.
+template <int D> struct PtsTrip { static constexpr int U = (D <= 5) ? PTS_U : PTS_U / 2; };
 
 template <int D, bool PRECISE>
 __device__ __forceinline__ void pts_accumulate(const float (&own)[D], const float* __restrict__ pts_lds,
@@ -48,19 +53,20 @@ __device__ __forceinline__ void pts_accumulate(const float (&own)[D], const floa
     // this lane's points of the staged chunk: first, first + PTS_STRIDE, ...   (PTS_U of them per trip).  The chunk is
     // padded to a whole number of trips with potential = -inf entries, so the trip is branch free: its
     // 2 x PTS_U LDS reads go out back to back (a per-point bounds test made every read wait for the previous one)
-    for (int t0 = first; t0 < n_stage; t0 += PTS_STRIDE * PTS_U) {
-        float pc[PTS_U][D]; double pp[PTS_U];
+    constexpr int U = PtsTrip<D>::U;
+    for (int t0 = first; t0 < n_stage; t0 += PTS_STRIDE * U) {
+        float pc[U][D]; double pp[U];
 #pragma unroll
-        for (int k = 0; k < PTS_U; ++k) {
+        for (int k = 0; k < U; ++k) {
             const int t = t0 + PTS_STRIDE * k;
             pp[k] = pot_lds[t];
 #pragma unroll
             for (int q = 0; q < D; ++q) pc[k][q] = pts_lds[t * D + q];
         }
-        double x[PTS_U];
+        double x[U];
         double mx = m;
 #pragma unroll
-        for (int k = 0; k < PTS_U; ++k) {
+        for (int k = 0; k < U; ++k) {
             float c = 0.f;
 #pragma unroll
             for (int q = 0; q < D; ++q) { const float df = own[q] - pc[k][q]; c = fmaf(df, df, c); }
@@ -70,12 +76,12 @@ __device__ __forceinline__ void pts_accumulate(const float (&own)[D], const floa
         if (PRECISE) {
             double acc = s_acc * exp(m - mx);
 #pragma unroll
-            for (int k = 0; k < PTS_U; ++k) acc += exp(x[k] - mx);
+            for (int k = 0; k < U; ++k) acc += exp(x[k] - mx);
             s_acc = acc;
         } else {
             float acc = (float)s_acc * __expf((float)(m - mx));
 #pragma unroll
-            for (int k = 0; k < PTS_U; ++k) acc += __expf((float)(x[k] - mx));
+            for (int k = 0; k < U; ++k) acc += __expf((float)(x[k] - mx));
             s_acc = (double)acc;
         }
         m = mx;
@@ -94,7 +100,7 @@ __device__ __forceinline__ void pts_merge(double& m, double& s, double m2, doubl
 // new_pot[o] = logw - LSE_t(pot_other[t] - |own_o - other_t|^2 / reg) for the 16 own points of the workgroup.
 // For the row update own = x0, for the column update own = x1: the difference has the other sign, its
 // square is bit-identical.
-#define PTS_PRE 4            // points per thread of the first staged chunk that are requested in the prologue
+#define PTS_PRE 4            // points per thread of the first staged chunk that are requested in the prologue (d <= 5; 2 beyond)
 template <int D>
 __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ own_pts, const float* __restrict__ other_pts,
                                                      int n_own, int n_other, double inv_reg, double logw, double wgt,
@@ -119,9 +125,10 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
 #pragma unroll
     for (int q = 0; q < D; ++q) own[q] = (o < n_own) ? own_pts[(size_t)o * D + q] : 0.f;
     const int n_stage0 = n_other < stage_cap ? n_other : stage_cap;
-    double pre_pot[PTS_PRE]; float pre_pts[PTS_PRE][D];
+    constexpr int PRE = (D <= 5) ? PTS_PRE : PTS_PRE / 2;
+    double pre_pot[PRE]; float pre_pts[PRE][D];
 #pragma unroll
-    for (int k = 0; k < PTS_PRE; ++k) {
+    for (int k = 0; k < PRE; ++k) {
         const int t = threadIdx.x + PTS_T * k;
         const bool ok = t < n_stage0;
         pre_pot[k] = ok ? pot_other[t] : SK_NEG;
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
         __syncthreads();
         if (c0 == 0) {
 #pragma unroll
-            for (int k = 0; k < PTS_PRE; ++k) {
+            for (int k = 0; k < PRE; ++k) {
                 const int t = threadIdx.x + PTS_T * k;
                 if (t < n_pad) {
                     pot_lds[t] = pre_pot[k];
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
                     for (int q = 0; q < D; ++q) pts_lds[t * D + q] = pre_pts[k][q];
                 }
             }
-            for (int t = threadIdx.x + PTS_T * PTS_PRE; t < n_pad; t += PTS_T) {
+            for (int t = threadIdx.x + PTS_T * PRE; t < n_pad; t += PTS_T) {
                 pot_lds[t] = (t < n_stage) ? pot_other[t] : SK_NEG;
 #pragma unroll
                 for (int q = 0; q < D; ++q) pts_lds[t * D + q] = (t < n_stage) ? other_pts[(size_t)t * D + q] : 0.f;
