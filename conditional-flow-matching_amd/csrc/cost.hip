@@ -196,6 +196,9 @@ __global__ __launch_bounds__(256) void cost_tiled(const float* __restrict__ x0,
 // packed vector pipes: 0.17 ms vs 0.33 ms floor at B = 4096, d = 784.
 typedef float cost_f32x16 __attribute__((ext_vector_type(16)));
 
+// (round 4: both kernels request their loads ahead of the dependent adds — the sums run in the same order as before,
+//  so mu and the norms keep their bits: 25 + 20 us of dependent-latency chains stood in front of every cost matrix;
+//  tools/gemm_quick.py, scratch/gemm_kscan.py: time(d) = 58 us + 0.29 us x d before the change)
 __global__ __launch_bounds__(256) void cost_center(const float* __restrict__ x0, const float* __restrict__ x1,
                                                    int B0, int B1, int d, float* __restrict__ mu) {
     __shared__ float part[4][64];
@@ -204,8 +207,18 @@ __global__ __launch_bounds__(256) void cost_center(const float* __restrict__ x0,
     const int n0 = min(B0, 64), n1 = min(B1, 64);
     float s = 0.f;
     if (c < d) {
-        for (int q = g; q < n0; q += 4) s += x0[(size_t)((long long)q * B0 / n0) * d + c];
-        for (int q = g; q < n1; q += 4) s += x1[(size_t)((long long)q * B1 / n1) * d + c];
+        // sample rows g, g + 4, ...: at most 16 per cloud and thread, all in flight together
+        float v0[16], v1[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int q = g + 4 * t;
+            v0[t] = (q < n0) ? x0[(size_t)((long long)q * B0 / n0) * d + c] : 0.f;
+            v1[t] = (q < n1) ? x1[(size_t)((long long)q * B1 / n1) * d + c] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) if (g + 4 * t < n0) s += v0[t];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) if (g + 4 * t < n1) s += v1[t];
     }
     part[g][lane] = s;
     __syncthreads();
@@ -221,7 +234,15 @@ __global__ __launch_bounds__(256) void cost_norms(const float* __restrict__ x0, 
     if (row >= B0 + B1) return;
     const float* p = row < B0 ? x0 + (size_t)row * d : x1 + (size_t)(row - B0) * d;
     float s = 0.f;
-    for (int k = lane; k < d; k += 64) {
+    int k = lane;
+    for (; k + 64 * 7 < d; k += 64 * 8) {                 // 8 trips' loads in flight, the chain in k order as before
+        float xv[8], mv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { xv[t] = p[k + 64 * t]; mv[t] = mu[k + 64 * t]; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const float tt = xv[t] - mv[t]; s = fmaf(tt, tt, s); }
+    }
+    for (; k < d; k += 64) {
         const float t = p[k] - mu[k];
         s = fmaf(t, t, s);
     }
@@ -231,12 +252,25 @@ __global__ __launch_bounds__(256) void cost_norms(const float* __restrict__ x0, 
 
 // 128 x 128 output tile per workgroup on the shared tile engine (gemm_core.h): both clouds K-contiguous,
 // centred by mu on the way into LDS.
+// hook of the tile engine: the common centre mu[k] is subtracted from both clouds on their way into LDS
+struct CostCentre {
+    const float* mu; int d;
+    template <typename OA> __device__ __forceinline__ void a(OA& oa, int k0) const { oa.sub_k(mu, k0, d); }
+    template <typename OB> __device__ __forceinline__ void b(OB& ob, int k0) const { ob.sub_k(mu, k0, d); }
+};
+
+#ifndef COST_BK
+#define COST_BK 16       // K depth of a stage (tuning switch)
+#endif
+#ifndef COST_MINW
+#define COST_MINW 1      // minimum waves per SIMD the register allocation must leave room for (tuning switch)
+#endif
 template <int BM, bool VEC>
-__global__ __launch_bounds__(256) void cost_gemm(const float* __restrict__ x0, const float* __restrict__ x1,
+__global__ __launch_bounds__(256, COST_MINW) void cost_gemm(const float* __restrict__ x0, const float* __restrict__ x1,
                                                  int B0, int B1, int d, const float* __restrict__ mu,
                                                  const float* __restrict__ nrm, float* __restrict__ M,
                                                  int tiles_m, int tiles_n) {
-    constexpr int BN = 128, BK = 16;
+    constexpr int BN = 128, BK = COST_BK;
     using Core = GemmCore<BM, BN, BK, false, false, VEC, VEC>;
     __shared__ __attribute__((aligned(16))) float lds[Core::LDS_FLOATS];
 
@@ -260,8 +294,7 @@ __global__ __launch_bounds__(256) void cost_gemm(const float* __restrict__ x0, c
 
     Core g;
     g.zero();
-    auto pre = [&](auto& oa, auto& ob, int k0) { oa.sub_k(mu, k0, d); ob.sub_k(mu, k0, d); };
-    g.run(lds, x0, d, row0, B0, x1, d, col0, B1, 0, d, pre, GcNoPost());
+    g.run(lds, x0, d, row0, B0, x1, d, col0, B1, 0, d, CostCentre{mu, d}, GcNoPost());
 
     // ---- epilogue: |a|^2 + |b|^2 - 2 a.b, clamped; entries that cancel are recomputed directly by their wave ----
     __syncthreads();                                   // every wave is done with the last stage
@@ -273,43 +306,60 @@ __global__ __launch_bounds__(256) void cost_gemm(const float* __restrict__ x0, c
     const int cl = Core::col_lo();
     const float ny[2] = {Bn[cl], Bn[cl + NT - 1]};
     const bool pair = NT == 2 && (B1 & 1) == 0 && col0 + cl + 1 < B1;
+    // Per block of ER rows (one accumulator row block): all entries first, ONE ballot asking whether any of them
+    // cancels (round 3: a ballot + branch pair in front of every entry, 128 per wave; at the reference's shapes no
+    // entry ever cancels), the per-entry recomputation only then, and the stores.
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+        float v[ER][2];
+        bool anybad = false;
 #pragma unroll
         for (int r = 0; r < ER; ++r) {
             const int rl = Core::row_of(m, r);
-            const int gr = row0 + rl;
-            float v[2];
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
-                const int gc = col0 + cl + u;
                 const float sum = An[rl] + ny[u];
-                float x = fmaxf(fmaf(-2.f, g.at(m, u, r), sum), 0.f);
-                const bool ok = gr < B0 && gc < B1;
-                // cancellation: this wave recomputes the entry in the direct form
-                unsigned long long mask = __ballot(ok && x < 0.125f * sum);
-                while (mask) {
-                    const int l = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const int gi = __shfl(gr, l, 64), gj = __shfl(gc, l, 64);
-                    const float* pa = x0 + (size_t)gi * d;
-                    const float* pb = x1 + (size_t)gj * d;
-                    float p = 0.f;
-                    for (int k = lane; k < d; k += 64) {
-                        const float t = pa[k] - pb[k];
-                        p = fmaf(t, t, p);
-                    }
-                    p = wave_sum_f(p);
-                    if (lane == l) x = p;
-                }
-                v[u] = x;
+                const float x = fmaxf(fmaf(-2.f, g.at(m, u, r), sum), 0.f);
+                anybad |= (row0 + rl < B0 && col0 + cl + u < B1 && x < 0.125f * sum);
+                v[r][u] = x;
             }
+        }
+        if (__ballot(anybad) != 0ull) {                       // wave uniform, rare
+#pragma unroll
+            for (int r = 0; r < ER; ++r) {
+                const int gr = row0 + Core::row_of(m, r);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int gc = col0 + cl + u;
+                    const float sum = An[Core::row_of(m, r)] + ny[u];
+                    // cancellation: this wave recomputes the entry in the direct form
+                    unsigned long long mask = __ballot(gr < B0 && gc < B1 && v[r][u] < 0.125f * sum);
+                    while (mask) {
+                        const int l = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int gi = __shfl(gr, l, 64), gj = __shfl(gc, l, 64);
+                        const float* pa = x0 + (size_t)gi * d;
+                        const float* pb = x1 + (size_t)gj * d;
+                        float p = 0.f;
+                        for (int k = lane; k < d; k += 64) {
+                            const float t = pa[k] - pb[k];
+                            p = fmaf(t, t, p);
+                        }
+                        p = wave_sum_f(p);
+                        if (lane == l) v[r][u] = p;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ER; ++r) {
+            const int gr = row0 + Core::row_of(m, r);
             if (gr < B0) {
                 float* po = M + (size_t)gr * B1 + col0 + cl;
-                if (pair) *reinterpret_cast<float2*>(po) = make_float2(v[0], v[NT - 1]);
+                if (pair) *reinterpret_cast<float2*>(po) = make_float2(v[r][0], v[r][NT - 1]);
                 else {
 #pragma unroll
-                    for (int u = 0; u < NT; ++u) if (col0 + cl + u < B1) po[u] = v[u];
+                    for (int u = 0; u < NT; ++u) if (col0 + cl + u < B1) po[u] = v[r][u];
                 }
             }
         }

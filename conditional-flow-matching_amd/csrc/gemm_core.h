@@ -23,6 +23,18 @@
 #pragma once
 #include "cfm_common.h"
 
+// where in a K step the global loads of the stage after next are issued (tuning switch; results do not depend on it):
+//   0: both operands behind the third MFMA group (round 3)    1: both behind the second group, right after the B stash
+//   2: each operand right behind its own stash (A in group 0, B in group 1): the longest flight time
+#ifndef GC_FETCH_MODE
+#define GC_FETCH_MODE 0
+#endif
+// timing probes (tools/probe/build_variant_all.sh; the results are WRONG with any of them set): which part of a K step
+// keeps the matrix pipe idle?  bit 0: no global loads in the loop, bit 1: no LDS stores, bit 2: fragments read once
+// per step only, bit 3: no barrier
+#ifndef GC_DBG
+#define GC_DBG 0
+#endif
 typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gc_f32x2 __attribute__((ext_vector_type(2)));
 typedef float gc_f32x4 __attribute__((ext_vector_type(4)));
@@ -45,8 +57,40 @@ struct GcOperand {
     // Loads are unconditional from a clamped (always valid) address and zeroed afterwards: no branches in the main
     // loop.  VEC preconditions (the launchers check them): K-contiguous: ld % 4 == 0, kend % 4 == 0, 16-byte aligned
     // base; K-major: ld % 4 == 0, nrows % 4 == 0, aligned base — so a vector never straddles the valid range.
+    // Per-thread base pointers of the stage at k0 = 0 and the in-range mask of their rows, formed ONCE (bind): a stage
+    // whose K range lies inside the operand then costs one 64-bit add of a uniform offset per 16-byte load.  Round 3
+    // re-derived every address per stage — two v_mad_u64_u32, selects and compares per load, ~60 VALU instructions
+    // per K step — and the probes of round 4 (GC_DBG) priced the global loads at 13 % of the asymptotic rate.
+    const float* base[VEC ? NV : 1];
+    unsigned rowm = 0u;
+    bool bound = false;
+    __device__ __forceinline__ void bind(const float* __restrict__ p, int ld, int row0, int nrows) {
+        if (!VEC) return;
+        const int tid = threadIdx.x;
+        rowm = 0u;
+#pragma unroll
+        for (int q = 0; q < (VEC ? NV : 1); ++q) {
+            int r, k;
+            if (!KMAJOR) { k = 4 * (tid % (BK / 4)); r = tid / (BK / 4) + q * (1024 / BK); }
+            else { r = 4 * (tid % (ROWS / 4)); k = tid / (ROWS / 4) + q * (1024 / ROWS); }
+            const int gr = row0 + r;
+            const bool ok = gr < nrows;
+            const int cr = ok ? gr : 0;
+            base[q] = KMAJOR ? p + (size_t)k * ld + cr : p + (size_t)cr * ld + k;
+            rowm |= ok ? (1u << q) : 0u;
+        }
+        bound = true;
+    }
+
     __device__ __forceinline__ void fetch(const float* __restrict__ p, int ld, int row0, int nrows, int k0, int kend) {
         const int tid = threadIdx.x;
+        if (VEC && bound && k0 + BK <= kend) {                 // (uniform) the whole K range of the stage is inside
+            const size_t koff = KMAJOR ? (size_t)k0 * (size_t)ld : (size_t)k0;
+#pragma unroll
+            for (int q = 0; q < (VEC ? NV : 1); ++q) v[q] = *reinterpret_cast<const float4*>(base[q] + koff);
+            okm = rowm;
+            return;
+        }
         okm = 0u;
         if (VEC) {
 #pragma unroll
@@ -77,8 +121,9 @@ struct GcOperand {
 
     // optional per-k offset (cost_gemm subtracts the common centre mu[k] on the way in): the offsets of the fetched
     // k slice are loaded here and applied at stash time
-    // (out-of-range offsets are zeroed when they are CONSUMED, like the operand itself: a select right behind the load
-    //  made the wave wait for it — one L2 round trip per K step with no MFMA issued: round 4, tools/isa_report.py)
+    // (out-of-range offsets need no zeroing of their own: they come from a clamped, valid address and the element they
+    //  are subtracted from is zeroed by okm when it is consumed.  A select right behind the load made the wave wait
+    //  for it — one L2 round trip per K step with no MFMA issued: round 4, tools/isa_report.py)
     float4 off4; float off1; bool has_off = false, off_in = true;
     __device__ __forceinline__ void sub_k(const float* __restrict__ mu, int k0, int kend) {
         const int tid = threadIdx.x;
@@ -101,7 +146,7 @@ struct GcOperand {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 float4 x = v[q];
-                if (has_off && off_in) { x.x -= off4.x; x.y -= off4.y; x.z -= off4.z; x.w -= off4.w; }
+                if (has_off) { x.x -= off4.x; x.y -= off4.y; x.z -= off4.z; x.w -= off4.w; }      // (k >= kend: zeroed by okm below)
                 if (!((okm >> q) & 1u)) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!KMAJOR) {
                     const int k = 4 * (tid % (BK / 4)), r = tid / (BK / 4) + q * (1024 / BK);
@@ -119,7 +164,7 @@ struct GcOperand {
                 if (!KMAJOR) { k = tid % BK; r = tid / BK + q * (256 / BK); }
                 else { r = tid % ROWS; k = tid / ROWS + q * (256 / ROWS); }
                 float x = s[q];
-                if (has_off && off_in) x -= off1;
+                if (has_off) x -= off1;
                 T[k * LD + r] = ((okm >> q) & 1u) ? x : 0.f;
             }
         }
@@ -171,9 +216,10 @@ struct GemmCore {
     // SIMD (one 128 x 64 tile per CU at the C3 layer shapes) then spends the step issuing MFMAs back to back: the
     // stores / loads go out in the 64-cycle shadows of the matrix pipe.  Fragment reads run two k-pair groups ahead
     // (a group = two k-pairs = one ds_read2 per operand = 2 MT NT MFMAs).
-    template <bool NEXT, typename OA, typename OB, typename Fetch>
+    template <bool NEXT, typename OA, typename OB, typename FetchA, typename FetchB>
     __device__ __forceinline__ void step(const float* __restrict__ As, const float* __restrict__ Bs,
-                                         float* __restrict__ An, float* __restrict__ Bn, OA& oa, OB& ob, Fetch fetch_next) {
+                                         float* __restrict__ An, float* __restrict__ Bn, OA& oa, OB& ob, FetchA fetch_a,
+                                         FetchB fetch_b) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         const int wm = wv >> 1, wn = wv & 1;
         if (M16) {
@@ -201,10 +247,11 @@ struct GemmCore {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 mm(2 * g);
-                if (NEXT && g == 0) oa.stash(An);
+                if (NEXT && g == 0) { oa.stash(An); if (GC_FETCH_MODE == 2) fetch_a(); }
                 if (NEXT && g == 1) ob.stash(Bn);
                 if (NEXT && NG == 1 && g == 0) ob.stash(Bn);
-                if (NEXT && g == (NG > 2 ? 2 : NG - 1)) fetch_next();
+                if (NEXT && GC_FETCH_MODE == 2 && g == (NG > 1 ? 1 : 0)) fetch_b();
+                if (NEXT && GC_FETCH_MODE != 2 && g == (GC_FETCH_MODE == 1 ? (NG > 1 ? 1 : 0) : (NG > 2 ? 2 : NG - 1))) { fetch_a(); fetch_b(); }
                 mm(2 * g + 1);
                 if (g + 2 < NG) { rd(2 * g + 4); rd(2 * g + 5); }
                 __builtin_amdgcn_sched_barrier(0);
@@ -234,18 +281,19 @@ struct GemmCore {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            mm(2 * g);
-            if (NEXT && g == 0) oa.stash(An);
-            if (NEXT && g == 1) ob.stash(Bn);
-            if (NEXT && NG == 1 && g == 0) ob.stash(Bn);
-            if (NEXT && g == (NG > 2 ? 2 : NG - 1)) fetch_next();
-            mm(2 * g + 1);
-            if (g + 2 < NG) { rd(2 * g + 4); rd(2 * g + 5); }
+            mm((GC_DBG & 4) ? 0 : 2 * g);
+            if (NEXT && !(GC_DBG & 2) && g == 0) { oa.stash(An); if (GC_FETCH_MODE == 2) fetch_a(); }
+            if (NEXT && !(GC_DBG & 2) && g == 1) ob.stash(Bn);
+            if (NEXT && !(GC_DBG & 2) && NG == 1 && g == 0) ob.stash(Bn);
+            if (NEXT && !(GC_DBG & 1) && GC_FETCH_MODE == 2 && g == (NG > 1 ? 1 : 0)) fetch_b();
+            if (NEXT && !(GC_DBG & 1) && GC_FETCH_MODE != 2 && g == (GC_FETCH_MODE == 1 ? (NG > 1 ? 1 : 0) : (NG > 2 ? 2 : NG - 1))) { fetch_a(); fetch_b(); }
+            mm((GC_DBG & 4) ? 1 : 2 * g + 1);
+            if (!(GC_DBG & 4) && g + 2 < NG) { rd(2 * g + 4); rd(2 * g + 5); }
             __builtin_amdgcn_sched_barrier(0);       // the reads of group g + 2 stay in front of the MFMAs of group g + 1
         }
     }
 
-    // Main loop over [k_begin, k_end).  pre(opA, opB, k0): hook applied to freshly fetched registers (cost_gemm's
+    // Main loop over [k_begin, k_end).  pre.a(opA, k0) / pre.b(opB, k0): hooks applied to freshly fetched registers (cost_gemm's
     // centring); post(As_stage, k0): hook run once per stage after its barrier, before the MFMAs (wgrad's bias sums).
     template <typename Pre, typename Post>
     __device__ __forceinline__ void run(float* __restrict__ lds, const float* __restrict__ A, int lda, int row0, int M,
@@ -255,12 +303,13 @@ struct GemmCore {
         GcOperand<BN, BK, B_KMAJOR, VEC_B> ob;
         float* As = lds; float* Bs = lds + 2 * STAGE_A;
         if (k_begin >= k_end) return;
+        oa.bind(A, lda, row0, M); ob.bind(B, ldb, col0, N);
         oa.fetch(A, lda, row0, M, k_begin, k_end); ob.fetch(B, ldb, col0, N, k_begin, k_end);
-        pre(oa, ob, k_begin);
+        pre.a(oa, k_begin); pre.b(ob, k_begin);
         oa.stash(As); ob.stash(Bs);
         __syncthreads();
         int st = 0;
-        if (k_begin + BK < k_end) { oa.fetch(A, lda, row0, M, k_begin + BK, k_end); ob.fetch(B, ldb, col0, N, k_begin + BK, k_end); pre(oa, ob, k_begin + BK); }
+        if (k_begin + BK < k_end) { oa.fetch(A, lda, row0, M, k_begin + BK, k_end); ob.fetch(B, ldb, col0, N, k_begin + BK, k_end); pre.a(oa, k_begin + BK); pre.b(ob, k_begin + BK); }
         // ONE body in the loop, the last K step peeled behind it: with both step<> forms inside the loop (round 3) the
         // accumulators were loop-carried through a phi the register allocator resolved with a full copy of the
         // accumulator file on entry AND exit of every K step (64 + 64 v_accvgpr moves per step at 128 x 128:
@@ -269,19 +318,16 @@ struct GemmCore {
         for (; k0 + BK < k_end; k0 += BK) {
             float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
             post(Ac, k0);
-            step<true>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob, [&]() {
-                if (k0 + 2 * BK < k_end) {
-                    oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end);
-                    pre(oa, ob, k0 + 2 * BK);
-                }
-            });
-            __syncthreads();
+            step<true>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob,
+                       [&]() { if (k0 + 2 * BK < k_end) { oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); pre.a(oa, k0 + 2 * BK); } },
+                       [&]() { if (k0 + 2 * BK < k_end) { ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end); pre.b(ob, k0 + 2 * BK); } });
+            if (!(GC_DBG & 8)) __syncthreads();
             st ^= 1;
         }
         {
             float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
             post(Ac, k0);
-            step<false>(Ac, Bc, nullptr, nullptr, oa, ob, []() {});
+            step<false>(Ac, Bc, nullptr, nullptr, oa, ob, []() {}, []() {});
         }
     }
 
@@ -302,5 +348,8 @@ struct GemmCore {
     }
 };
 
-struct GcNoPre { template <typename OA, typename OB> __device__ __forceinline__ void operator()(OA&, OB&, int) const {} };
+struct GcNoPre {
+    template <typename OA> __device__ __forceinline__ void a(OA&, int) const {}
+    template <typename OB> __device__ __forceinline__ void b(OB&, int) const {}
+};
 struct GcNoPost { __device__ __forceinline__ void operator()(const float*, int) const {} };
