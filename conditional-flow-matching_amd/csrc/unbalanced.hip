@@ -23,6 +23,9 @@
 #include "cfm_common.h"
 
 #define UB_NCHUNK_MAX 64
+#ifndef UB_FUSED
+#define UB_FUSED 1               // 0: the launch-per-step loops of round 3 (A/B switch; same results)
+#endif
 
 struct UbState {
     int done, iters, status, final_idx;   // status: 0 ok, 1 numerical error (previous iterate returned)
@@ -33,8 +36,12 @@ struct UbState {
     double total;               // partial: sum_j beta2_j * coldot_j
     unsigned long long mx[6];   // ordered-double maxima: |u-u'|, |u|, |u'|, |v-v'|, |v|, |v'|
     double err2;                // partial: || Kprev - K ||_F^2
-    double fold;                // partial: scalar factor sigma * s on its way into alpha2
+    double fold[2];             // partial: scalar factor sigma * s that alpha (U[0] / U[1]) still has to be multiplied by
+    unsigned long long amax;    // partial: ordered-double max |alpha2| of the iteration (finiteness of alpha2 * fold)
+    unsigned tiles_done;        // fused column kernel: arrival word
+    unsigned pad2;
 };
+static_assert(sizeof(UbState) <= 512, "UbState must fit the 512 bytes carved for it");
 
 struct UbWs {
     UbState* st;
@@ -108,6 +115,7 @@ __global__ void ub_state_init(UbState* st) {
         st->done = 0; st->iters = 0; st->status = 0; st->final_idx = 0;
         st->flag_bad = 0; st->n_zero = 0; st->n_nonfinite = 0;
         st->err = 1.0; st->sumK = 0.0; st->sigma = 1.0; st->total = 0.0; st->err2 = 0.0;
+        st->fold[0] = 1.0; st->fold[1] = 1.0; st->amax = 0ull; st->tiles_done = 0u;
         for (int k = 0; k < 6; ++k) st->mx[k] = 0ull;
     }
 }
@@ -256,6 +264,203 @@ __global__ void ub_info(const UbState* st, int* info) {
     }
 }
 
+// ---------------------------------------------------------------- fused iteration (round 4)
+// Round 3 ran an iteration as a chain of launches: two streaming passes and, around them, one small launch per
+// elementwise update and per control decision — five ~4.8 us launches per partial iteration that did nothing wide
+// (24 of 78 us), and a column update whose 16 workgroups summed 64 strip partials one dependent load at a time (21 us).
+// Here an iteration is THREE launches:
+//   ub_row_fused:  y_i = sum_j K_ij x_j and, by the wave that owns the row, the row update itself;
+//   ub_coldot:     the strip partials of z_j = sum_i K_ij w_i (unchanged);
+//   ub_col_fused:  per 64-column workgroup the sum of the strip partials (same order, all loads in flight) and the
+//                  column update; the LAST workgroup to arrive (one device-scope ticket; everything it needs from the
+//                  others — the running total, the flags, the maxima — travels through device-scope atomics, so no
+//                  fence is paid) takes the scalar step and the loop's control decision.
+// (The strip partials are NOT merged inside ub_coldot by a last-strip-done ticket: 1024 workgroups each writing back
+//  and invalidating their L2 measured 124 us against 39 us for the same structure in the Sinkhorn column pass.)
+// Same arithmetic in the same order as the launch-per-step loop (kept behind -DUB_FUSED=0).
+__device__ __forceinline__ int ub_ld_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ub_ld_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ub_ld_f64(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ double ub_row_dot(const double* __restrict__ row, const double* __restrict__ x, int B1, int lane) {
+    double acc = 0.0;
+    if ((B1 & 1) == 0) {
+        for (int j = lane * 2; j < B1; j += 128 * 4) {
+            double2 k2[4], x2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jj = j + 128 * q;
+                k2[q] = (jj < B1) ? *reinterpret_cast<const double2*>(row + jj) : make_double2(0.0, 0.0);
+                x2[q] = (jj < B1) ? *reinterpret_cast<const double2*>(x + jj) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += k2[q].x * x2[q].x + k2[q].y * x2[q].y;
+        }
+    } else {
+        for (int j = lane; j < B1; j += 64) acc += row[j] * x[j];
+    }
+    return wave_sum_d(acc);
+}
+
+// MODE 0 (unbalanced): u_new = (a / (K v)_i)^fi          MODE 1 (partial): the Dykstra row step
+template <int MODE>
+__global__ __launch_bounds__(256) void ub_row_fused(const double* __restrict__ K, int B0, int B1, UbState* st,
+                                                    const double* __restrict__ x, double a, double fi,
+                                                    const double* __restrict__ uprev, double* __restrict__ unew,
+                                                    double* __restrict__ rho, int check, int p) {
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= B0) return;
+    // (the operands of the row update are requested before the row is streamed: no dependent load behind the dot)
+    const double up = (MODE == 1) ? uprev[r] : 0.0;
+    const double rh = (MODE == 1) ? rho[r] : 0.0;
+    const double fo = (MODE == 1) ? st->fold[p] : 1.0;
+    const double kv = ub_row_dot(K + (size_t)r * B1, x, B1, lane);
+    if (lane != 0) return;
+    if (MODE == 0) {
+        const double u = pow(a / kv, fi);
+        unew[r] = u;
+        if (isnan(u) || isinf(u)) atomicOr(&st->flag_bad, 1);
+        // (the maxima |u - u'|, |u|, |u'| of a check iteration are taken by the deciding wave of ub_col_fused from the
+        //  two arrays: one device-scope atomic per ROW — 4096 waves, one lane each, on one address — cost 11 ns apiece
+        //  at the memory side, 135 us per check launch; the launch-per-step kernel issued them 64 lanes at a time)
+    } else {
+        // alpha arrives with its scalar factor still pending (fold[p]: one multiplication, exactly the one pt_fold did)
+        const double al = up * fo, a1 = al * rh;
+        const double rowsum = a1 * kv;
+        const double rr = fmin(a / rowsum, 1.0);
+        const double a2 = rr * a1;
+        unew[r] = a2;
+        rho[r] = rh * al / a2;
+        if (!isfinite(a2)) atomicOr(&st->flag_bad, 1);         // (max |alpha2|: by the deciding wave of ub_col_fused)
+    }
+}
+
+// MODE 0 (unbalanced): v_new = (b / (K^T u)_j)^fi, then ub_decide      MODE 1 (partial): the Dykstra column step, the
+// scalar step, the finiteness flags and (unless an error pass follows: defer_decide) pt_decide
+#define UB_COLW 64       // columns per workgroup of the fused column kernel (one wave: B1 / 64 workgroups spread over the chip)
+template <int MODE>
+__global__ __launch_bounds__(UB_COLW) void ub_col_fused(int B1, int nchunk, UbState* st, const double* __restrict__ part,
+                                                        double b, double fi, const double* __restrict__ vprev,
+                                                        double* __restrict__ vnew, double* __restrict__ kappa, int check,
+                                                        int cpt, int max_iter, double stop_thr, double m, int defer_decide,
+                                                        const double* __restrict__ errbuf, int B0,
+                                                        const double* __restrict__ uold, const double* __restrict__ unew) {
+    if (st->done) return;
+    const int j = blockIdx.x * UB_COLW + threadIdx.x;
+    double contrib = 0.0;
+    double cm0 = 0.0, cm1 = 0.0, cm2 = 0.0;                 // unbalanced, check iterations: this wave's column maxima
+    if (j < B1) {
+        // every strip partial of the column is requested at once (nchunk <= UB_NCHUNK_MAX = 64), then summed in strip
+        // order as before: round 3 walked them one dependent load at a time in 16 workgroups (21 us per iteration)
+        const double be = vprev[j];
+        const double ka = (MODE == 1) ? kappa[j] : 0.0;
+        double pv[UB_NCHUNK_MAX];
+#pragma unroll
+        for (int c = 0; c < UB_NCHUNK_MAX; ++c) pv[c] = part[(size_t)min(c, nchunk - 1) * B1 + j];     // (clamped: back-to-back requests)
+        double kt = 0.0;
+#pragma unroll
+        for (int c = 0; c < UB_NCHUNK_MAX; ++c) if (c < nchunk) kt += pv[c];
+        if (MODE == 0) {
+            const double v = pow(b / kt, fi);
+            vnew[j] = v;
+            if (kt == 0.0 || isnan(v) || isinf(v)) atomicOr(&st->flag_bad, 1);
+            if (check) { cm0 = fabs(v - be); cm1 = fabs(v); cm2 = fabs(be); }
+        } else {
+            const double b1 = be * ka;
+            const double colsum = b1 * kt;
+            const double cc = fmin(b / colsum, 1.0);
+            const double b2 = cc * b1;
+            vnew[j] = b2;
+            kappa[j] = ka * be / b2;
+            contrib = b2 * kt;
+            if (!isfinite(b2)) atomicOr(&st->flag_bad, 1);
+        }
+    }
+    if (MODE == 1) {
+        contrib = wave_sum_d(contrib);
+        if (threadIdx.x == 0 && contrib != 0.0) atomicAdd(&st->total, contrib);
+    } else if (check) {                                      // one atomic per wave and maximum, not one per lane
+        cm0 = wave_max_d(cm0); cm1 = wave_max_d(cm1); cm2 = wave_max_d(cm2);
+        if (threadIdx.x == 0) { ub_atomic_max_abs(&st->mx[3], cm0); ub_atomic_max_abs(&st->mx[4], cm1); ub_atomic_max_abs(&st->mx[5], cm2); }
+    }
+    // arrival: the last workgroup (one wave) takes the control decision of the iteration.  What it needs from the other
+    // workgroups of THIS launch travels through device-scope atomics (total, flags, column maxima); the row side it
+    // reads from the arrays the row kernel wrote one launch earlier.
+    unsigned tt = 0u;
+    if (threadIdx.x == 0) tt = atomicAdd(&st->tiles_done, 1u);
+    tt = (unsigned)__shfl((int)tt, 0, 64);
+    if (tt != gridDim.x - 1u) return;
+    const int lane = threadIdx.x;
+    const int next = cpt + 1;
+    if (MODE == 0) {
+        double du = 0.0, mu = 0.0, mup = 0.0;
+        if (check) {
+            for (int i0 = lane; i0 < B0; i0 += 64 * 16) {    // 2 x 16 loads per lane in flight
+                double uu[16], pp[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {              // (clamped index, no predicated load: the requests go out back to back;
+                    const int i = min(i0 + 64 * q, B0 - 1);  //  an element read twice changes no maximum)
+                    uu[q] = unew[i]; pp[q] = uold[i];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { du = fmax(du, fabs(uu[q] - pp[q])); mu = fmax(mu, fabs(uu[q])); mup = fmax(mup, fabs(pp[q])); }
+            }
+            du = wave_max_d(du); mu = wave_max_d(mu); mup = wave_max_d(mup);
+        }
+        if (lane != 0) return;
+        st->tiles_done = 0u;
+        if (ub_ld_i32(&st->flag_bad)) {                      // u, v = uprev, vprev; break
+            st->status = 1; st->final_idx = cpt & 1; st->iters = cpt; st->done = 1;
+            return;
+        }
+        if (check) {
+            const double dv = __longlong_as_double((long long)ub_ld_u64(&st->mx[3])), mv = __longlong_as_double((long long)ub_ld_u64(&st->mx[4])),
+                         mvp = __longlong_as_double((long long)ub_ld_u64(&st->mx[5]));
+            const double err_u = du / fmax(fmax(mu, mup), 1.0);
+            const double err_v = dv / fmax(fmax(mv, mvp), 1.0);
+            st->err = 0.5 * (err_u + err_v);
+            for (int k = 0; k < 6; ++k) st->mx[k] = 0ull;
+        }
+        st->iters = next; st->final_idx = next & 1;
+        if (!(st->err > stop_thr) || next >= max_iter) st->done = 1;
+    } else {
+        double am = 0.0;                                     // largest |alpha2| of the iteration (non-finite ones are flagged)
+        for (int i0 = lane; i0 < B0; i0 += 64 * 32) {        // 32 loads per lane in flight
+            double uu[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) uu[q] = unew[min(i0 + 64 * q, B0 - 1)];     // (clamped: back-to-back requests)
+#pragma unroll
+            for (int q = 0; q < 32; ++q) am = fmax(am, fabs(uu[q]));
+        }
+        am = wave_max_d(am);
+        if (lane != 0) return;
+        st->tiles_done = 0u;
+        // pt_scalar: K = K2 * q3 * (m / sum(K2 * q3)); q3 <- 1 / s; the factor sigma * s stays pending on alpha2 = U[q]
+        const double S = st->sigma * ub_ld_f64(&st->total);
+        const double sc = m / S;
+        const double fold = st->sigma * sc;
+        st->fold[next & 1] = fold;
+        st->sigma = 1.0 / sc;
+        st->total = 0.0;
+        // pt_flags: alpha2 * fold and beta2 finite (the largest |alpha2| times the common factor decides for every row)
+        if (!isfinite(am * fold)) atomicOr(&st->flag_bad, 1);
+        if (defer_decide) return;                            // an error pass follows, then pt_decide
+        if (ub_ld_i32(&st->flag_bad)) { st->status = 1; st->final_idx = next & 1; st->iters = cpt; st->done = 1; return; }
+        st->iters = next; st->final_idx = next & 1;
+        if (!(*errbuf > stop_thr) || next >= max_iter) st->done = 1;
+    }
+}
+
+// apply the scalar factors still pending on alpha (partial: before the plan is written)
+__global__ void pt_fold_final(int B0, const UbState* st, double* __restrict__ u0, double* __restrict__ u1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B0) { u0[i] *= st->fold[0]; u1[i] *= st->fold[1]; }
+}
+
 extern "C" int cfm_unbalanced_sinkhorn_f64(const float* M, int B0, int B1, double reg, double reg_m,
                                            int max_iter, double stop_thr, double* plan, int* info,
                                            void* ws, void* stream) {
@@ -275,6 +480,15 @@ extern "C" int cfm_unbalanced_sinkhorn_f64(const float* M, int B0, int B1, doubl
     for (int cpt = 0; cpt < max_iter; ++cpt) {
         const int check = (cpt % 10 == 0) ? 1 : 0;
         const int p = cpt & 1, q = p ^ 1;
+#if UB_FUSED
+        hipLaunchKernelGGL(ub_row_fused<0>, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], a, fi,
+                           w.U[p], w.U[q], (double*)nullptr, check, p);
+        hipLaunchKernelGGL(ub_coldot, dim3((B1 + 255) / 256, nchunk), dim3(256), 0, s, plan, B0, B1, w.st,
+                           w.U[q], w.part, rows_per_chunk);
+        hipLaunchKernelGGL(ub_col_fused<0>, dim3((B1 + UB_COLW - 1) / UB_COLW), dim3(UB_COLW), 0, s, B1, nchunk, w.st, w.part, b, fi,
+                           w.V[p], w.V[q], (double*)nullptr, check, cpt, max_iter, stop_thr, 0.0, 0, (const double*)nullptr,
+                           B0, (const double*)w.U[p], (const double*)w.U[q]);
+#else
         hipLaunchKernelGGL(ub_rowdot, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], w.rowacc);
         hipLaunchKernelGGL(ub_u_update, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, a, fi, w.st, w.rowacc,
                            w.U[p], w.U[q], check);
@@ -283,6 +497,7 @@ extern "C" int cfm_unbalanced_sinkhorn_f64(const float* M, int B0, int B1, doubl
         hipLaunchKernelGGL(ub_v_update, dim3((B1 + 255) / 256), dim3(256), 0, s, B1, nchunk, b, fi, w.st,
                            w.part, w.V[p], w.V[q], check);
         hipLaunchKernelGGL(ub_decide, dim3(1), dim3(1), 0, s, w.st, cpt, max_iter, stop_thr, check);
+#endif
     }
     hipLaunchKernelGGL(ub_plan, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[0], w.U[1], w.V[0], w.V[1], 0);
     hipLaunchKernelGGL(ub_info, dim3(1), dim3(64), 0, s, w.st, info);
@@ -338,13 +553,17 @@ __global__ void pt_col_update(int B1, int nchunk, double b, UbState* st, const d
 // || diag(alpha) K0 diag(beta) - diag(alpha2) K0 diag(beta2) ||_F^2 (alpha2 already carries sigma * s)
 __global__ __launch_bounds__(256) void pt_err(const double* __restrict__ K, int B0, int B1, UbState* st,
                                               const double* __restrict__ alpha, const double* __restrict__ beta,
-                                              const double* __restrict__ alpha2, const double* __restrict__ beta2) {
+                                              const double* __restrict__ alpha2, const double* __restrict__ beta2, int p) {
     if (st->done) return;
     const size_t n = (size_t)B0 * B1;
+    // fused loop: the scalar factors are still pending on alpha = U[p] and alpha2 = U[p ^ 1] (one multiplication each,
+    // the one pt_fold did before the value was stored); launch-per-step loop (p < 0): already applied
+    const double fa = p >= 0 ? st->fold[p] : 1.0, fb = p >= 0 ? st->fold[p ^ 1] : 1.0;
     double acc = 0.0;
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
         const int i = (int)(k / B1), j = (int)(k - (size_t)i * B1);
-        const double d = K[k] * (alpha[i] * beta[j] - alpha2[i] * beta2[j]);
+        const double al = p >= 0 ? alpha[i] * fa : alpha[i], al2 = p >= 0 ? alpha2[i] * fb : alpha2[i];
+        const double d = K[k] * (al * beta[j] - al2 * beta2[j]);
         acc += d * d;
     }
     acc = wave_sum_d(acc);
@@ -360,7 +579,7 @@ __global__ void pt_scalar(UbState* st, double m) {
     if (st->done) return;
     const double S = st->sigma * st->total;      // sum(K2 * q3)
     const double s = m / S;
-    st->fold = st->sigma * s;                    // the scalar factor of this iteration, folded into alpha2
+    st->fold[0] = st->sigma * s;                 // the scalar factor of this iteration, folded into alpha2 (launch-per-step loop)
     st->sigma = 1.0 / s;
     st->total = 0.0;
 }
@@ -369,7 +588,7 @@ __global__ void pt_fold(int B0, const UbState* st, double* __restrict__ alpha2) 
     if (st->done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B0) {
-        alpha2[i] *= st->fold;
+        alpha2[i] *= st->fold[0];
     }
 }
 
@@ -421,6 +640,19 @@ extern "C" int cfm_partial_entropic_f64(const float* M, int B0, int B1, double r
     for (int cpt = 0; cpt < max_iter; ++cpt) {
         const int check = (cpt % 10 == 0) ? 1 : 0;
         const int p = cpt & 1, q = p ^ 1;    // (alpha, beta) = (U[p], V[p]) -> (U[q], V[q])
+#if UB_FUSED
+        hipLaunchKernelGGL(ub_row_fused<1>, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], a, 0.0,
+                           w.U[p], w.U[q], w.rho, 0, p);
+        hipLaunchKernelGGL(ub_coldot, dim3((B1 + 255) / 256, nchunk), dim3(256), 0, s, plan, B0, B1, w.st,
+                           w.U[q], w.part, rows_per_chunk);
+        hipLaunchKernelGGL(ub_col_fused<1>, dim3((B1 + UB_COLW - 1) / UB_COLW), dim3(UB_COLW), 0, s, B1, nchunk, w.st, w.part, b, 0.0,
+                           w.V[p], w.V[q], w.kappa, check, cpt, max_iter, stop_thr, m, check, (const double*)w.colacc,
+                           B0, (const double*)w.U[p], (const double*)w.U[q]);
+        if (check) {
+            hipLaunchKernelGGL(pt_err, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[p], w.V[p], w.U[q], w.V[q], p);
+            hipLaunchKernelGGL(pt_decide, dim3(1), dim3(1), 0, s, w.st, cpt, max_iter, stop_thr, check, w.colacc);
+        }
+#else
         hipLaunchKernelGGL(ub_rowdot, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], w.rowacc);
         hipLaunchKernelGGL(pt_row_update, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, a, w.st, w.rowacc,
                            w.U[p], w.rho, w.U[q]);
@@ -432,9 +664,13 @@ extern "C" int cfm_partial_entropic_f64(const float* M, int B0, int B1, double r
         hipLaunchKernelGGL(pt_fold, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, w.st, w.U[q]);
         hipLaunchKernelGGL(pt_flags, dim3((nmax + 255) / 256), dim3(256), 0, s, B0, B1, w.st, w.U[q], w.V[q]);
         if (check)
-            hipLaunchKernelGGL(pt_err, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[p], w.V[p], w.U[q], w.V[q]);
+            hipLaunchKernelGGL(pt_err, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[p], w.V[p], w.U[q], w.V[q], -1);
         hipLaunchKernelGGL(pt_decide, dim3(1), dim3(1), 0, s, w.st, cpt, max_iter, stop_thr, check, w.colacc);
+#endif
     }
+#if UB_FUSED
+    hipLaunchKernelGGL(pt_fold_final, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, w.st, w.U[0], w.U[1]);
+#endif
     // POT keeps the NaN matrix when K had zeros (0 / 0 in the q updates poisons every entry within
     // two iterations): reproduce it so the caller's diagnostics (optimal_transport.py:88-92) fire
     hipLaunchKernelGGL(ub_plan, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[0], w.U[1], w.V[0], w.V[1], 1);
