@@ -232,6 +232,11 @@ def sinkhorn_log(M, reg, max_iter=_SINKHORN_MAX_ITER, stop_thr=_SINKHORN_STOP_TH
 
 
 _POINTS_MAX_DIM = 8     # cfm_sinkhorn_log_points_f32: cost entries recomputed on the fly up to this dimension
+# ... and the dimension up to which OTPlanSampler TAKES that solver.  Measured in round 4 (fp32-exp regime, 200
+# iterations, variant B / matrix streaming): B = 4096: d = 1..3 1.55 / 1.34 / 1.19, d = 4..8 0.95 ... 0.54;
+# B = 8192: 1.47 / 1.28 / 1.15, then 0.96 ... 0.56; B = 1024-2048: 1.1 ... 0.9 at d <= 3, 0.86 ... 0.37 beyond.
+# The per-pair cost chain grows with d while a matrix entry stays 4 bytes (round 3 sent every d <= 8 to variant B).
+_POINTS_TAKE_DIM = 3
 
 
 def sinkhorn_log_points(x0, x1, M, reg, max_iter=_SINKHORN_MAX_ITER, stop_thr=_SINKHORN_STOP_THR,
@@ -433,7 +438,7 @@ class OTPlanSampler:
             perm = assign_exact(M)        # raises unless the fp64 certificate holds; nothing is read back
             self._last = {"certified": True}
             return "perm", perm, M
-        if a.shape[1] <= _POINTS_MAX_DIM and not self.normalize_cost:
+        if a.shape[1] <= _POINTS_TAKE_DIM and not self.normalize_cost:
             r = sinkhorn_log_points(a, b, M, self.reg)      # low-dimensional clouds: no pass over the matrix
         else:
             r = sinkhorn_log(M, self.reg)
