@@ -61,13 +61,15 @@ def synth_batches(B, d, n, seed, dev):
 
 
 # --------------------------------------------------------------------------- the timed loop
-def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, depth=0, group=1, couple_group=None):
+def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, depth=0, group=1, couple_group=None, ramp=()):
     """`count` steps starting at pool index `first`: every step = one coupling + one model update,
     all of them inside this call (a prefetch pipeline starts empty and is drained).  Returns the
     last (t, xt, ut).  Device agnostic: `couple(x0, x1, drawn)` and `model_step(t, xt, ut)` are the
     caller's; the CPU multi-process test drives this with CPU stand-ins.
     group > 1: the couplings of `group` consecutive minibatches are one prefetch job
-    (`couple_group(batches, drawn_list)` -> one result per minibatch), `depth` such jobs in flight."""
+    (`couple_group(batches, drawn_list)` -> one result per minibatch), `depth` such jobs in flight.
+    ramp: group sizes of the FIRST jobs (then `group`): the pipeline starts empty inside the timed call, and the first
+    model step cannot start before the first job is back — a small first job shortens that fill."""
     last = None
     if not depth or prefetcher is None:
         for k in range(count):
@@ -77,9 +79,12 @@ def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, dep
         return last
     inflight, submitted = collections.deque(), 0
     if group > 1 and couple_group is not None:
+        njobs = 0
+
         def submit_next():
-            nonlocal submitted
-            k = min(group, count - submitted)
+            nonlocal submitted, njobs
+            k = min(ramp[njobs] if njobs < len(ramp) else group, count - submitted)
+            njobs += 1
             batches = [pool[(first + submitted + q) % len(pool)] for q in range(k)]
             inflight.append(prefetcher.submit_group(batches, couple_group, draw)); submitted += k
         while submitted < count and len(inflight) < depth:
@@ -102,13 +107,13 @@ def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, dep
 
 
 def timed_region(D, sync, pool, warmup, steps, couple, model_step, draw, prefetcher, depth, device=None, group=1,
-                 couple_group=None):
+                 couple_group=None, ramp=()):
     """Warm-up, barrier + sync, K steps + ONE all-gather of the final samples, sync + barrier; the
     MAX over ranks of the elapsed time.  Returns (elapsed_s, gathered_final_xt)."""
-    run_steps(pool, 0, warmup, couple, model_step, draw, prefetcher, depth, group, couple_group)
+    run_steps(pool, 0, warmup, couple, model_step, draw, prefetcher, depth, group, couple_group, ramp)
     D.barrier(); sync()
     t0 = time.perf_counter()
-    last = run_steps(pool, warmup, steps, couple, model_step, draw, prefetcher, depth, group, couple_group)
+    last = run_steps(pool, warmup, steps, couple, model_step, draw, prefetcher, depth, group, couple_group, ramp)
     gathered = D.all_gather_samples(last[1]) if last is not None else None
     sync(); D.barrier()
     return D.max_over_ranks(time.perf_counter() - t0, device), gathered
@@ -580,6 +585,9 @@ def main():
     ap.add_argument("--group", type=int, default=4,
                     help="G > 1: a prefetch job couples G consecutive minibatches together (the exact solver takes the G "
                          "assignment problems in one chain of launches); --pipeline such jobs in flight")
+    ap.add_argument("--ramp", default=os.environ.get("CFM_BENCH_RAMP", "1"),
+                    help="comma-separated group sizes of the FIRST prefetch jobs of a run (then --group): the pipeline starts "
+                         "empty inside the timed region, a small first job lets the first model step start sooner")
     ap.add_argument("--model-step", default="fused", choices=["fused", "eager"],
                     help="fused: cfm_amd.RegressionStep (one C call: forward + MSE + backward, then the one-launch Adam); "
                          "eager: the reference's four lines on the autograd.Function path")
@@ -685,6 +693,7 @@ def main():
         opt.step()
 
     pre = None
+    ramp = tuple(int(x) for x in args.ramp.split(",") if x.strip()) if (args.pipeline and args.group > 1) else ()
     part, main_stream = None, None
     if args.pipeline and args.partition > 0:
         from cfm_amd.streams import ChipPartition
@@ -697,7 +706,7 @@ def main():
         # one-time costs per worker thread (stream, workspaces, the solver's captured launch programs for each job shape
         # the loops are going to submit) are paid before the warm-up steps, on every worker
         rs_np, rs_t = np.random.get_state(), torch.get_rng_state()
-        shapes = {args.group} | {args.steps % args.group, args.warmup % args.group} if args.group > 1 else {1}
+        shapes = ({args.group} | set(ramp) | set(range(1, args.group))) if args.group > 1 else {1}
         for k in sorted(shapes - {0}, reverse=True):
             if args.group > 1:
                 pre.prime(lambda k=k: couple_group([pool[q % len(pool)] for q in range(k)], [draw() for _ in range(k)]))
@@ -710,7 +719,7 @@ def main():
     regions = []
     for _ in range(max(1, args.repeats)):
         el, gathered = timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple, model_step,
-                                    draw, pre, args.pipeline, dev, args.group, couple_group)
+                                    draw, pre, args.pipeline, dev, args.group, couple_group, ramp)
         assert gathered is None or gathered.shape[0] == world * B
         regions.append(el)
     elapsed = float(np.median(regions))
@@ -753,6 +762,7 @@ def main():
                                     "cfm_assign_exact_batch_f32)" if args.group > 1 else ""))
                                 if args.pipeline else "sequential"),
                    "prefetch_jobs": args.pipeline, "prefetch_group": args.group if args.pipeline else 0,
+                   "prefetch_ramp": list(ramp),
                    "chip_partition": ({"solver_cus": part.solver_cus, "dense_cus": part.dense_cus,
                                        "note": "CU-masked streams: the exact solver's launches on solver_cus, cost matrix "
                                                "/ sampling / model step on dense_cus"} if part is not None else None),

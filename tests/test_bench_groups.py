@@ -75,3 +75,20 @@ def test_prime_runs_once_on_every_worker():
     pre.prime(lambda: seen.append(threading.get_ident()))
     pre.close()
     assert len(seen) == 3 and len(set(seen)) == 3
+
+
+def test_ramped_first_jobs_keep_order_and_results():
+    """--ramp: the first prefetch jobs of a run are smaller (the pipeline starts empty inside the timed call); the steps,
+    their order and their results are those of the sequential loop."""
+    import bench
+    from cfm_amd.prefetch import CouplingPrefetcher
+    pool, draw, couple, couple_group, model_step, log = _setup()
+    np.random.seed(3); torch.manual_seed(3)
+    bench.run_steps(pool, 1, 12, couple, model_step, draw)
+    seq = list(log["stepped"]); log["stepped"].clear(); log["coupled"].clear()
+    np.random.seed(3); torch.manual_seed(3)
+    pre = CouplingPrefetcher(None, torch.device("cpu"), workers=3)
+    bench.run_steps(pool, 1, 12, couple, model_step, draw, pre, 3, 4, couple_group, ramp=(1, 2))
+    pre.close()
+    assert log["stepped"] == seq
+    assert log["groups"] == [1, 2, 4, 4, 1]
