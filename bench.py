@@ -43,6 +43,18 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+def newest_profile(name):
+    """profiles/rNN_<name> of the latest round that has one (the committed rocprofv3 summaries bench.py quotes)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_" + name)):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md)
 F32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32-input MFMA peak
 
@@ -151,11 +163,11 @@ def sinkhorn_leg(dev, cfg, reg, iters=200):
                 "bytes move; achieved = the algorithmic 2 x 4 x B^2 bytes per iteration / time (it may exceed the "
                 "HBM peak: it is an equivalent rate, the kernel is VALU / exp bound); matrix-streaming solver on the "
                 "same input: %.0f it/s" % (iters / (ms_stream * 1e-3)))
-    # HBM bytes per iteration from the committed counter passes (profiles/r3_sk_pmc_summary.json: rocprofv3 --pmc
+    # HBM bytes per iteration from the committed counter passes (profiles/rNN_sk_pmc_summary.json: rocprofv3 --pmc
     # FETCH_SIZE x2 + WRITE_SIZE over tools/sk_probe.py), next to the algorithmic figure
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_sk_pmc_summary.json")))
+        pmc = json.load(open(newest_profile("sk_pmc_summary.json")))
         traffic = pmc.get(f"{cfg}_points_hbm_bytes_per_iteration" if points else f"{cfg}_streaming_hbm_bytes_per_iteration")
         traffic_stream = pmc.get(f"{cfg}_streaming_hbm_bytes_per_iteration")
     except Exception:  # noqa: BLE001
@@ -467,8 +479,8 @@ def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
     t_step = float(np.mean(step_us)) * 1e-6
     gbs = bytes_solve / t_step / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r3_asg_pmc_summary.json")
-    if os.path.exists(pmc):
+    pmc = newest_profile("asg_pmc_summary.json")
+    if pmc and os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("asg_step_hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001

@@ -22,6 +22,7 @@
 //                  stay in that XCD's 4 MiB L2.
 #include "cfm_common.h"
 #include "gemm_core.h"
+#include "gemm_glds.h"
 #include <stdlib.h>
 
 // ---------------------------------------------------------------- small d ----
@@ -226,13 +227,16 @@ __global__ __launch_bounds__(256) void cost_center(const float* __restrict__ x0,
 }
 
 // nrm[i] = |fl(x0_i - mu)|^2 (i < B0), nrm[B0 + j] = |fl(x1_j - mu)|^2: one wave per row
+// xc (may be NULL): the centred rows fl(x - mu) themselves, [B0 + B1][d] — the operands of the direct-to-LDS product
+// (cost_gemm_glds), which cannot subtract on the way in; the same fp32 values the register-staged engine forms.
 __global__ __launch_bounds__(256) void cost_norms(const float* __restrict__ x0, const float* __restrict__ x1,
                                                   int B0, int B1, int d, const float* __restrict__ mu,
-                                                  float* __restrict__ nrm) {
+                                                  float* __restrict__ nrm, float* __restrict__ xc) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B0 + B1) return;
     const float* p = row < B0 ? x0 + (size_t)row * d : x1 + (size_t)(row - B0) * d;
+    float* pc = xc ? xc + (size_t)row * d : nullptr;
     float s = 0.f;
     int k = lane;
     for (; k + 64 * 7 < d; k += 64 * 8) {                 // 8 trips' loads in flight, the chain in k order as before
@@ -240,11 +244,12 @@ __global__ __launch_bounds__(256) void cost_norms(const float* __restrict__ x0, 
 #pragma unroll
         for (int t = 0; t < 8; ++t) { xv[t] = p[k + 64 * t]; mv[t] = mu[k + 64 * t]; }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const float tt = xv[t] - mv[t]; s = fmaf(tt, tt, s); }
+        for (int t = 0; t < 8; ++t) { const float tt = xv[t] - mv[t]; s = fmaf(tt, tt, s); if (pc) pc[k + 64 * t] = tt; }
     }
     for (; k < d; k += 64) {
         const float t = p[k] - mu[k];
         s = fmaf(t, t, s);
+        if (pc) pc[k] = t;
     }
     s = wave_sum_f(s);
     if (lane == 0) nrm[row] = s;
@@ -366,6 +371,95 @@ __global__ __launch_bounds__(256, COST_MINW) void cost_gemm(const float* __restr
     }
 }
 
+// The same product on the direct-to-LDS engine (gemm_glds.h): operands = the centred clouds cost_norms wrote (xc0, xc1),
+// same k order, same epilogue arithmetic — the matrix is bit-equal to cost_gemm's.  x0 / x1: the original clouds, read
+// only by the recomputation of cancelling entries.  64 KiB of dynamic LDS, two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void cost_gemm_glds(const float* __restrict__ xc0, const float* __restrict__ xc1,
+                                                         const float* __restrict__ x0, const float* __restrict__ x1,
+                                                         int B0, int B1, int d, const float* __restrict__ nrm,
+                                                         float* __restrict__ M, int tiles_m, int tiles_n,
+                                                         const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float glds_lds[];
+    unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    {
+        const int G = 8;
+        const int per_band = G * tiles_n;
+        const int band = lid / per_band, r = lid - band * per_band;
+        const int rows_in_band = min(G, tiles_m - band * G);
+        const int fgt = rows_in_band * G;
+        const int gcol = r / fgt;
+        const int rr = r - gcol * fgt;
+        const int cols_in_group = min(G, tiles_n - gcol * G);
+        tm = band * G + rr / cols_in_group;
+        tn = gcol * G + rr % cols_in_group;
+    }
+    const int row0 = tm * GL_BM, col0 = tn * GL_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    GldsCore g;
+    g.zero();
+    g.run(glds_lds, xc0, d, row0, B0, xc1, d, col0, B1, d, zeros);
+    gl_wait_barrier();                                   // every wave is done with the last stage
+    float* An = glds_lds; float* Bn = glds_lds + GL_BM;
+    if (tid < GL_BM) An[tid] = (row0 + tid < B0) ? nrm[row0 + tid] : 0.f;
+    if (tid < GL_BN) Bn[tid] = (col0 + tid < B1) ? nrm[B0 + col0 + tid] : 0.f;
+    __syncthreads();
+    const float ny[2] = {Bn[GldsCore::col_of(0)], Bn[GldsCore::col_of(1)]};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        float v[16][2];
+        bool anybad = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = GldsCore::row_of(m, r);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float sum = An[rl] + ny[u];
+                const float x = fmaxf(fmaf(-2.f, g.acc[m][u][r], sum), 0.f);
+                anybad |= (row0 + rl < B0 && col0 + GldsCore::col_of(u) < B1 && x < 0.125f * sum);
+                v[r][u] = x;
+            }
+        }
+        if (__ballot(anybad) != 0ull) {                       // wave uniform, rare: recompute the cancelling entries directly
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = row0 + GldsCore::row_of(m, r);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int gc = col0 + GldsCore::col_of(u);
+                    const float sum = An[GldsCore::row_of(m, r)] + ny[u];
+                    unsigned long long mask = __ballot(gr < B0 && gc < B1 && v[r][u] < 0.125f * sum);
+                    while (mask) {
+                        const int l = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int gi = __shfl(gr, l, 64), gj = __shfl(gc, l, 64);
+                        const float* pa = x0 + (size_t)gi * d;
+                        const float* pb = x1 + (size_t)gj * d;
+                        float p = 0.f;
+                        for (int k = lane; k < d; k += 64) {
+                            const float t = pa[k] - pb[k];
+                            p = fmaf(t, t, p);
+                        }
+                        p = wave_sum_f(p);
+                        if (lane == l) v[r][u] = p;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = row0 + GldsCore::row_of(m, r);
+            if (gr < B0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int gc = col0 + GldsCore::col_of(u);
+                    if (gc < B1) M[(size_t)gr * B1 + gc] = v[r][u];
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void max_reduce_f32(const float* __restrict__ M, size_t n,
                                                       unsigned* __restrict__ out_bits) {
     float m = 0.f;  // costs are >= 0
@@ -404,25 +498,50 @@ static void launch_small(const float* x0, const float* x1, int B0, int B1, float
 
 // Gram form on the matrix cores for d >= 64 and at least a 2 x 2 grid of tiles (ws: mu [d padded],
 // norms [B0 + B1]); 0 = not taken.
+// ws: mu [d padded to 64] | norms [B0 + B1, padded to 4] | 16 floats of zeros | centred rows [(B0 + B1) x d] (the
+// operands of the direct-to-LDS product; d % 4 == 0 only)
+static inline size_t cost_ws_head_floats(int B0, int B1, int d) {
+    return (size_t)((d + 63) & ~63) + (((size_t)B0 + (size_t)B1 + 3) & ~(size_t)3) + 16;
+}
+static bool cost_use_glds();
 extern "C" size_t cfm_cost_ws_bytes_internal(int B0, int B1, int d) {
-    return sizeof(float) * ((size_t)((d + 63) & ~63) + (size_t)B0 + (size_t)B1) + 256;
+    const size_t centred = (cost_use_glds() && d % 4 == 0) ? ((size_t)B0 + (size_t)B1) * (size_t)d : 0;
+    return sizeof(float) * (cost_ws_head_floats(B0, B1, d) + centred) + 256;
 }
 static bool cost_use_mfma(int B0, int B1, int d) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("CFM_COST_MFMA"); off = (e && e[0] == '0') ? 1 : 0; }
     return !off && d >= 64 && B0 >= 256 && B1 >= 256;
 }
+// CFM_COST_GLDS=1: the direct-to-LDS engine (gemm_glds.h) for the cost matrix; default: the register-staged engine.
+// The matrix has the same bits either way (asserted by tests/test_gpu_glds.py); measured in round 4 at 4096 x 4096:
+// d = 784 274.4 vs 279.6 us, d = 3136 111.5 vs 110.5 TFLOP/s — a tie, for 25 MB more scratch (the centred copies), so it
+// stays the experiment it was built as (profiles/r4_gemm_probes.txt: neither load path is what holds the product at 70 %
+// of the matrix pipe).
+static bool cost_use_glds() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("CFM_COST_GLDS"); on = (e && e[0] == '1') ? 1 : 0; }
+    return on != 0;
+}
+__global__ void cost_zero16(float* z) { if (threadIdx.x < 16) z[threadIdx.x] = 0.f; }
 static int cost_mfma(const float* x0, const float* x1, int B0, int B1, int d, float* M, void* ws,
                      hipStream_t st) {
     float* mu = reinterpret_cast<float*>(ws);
     float* nrm = mu + ((d + 63) & ~63);
-    hipLaunchKernelGGL(cost_center, dim3((d + 63) / 64), dim3(256), 0, st, x0, x1, B0, B1, d, mu);
-    hipLaunchKernelGGL(cost_norms, dim3((B0 + B1 + 3) / 4), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm);
+    float* zeros = nrm + (((size_t)B0 + (size_t)B1 + 3) & ~(size_t)3);
+    float* xc = zeros + 16;
     const bool vec = (d % 4 == 0) && (((uintptr_t)x0 & 15) == 0) && (((uintptr_t)x1 & 15) == 0);
+    const bool glds = vec && cost_use_glds();
+    hipLaunchKernelGGL(cost_center, dim3((d + 63) / 64), dim3(256), 0, st, x0, x1, B0, B1, d, mu);
+    hipLaunchKernelGGL(cost_norms, dim3((B0 + B1 + 3) / 4), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, glds ? xc : nullptr);
     // (256 x 128 tiles — 8 MFMA tiles per wave, one resident round at B = 4096 — were measured at
     //  549 us against 368 us for 128 x 128: the accumulators leave two waves per SIMD no room.)
     const int tm = (B0 + 127) / 128, tn = (B1 + 127) / 128;
-    if (vec) hipLaunchKernelGGL((cost_gemm<128, true>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, M, tm, tn);
+    if (glds) {
+        hipLaunchKernelGGL(cost_zero16, dim3(1), dim3(64), 0, st, zeros);
+        hipLaunchKernelGGL(cost_gemm_glds, dim3(tm * tn), dim3(256), GL_LDS_BYTES, st, xc, xc + (size_t)B0 * d, x0, x1, B0, B1, d,
+                           nrm, M, tm, tn, zeros);
+    } else if (vec) hipLaunchKernelGGL((cost_gemm<128, true>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, M, tm, tn);
     else     hipLaunchKernelGGL((cost_gemm<128, false>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, M, tm, tn);
     return cfm_status();
 }

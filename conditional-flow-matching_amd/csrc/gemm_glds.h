@@ -1,0 +1,151 @@
+// gemm_glds.h — the fp32-MFMA tile engine with DIRECT-TO-LDS operand loads (gfx950 global_load_lds_dwordx4), for
+// products whose two operands are both K-contiguous in memory ([rows][k]: point clouds, activations, nn.Linear weights).
+//
+//   C tile [128 x 128] += sum_k A(i, k) . B(j, k)   on v_mfma_f32_32x32x2_f32, ascending k: bitwise the same fmaf
+//   chain per output as gemm_core.h (MFMA j of a K step covers k = 2 j on lanes 0-31 and 2 j + 1 on lanes 32-63).
+//
+// Why a second engine (round 4, profiles/r4_gemm_probes.txt): in gemm_core.h an operand travels global -> registers ->
+// (transposing ds_write_b32 x 4) -> K-major LDS.  Probes priced that path at 21.5 % of the asymptotic time (the loads
+// 13 %, the stores 8.5 %) while fragment reads and the barrier were free; re-placing, re-addressing or deepening it
+// moved nothing.  Here nothing of it is left:
+//   * a stage of an operand is ROW-major in LDS, 32 floats (128 bytes = one cache line) per row, written by the memory
+//     pipeline itself: one global_load_lds_dwordx4 per wave moves 8 rows x 128 B (lane l: row l >> 3, 16-byte slot
+//     l & 7) — no staging registers, no LDS store instructions, no per-element VALU, full-line requests;
+//   * the LDS image is lane-linear (the hardware writes base + 16 x lane), so the bank swizzle lives on the SOURCE side:
+//     the lane that fills slot s of row r fetches k-quad s ^ g(r), g(r) = (r >> 1) & 7, and a fragment read of k-quad q
+//     of row r looks at slot q ^ g(r): the 16 lanes of every ds_read_b128 group then hit 16 distinct 16-byte columns;
+//   * a lane's ds_read_b128 holds k = 4 q .. 4 q + 3 of its row: MFMA 2 q takes (x | y) and MFMA 2 q + 1 (z | w), the
+//     half-waves selecting their component with one v_cndmask per operand — the k order of gemm_core.h exactly;
+//   * rows beyond the operand and k-quads beyond K are fetched from a 16-byte block of zeros (`zeros`), so edges need
+//     no masks anywhere;
+//   * two stages, one barrier per K step: wait for the stage's DMA (issued a whole step earlier), barrier, issue the next
+//     stage's DMA into the buffer everybody has just finished reading, compute.
+#pragma once
+#include "cfm_common.h"
+
+typedef float gl_f32x16 __attribute__((ext_vector_type(16)));
+
+#define GL_BM 128
+#define GL_BN 128
+#define GL_BK 32
+#define GL_STAGE_FLOATS ((GL_BM + GL_BN) * GL_BK)            // 8192 floats = 32 KiB per stage
+#define GL_LDS_BYTES (2 * GL_STAGE_FLOATS * 4)               // two stages: 64 KiB
+
+__device__ __forceinline__ void gl_dma16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+// wait for this wave's DMAs, then the workgroup barrier: orders LDS-DMA writes against the ds_reads behind it
+__device__ __forceinline__ void gl_wait_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct GldsCore {
+    gl_f32x16 acc[2][2];                 // wave (wm, wn): rows wm * 64 + m * 32 + rho, columns wn * 64 + n * 32 + (lane & 31)
+    const float* pa[4]; const float* pb[4];   // this lane's source of each of its 4 + 4 DMA pieces at k0 = 0 (or `zeros`)
+    int kqa[4], kqb[4];                  // first k of the lane's 16 bytes inside a stage (swizzled k-quad x 4)
+    bool za[4], zb[4];                   // piece lies in a row beyond the operand: always zeros
+
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    }
+
+    __device__ __forceinline__ void bind(const float* __restrict__ A, int lda, int row0, int M,
+                                         const float* __restrict__ B, int ldb, int col0, int N) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 8 * (wv + 4 * q) + (lane >> 3);          // row of the tile this lane fills in piece q
+            const int kq = (lane & 7) ^ ((r >> 1) & 7);            // the k-quad that belongs into its slot
+            kqa[q] = 4 * kq; kqb[q] = 4 * kq;
+            za[q] = row0 + r >= M; zb[q] = col0 + r >= N;
+            pa[q] = A + (size_t)(za[q] ? 0 : row0 + r) * lda + 4 * kq;
+            pb[q] = B + (size_t)(zb[q] ? 0 : col0 + r) * ldb + 4 * kq;
+        }
+    }
+
+    // DMA of the stage [k0, k0 + 32) into LDS stage `st` (8 pieces of 1 KiB per wave)
+    __device__ __forceinline__ void issue(float* __restrict__ lds, int st, int k0, int K, const float* __restrict__ zeros) {
+        const int wv = threadIdx.x >> 6;
+        float* As = lds + st * GL_STAGE_FLOATS;
+        float* Bs = As + GL_BM * GL_BK;
+        const bool tail = k0 + GL_BK > K;                           // (uniform) some k-quads lie beyond K
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool oa = za[q] || (tail && k0 + kqa[q] >= K);
+            const bool ob = zb[q] || (tail && k0 + kqb[q] >= K);
+            gl_dma16(oa ? zeros : pa[q] + k0, As + (wv + 4 * q) * 256);
+            gl_dma16(ob ? zeros : pb[q] + k0, Bs + (wv + 4 * q) * 256);
+        }
+    }
+
+    // the 64 MFMAs of a stage
+    __device__ __forceinline__ void compute(const float* __restrict__ lds, int st) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int wm = wv >> 1, wn = wv & 1;
+        const bool hi = lane >= 32;
+        const int fr = lane & 31, sw = (fr >> 1) & 7;
+        const float* As = lds + st * GL_STAGE_FLOATS + (wm * 64 + fr) * GL_BK;
+        const float* Bs = lds + st * GL_STAGE_FLOATS + GL_BM * GL_BK + (wn * 64 + fr) * GL_BK;
+        // fragments of k-quad q + 1 are requested before the MFMAs of k-quad q are issued (two register sets)
+        float4 ta0, ta1, tb0, tb1, na0, na1, nb0, nb1;
+        {
+            const int so = 4 * sw;
+            ta0 = *reinterpret_cast<const float4*>(As + so); ta1 = *reinterpret_cast<const float4*>(As + 32 * GL_BK + so);
+            tb0 = *reinterpret_cast<const float4*>(Bs + so); tb1 = *reinterpret_cast<const float4*>(Bs + 32 * GL_BK + so);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < 7) {
+                const int so = 4 * ((q + 1) ^ sw);                   // swizzled slot of the next k-quad in this lane's rows
+                na0 = *reinterpret_cast<const float4*>(As + so); na1 = *reinterpret_cast<const float4*>(As + 32 * GL_BK + so);
+                nb0 = *reinterpret_cast<const float4*>(Bs + so); nb1 = *reinterpret_cast<const float4*>(Bs + 32 * GL_BK + so);
+            }
+            __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise sinks these reads behind the MFMAs and waits for them at once)
+            const float a00 = hi ? ta0.y : ta0.x, a01 = hi ? ta1.y : ta1.x;      // k = 4 q (+ 1 on the upper half-wave)
+            const float b00 = hi ? tb0.y : tb0.x, b01 = hi ? tb1.y : tb1.x;
+            const float a10 = hi ? ta0.w : ta0.z, a11 = hi ? ta1.w : ta1.z;      // k = 4 q + 2 (+ 1)
+            const float b10 = hi ? tb0.w : tb0.z, b11 = hi ? tb1.w : tb1.z;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b00, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b01, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, b00, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, b01, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, b10, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, b11, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b10, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b11, acc[1][1], 0, 0, 0);
+            if (q < 7) { ta0 = na0; ta1 = na1; tb0 = nb0; tb1 = nb1; }
+        }
+    }
+
+    // Main loop over [0, K).  lds: GL_LDS_BYTES of dynamic LDS; zeros: >= 16 bytes of zeros in global memory.
+    __device__ __forceinline__ void run(float* __restrict__ lds, const float* __restrict__ A, int lda, int row0, int M,
+                                        const float* __restrict__ B, int ldb, int col0, int N, int K,
+                                        const float* __restrict__ zeros) {
+        bind(A, lda, row0, M, B, ldb, col0, N);
+        issue(lds, 0, 0, K, zeros);
+        int st = 0;
+        for (int k0 = 0; k0 < K; k0 += GL_BK) {
+            gl_wait_barrier();                                      // stage `st` has landed; everybody is done with the other one
+#ifndef GL_DBG
+#define GL_DBG 0      // timing probes (results WRONG): bit 0: no DMA inside the loop
+#endif
+            if (!(GL_DBG & 1) && k0 + GL_BK < K) issue(lds, st ^ 1, k0 + GL_BK, K, zeros);
+            compute(lds, st);
+            st ^= 1;
+        }
+    }
+
+    // epilogue geometry: C/D layout of the MFMA — column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    __device__ __forceinline__ static int row_of(int m, int r) {
+        const int lane = threadIdx.x & 63, wm = threadIdx.x >> 7;
+        return wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ __forceinline__ static int col_of(int n) {
+        const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 1;
+        return wn * 64 + n * 32 + (lane & 31);
+    }
+};

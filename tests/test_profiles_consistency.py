@@ -11,8 +11,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 
 
+def _newest(name):
+    """profiles/rNN_<name> of the latest round that committed one"""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(PROF, "r*_" + name)):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    assert best is not None, name
+    return best[1]
+
+
 def _bench():
-    with open(os.path.join(PROF, "r3_bench_default.json")) as fh:
+    with open(_newest("bench_default.json")) as fh:
         return json.loads(fh.read().strip().splitlines()[-1])
 
 
@@ -35,7 +48,7 @@ def test_roofline_rederivable_from_its_fields_and_the_pmc_passes():
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
     # achieved = algorithmic bytes per launch / average launch duration
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9, rel=1e-6)
-    with open(os.path.join(PROF, "r3_asg_pmc_summary.json")) as fh:
+    with open(_newest("asg_pmc_summary.json")) as fh:
         pmc = json.load(fh)
     assert r["traffic"] == pytest.approx(pmc["asg_step_hbm_bytes_per_launch"], rel=1e-9)
     assert pmc["asg_step_hbm_bytes_per_launch"] == pytest.approx(
@@ -45,7 +58,7 @@ def test_roofline_rederivable_from_its_fields_and_the_pmc_passes():
 
 
 def test_kernel_statistics_of_the_same_command_are_committed():
-    with open(os.path.join(PROF, "r3_bench_kernel_stats.csv")) as fh:
+    with open(_newest("bench_kernel_stats.csv")) as fh:
         rows = {row["kernel"]: row for row in csv.DictReader(fh)}
     for k in ("asg_step", "asg_solve", "asg_small"):
         assert k in rows and int(rows[k]["calls"]) > 0, k
@@ -55,7 +68,7 @@ def test_kernel_statistics_of_the_same_command_are_committed():
     for k in ("mse_grad", "adam_multi", "reduce_splits_multi"):
         assert k in rows and int(rows[k]["calls"]) > 0, k
     assert any(k.startswith("void mlp_layer") for k in rows)
-    with open(os.path.join(PROF, "r3_mfma_util.csv")) as fh:
+    with open(_newest("mfma_util.csv")) as fh:
         util = {row["kernel"]: float(row["MfmaUtil_percent"]) for row in csv.DictReader(fh)}
     assert all(0.0 < v <= 100.0 for v in util.values()) and len(util) >= 4
 
@@ -65,7 +78,7 @@ def test_parity_and_sinkhorn_traffic_are_in_the_line():
     par = d["parity"]
     assert par["c3_index_agreement"] == 1.0 and par["c3_cost_gap_rel"] == 0.0       # the north star's bit-exact plan indices, end to end
     assert par["c2_index_agreement"] > 0.99 and abs(par["c2_cost_gap_rel"]) < 1e-8
-    with open(os.path.join(PROF, "r3_sk_pmc_summary.json")) as fh:
+    with open(_newest("sk_pmc_summary.json")) as fh:
         sk = json.load(fh)
     c5 = d["c5"]["roofline"]
     assert c5["traffic"] == pytest.approx(sk["C5_streaming_hbm_bytes_per_iteration"], rel=1e-9)

@@ -4,7 +4,7 @@
 #   exact-assignment solves, MFMA-busy counters of the MFMA-bearing kernels.  Summaries land in gpurun_out/prof/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof; rm -rf $O; mkdir -p $O/raw
-rocprofv3 --kernel-trace --output-format csv -d $O/raw/bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_trace.json.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/raw/bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_trace.json.log 2>&1
 python tools/prof_summary.py stats $O/raw/bench $O/bench_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/raw/asg_$C -- python tools/asg_trace.py run > $O/asg_$C.log 2>&1
@@ -19,8 +19,13 @@ python tools/prof_summary.py stats $O/raw/mfma_trace $O/mfma_kernel_stats.csv
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/raw/mfma_pmc -- python tools/mfma_probe.py > $O/mfma_pmc.log 2>&1
 python tools/prof_summary.py pmc $O/raw/mfma_pmc $O/mfma_pmc.csv
 python tools/prof_summary.py util $O/mfma_pmc.csv $O/mfma_util.csv
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/raw/mfma_pmc2 -- python tools/mfma_probe.py > $O/mfma_pmc2.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/raw/mfma_pmc2 -- python tools/mfma_probe.py > $O/mfma_pmc2.log 2>&1
 python tools/prof_summary.py pmc $O/raw/mfma_pmc2 $O/mfma_pmc2.csv
+# kernel-space entropic solvers (unbalanced / partial): per-kernel statistics of the fused loops
+rocprofv3 --kernel-trace --output-format csv -d $O/raw/ub -- python tools/ub_probe.py > /dev/null 2>&1
+python tools/prof_summary.py stats $O/raw/ub $O/ub_kernel_stats.csv
+# how the couplings in flight overlap with the model step in the pipelined loop
+python tools/overlap_report.py $O/raw/bench > $O/bench_overlap.txt 2>&1
 # Sinkhorn: per-config kernel statistics and HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes), VALU-busy of variant B
 for CFG in C5 C2; do
   rocprofv3 --kernel-trace --output-format csv -d $O/raw/sk_$CFG -- python tools/sk_probe.py $CFG > /dev/null 2>&1
