@@ -404,9 +404,9 @@ def cpu_baseline(B, d, budget_s=25.0):
             pq = oracle.exact_perm(Mq); t2 = time.perf_counter()
             oracle.sample_map_reference(oracle.perm_plan(pq), 256)
             ts.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
-        med = np.median(np.array(ts[1:]), axis=0) * 1e3
-        c1_cpu = {"cpu_ms": float(med.sum()), "cpu_solve_ms": float(med[1]), "cpu_cdist_ms": float(med[0]),
-                  "cpu_sample_map_ms": float(med[2]), "cores": 1, "kind": "port",
+        med1 = np.median(np.array(ts[1:]), axis=0) * 1e3
+        c1_cpu = {"cpu_ms": float(med1.sum()), "cpu_solve_ms": float(med1[1]), "cpu_cdist_ms": float(med1[0]),
+                  "cpu_sample_map_ms": float(med1[2]), "cores": 1, "kind": "port",
                   "sample": "20 couplings of B=256, d=2 (cdist**2 + SciPy LSAP + dense-plan np.random.choice), per-stage medians"}
     except Exception as e:                                                        # noqa: BLE001
         c1_cpu = {"error": str(e)[:160]}
