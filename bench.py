@@ -764,6 +764,7 @@ def main():
         "repeats": len(regions), "ms_per_step_all": [round(r / args.steps * 1e3, 4) for r in regions],
         "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
         "spread_rel": (max(regions) - min(regions)) / elapsed,
+        "spread_rel_iqr": float(np.percentile(regions, 75) - np.percentile(regions, 25)) / elapsed,
         "config": {"workload": "C3: MNIST-shaped d=784, B=4096 per GPU, ExactOptimalTransportConditionalFlowMatcher "
                                "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd (fp32-MFMA HIP kernels) + fused Adam (HIP)"
                                + ("; one all-gather of the final x_t over RCCL inside the timed region" if world > 1 else ""),
