@@ -1835,7 +1835,18 @@ extern "C" int cfm_assign_exact_batch_f32(const float* const* M, int nb, int B, 
                                           double* total_cost, int* stats, void* ws, void* stream) {
     if (!M || !perm || nb < 0) return CFM_EINVAL;
     if (nb == 0) return 0;
-    const AsgParams P = asg_params_snapshot();
+    AsgParams P = asg_params_snapshot();
+    // The batch entry is the THROUGHPUT form of the solve (couplings prefetched beside a model step): its launches are
+    // capped at ASG_TP_WGS workgroups per problem whatever the batch size — also for a batch of one, two or three
+    // (the first, small job of a prefetch run; the remainder of a run).  A bid round occupies the chip for as long as
+    // its slowest workgroup whatever it does, and every workgroup stages the prices: fewer, fuller workgroups take
+    // less of the chip from the other jobs and the dense products.  Measured in the C3 pipelined loop (round 4,
+    // CFM_ASG_BLOCKS sweep, same box): 256 / 64 / 32 / 16 per problem for the odd-sized jobs: 1.201 / 1.163 / 1.162 /
+    // 1.276 ms per step; a lone solve prefers the wide grid (3.30 vs 3.68 ms sequential): cfm_assign_exact_f32 keeps it.
+#ifndef ASG_TP_WGS
+#define ASG_TP_WGS 64
+#endif
+    if (P.wide_blocks_cap == 0 || P.wide_blocks_cap > ASG_TP_WGS) P.wide_blocks_cap = ASG_TP_WGS;
     const size_t stride = cfm_align_up(asg_ws_bytes(B), 256);
     int rc = 0;
     for (int b0 = 0; b0 < nb && rc == 0; b0 += ASG_BATCH_MAX) {
@@ -1849,8 +1860,12 @@ extern "C" int cfm_assign_exact_batch_f32(const float* const* M, int nb, int B, 
         }
         const bool machine = !(P.small && B >= 2 && B <= SMA_N) && B > 1 && k > 1;
         if (!machine) {               // single problems and the one-workgroup sizes: one after the other
-            for (int b = 0; b < k && rc == 0; ++b)
-                rc = cfm_assign_exact_f32(pr[b].M, B, pr[b].perm, pr[b].certified, pr[b].total_cost, pr[b].stats, ws, stream);
+            for (int b = 0; b < k && rc == 0; ++b) {
+                if (P.small && B >= 2 && B <= SMA_N || B <= 1)
+                    rc = cfm_assign_exact_f32(pr[b].M, B, pr[b].perm, pr[b].certified, pr[b].total_cost, pr[b].stats, ws, stream);
+                else
+                    rc = asg_solve_one(pr[b], B, ws, stream, P, P.sparse);      // the chip-wide machine on the throughput grid
+            }
             continue;
         }
         rc = asg_run(pr, k, B, ws, stride, stream, P, P.sparse, cert, err);
