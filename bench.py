@@ -635,6 +635,14 @@ def main():
         lib_.cfm_assign_set_wide_blocks(int(os.environ["CFM_ASG_BLOCKS"]))
     if os.environ.get("CFM_ASG_ARR"):        # experiment knob: number of epsilon = 0 rounds
         lib_.cfm_assign_set_params(0, 0, 0, -1, 0, int(os.environ["CFM_ASG_ARR"]), 0)
+    if os.environ.get("CFM_ASG_STOP_EARLY"): # experiment knob: phase cut of every epsilon phase but the last
+        lib_.cfm_assign_set_stop_early(float(os.environ["CFM_ASG_STOP_EARLY"]))
+    if os.environ.get("CFM_ASG_EPS_LAST"):   # experiment knob: last epsilon as a fraction of the cost range
+        lib_.cfm_assign_set_params(0, 0, float(os.environ["CFM_ASG_EPS_LAST"]), -1, 0, -1, 0)
+    if os.environ.get("CFM_ASG_THETA"):      # experiment knob: epsilon scaling factor
+        lib_.cfm_assign_set_params(float(os.environ["CFM_ASG_THETA"]), 0, 0, -1, 0, -1, 0)
+    if os.environ.get("CFM_ASG_BULK"):       # experiment knob: launches enqueued before the first poll
+        lib_.cfm_assign_set_bulk(int(os.environ["CFM_ASG_BULK"]), 1024)
     if os.environ.get("CFM_ASG_DENSE"):      # experiment knob: no candidate-list solver
         lib_.cfm_assign_set_mode(0)
     if not torch.cuda.is_available():
