@@ -417,7 +417,9 @@ __device__ __forceinline__ int asg_key_row(unsigned long long key, int rb) {
 }
 
 // --------------------------------------------------------- wide: auction -----
+#ifndef WT
 #define WT 1024   // threads of the wide kernels (16 waves)
+#endif
 #define WIDE_PLDS_MAX 8192   // prices are staged into LDS for the bid rounds up to this n
 // One wave per bidding row.  r_k = c_ik + p_k (fp64).  Top-2 over the row.
 struct Top2 { double b; double s; int j; };
@@ -1351,14 +1353,15 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
     // Every launch starts cold: what a bid round needs first — the state block, all keys (they go to
     // LDS as prices + owner rows) and the last bid of the wave's row — is requested together.
     const bool stage_p = (n_host <= WIDE_PLDS_MAX);
-    ulonglong2 kst0, kst1, kst2, kst3;     // WIDE_PLDS_MAX / (2 * WT) = 4 key pairs per thread
+    constexpr int KP = WIDE_PLDS_MAX / (2 * WT);      // key pairs per thread (4 at 1024 threads)
+    ulonglong2 kst[KP];
     {
-        const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
         const int nn = stage_p ? n_host : 0;
-        kst0 = *reinterpret_cast<const ulonglong2*>(w.key + (j0 < nn ? j0 : 0));
-        kst1 = *reinterpret_cast<const ulonglong2*>(w.key + (j1 < nn ? j1 : 0));
-        kst2 = *reinterpret_cast<const ulonglong2*>(w.key + (j2 < nn ? j2 : 0));
-        kst3 = *reinterpret_cast<const ulonglong2*>(w.key + (j3 < nn ? j3 : 0));
+#pragma unroll
+        for (int q = 0; q < KP; ++q) {
+            const int j = threadIdx.x * 2 + 2 * WT * q;
+            kst[q] = *reinterpret_cast<const ulonglong2*>(w.key + (j < nn ? j : 0));
+        }
     }
     // (a grid smaller than one wave per row — batches, n > 8192 — gives a wave several rows: their last bids are requested
     //  together, or every further row would add a dependent round trip to the round)
@@ -1375,7 +1378,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
     if (w.cl != nullptr && wave_gid < n_host) { pre_e = w.cl[(size_t)wave_gid * ASG_BL + lane]; pre_T = w.cT[wave_gid]; }
     int mode = st->mode;
     gfp M = ASG_GLOBAL(st->Mptr);
-    asm volatile("" : "+v"(pre_bc), "+v"(pre_bc1), "+v"(pre_bc2), "+v"(pre_bc3), "+v"(my_bc), "+v"(pre_e.x), "+v"(pre_T), "+v"(kst0.x), "+v"(kst1.x), "+v"(kst2.x), "+v"(kst3.x) : "s"(mode) : "memory");   // all of it in flight
+    asm volatile("" : "+v"(pre_bc), "+v"(pre_bc1), "+v"(pre_bc2), "+v"(pre_bc3), "+v"(my_bc), "+v"(pre_e.x), "+v"(pre_T), "+v"(kst[0].x), "+v"(kst[KP - 1].x) : "s"(mode) : "memory");   // all of it in flight
     if (mode > MODE_CERT || st->error) return;
     const int n = n_host;
     unsigned payload = 0;
@@ -1416,16 +1419,13 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
         if (threadIdx.x == 0) { sh[0] = 0; sh[1] = 0; }
         if (stage_p) {
             const int mb = rb + ASG_RND_BITS;
-            const int j0 = threadIdx.x * 2, j1 = j0 + 2 * WT, j2 = j0 + 4 * WT, j3 = j0 + 6 * WT;
             // (a pair may straddle n when n is odd: the arrays are padded by one element)
-            if (j0 < n) { *reinterpret_cast<double2*>(p_lds + j0) = make_double2(asg_price(kst0.x, mb), asg_price(kst0.y, mb));
-                          *reinterpret_cast<int2*>(r_lds + j0) = make_int2(asg_key_row(kst0.x, rb), asg_key_row(kst0.y, rb)); }
-            if (j1 < n) { *reinterpret_cast<double2*>(p_lds + j1) = make_double2(asg_price(kst1.x, mb), asg_price(kst1.y, mb));
-                          *reinterpret_cast<int2*>(r_lds + j1) = make_int2(asg_key_row(kst1.x, rb), asg_key_row(kst1.y, rb)); }
-            if (j2 < n) { *reinterpret_cast<double2*>(p_lds + j2) = make_double2(asg_price(kst2.x, mb), asg_price(kst2.y, mb));
-                          *reinterpret_cast<int2*>(r_lds + j2) = make_int2(asg_key_row(kst2.x, rb), asg_key_row(kst2.y, rb)); }
-            if (j3 < n) { *reinterpret_cast<double2*>(p_lds + j3) = make_double2(asg_price(kst3.x, mb), asg_price(kst3.y, mb));
-                          *reinterpret_cast<int2*>(r_lds + j3) = make_int2(asg_key_row(kst3.x, rb), asg_key_row(kst3.y, rb)); }
+#pragma unroll
+            for (int q = 0; q < KP; ++q) {
+                const int j = threadIdx.x * 2 + 2 * WT * q;
+                if (j < n) { *reinterpret_cast<double2*>(p_lds + j) = make_double2(asg_price(kst[q].x, mb), asg_price(kst[q].y, mb));
+                             *reinterpret_cast<int2*>(r_lds + j) = make_int2(asg_key_row(kst[q].x, rb), asg_key_row(kst[q].y, rb)); }
+            }
         }
         __syncthreads();
         __shared__ int bq[ASG_BQ];
