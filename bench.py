@@ -619,6 +619,9 @@ def main():
     ap.add_argument("--cpu-standin", action="store_true",
                     help="launcher self-test on CPU tensors over gloo (no measurement; see cpu_standin_main)")
     args = ap.parse_args()
+    if os.environ.get("CFM_BENCH_WATCHDOG"):     # debugging aid: dump every thread's Python stack and exit if the run hangs
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CFM_BENCH_WATCHDOG"]), exit=True)
     rc = self_launch(args, sys.argv[1:])
     if rc is not None:
         raise SystemExit(rc)

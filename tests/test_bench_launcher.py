@@ -70,18 +70,44 @@ def test_gpus_2_on_a_one_gpu_box_fails_loudly():
     assert p.returncode != 0 and "GPU(s) visible" in p.stderr
 
 
+def _run_group(cmd, env, timeout):
+    """Run `cmd` in its own process group; on a timeout the WHOLE group (launcher, torchrun agent, ranks) is killed, so a
+    hung rank cannot linger on the GPU under the tests that follow.  Returns (returncode or None, stdout, stderr)."""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT,
+                         start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+        return p.returncode, out, err
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = p.communicate()
+        return None, out, err
+
+
 @pytest.mark.gpu
 def test_two_ranks_sharing_the_gpu_run_the_real_loop():
     """The N > 1 code path with the real HIP kernels on a one-GPU box: two ranks on the same device, collectives over
     gloo (CFM_BENCH_SHARE_GPU + CFM_DIST_BACKEND): per-rank pools, grouped prefetch workers, the fused regression step
-    with its gradient all-reduce, the all-gather of the final samples, max-over-ranks timing, ONE line from rank 0 —
-    marked invalid as a measurement."""
-    env = dict(os.environ, CFM_BENCH_SHARE_GPU="1", CFM_DIST_BACKEND="gloo")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4",
-                        "--batch", "1024", "--no-legs", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=600, env=env)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    with its bucketed gradient all-reduce, the all-gather of the final samples, max-over-ranks timing, ONE line from
+    rank 0 — marked invalid as a measurement.  The run takes ~10 s; a watchdog inside bench.py (CFM_BENCH_WATCHDOG)
+    dumps every thread's stack and exits should a rank hang, the whole process group is killed on a timeout, and one
+    retry is allowed: two processes x (1 + 3) threads oversubscribing ONE device over gloo is not a configuration the
+    product runs in, and one run in a few dozen has been seen to stall on a fresh box."""
+    env = dict(os.environ, CFM_BENCH_SHARE_GPU="1", CFM_DIST_BACKEND="gloo", CFM_BENCH_WATCHDOG="150")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4",
+           "--batch", "1024", "--no-legs", "--no-cpu-baseline"]
+    last = None
+    for attempt in range(2):
+        rc, out, err = _run_group(cmd, env, timeout=240)
+        last = (rc, err[-3000:])
+        if rc == 0:
+            break
+    assert last[0] == 0, last
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["valid"] is False and d["value"] > 0
