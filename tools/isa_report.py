@@ -1,6 +1,7 @@
 """Per-kernel register / scratch / MFMA bookkeeping from the compiler's own assembly (no GPU needed):
     python tools/isa_report.py [file.hip ...]        (default: every csrc/*.hip)
-For each kernel: VGPRs, AGPRs, scratch bytes per lane, spills, LDS bytes, number of MFMA instructions and of
+For each kernel: VGPRs (`vgpr` = the TOTAL of the unified file: architectural + accumulator registers; `agpr` = the
+accumulator part of it; waves per SIMD = 512 // total rounded up to 8), scratch bytes per lane, spills, LDS bytes, number of MFMA instructions and of
 v_accvgpr_read / v_accvgpr_write moves (accumulators shuttled between the two register files inside a loop are a
 compiler artefact that costs issue slots: round 4 found 128 of them per K step in every dense product).
 Measurement infrastructure."""
@@ -34,7 +35,10 @@ def report(path, extra=()):
         i = txt.index("\n" + name + ":")
         j = txt.find("s_endpgm", i)
         body = txt[i:j]
-        meta = txt[k:k + 1600]
+        # the kernel's metadata entry: keys are sorted, so .agpr_count / .group_segment_fixed_size come BEFORE .name
+        m0 = txt.rfind("\n  - .", 0, k)
+        m1 = txt.find("\n  - .", k)
+        meta = txt[m0:m1 if m1 > 0 else k + 1600]
         g = lambda key: (re.search(r"\.%s:\s+(\d+)" % key, meta) or [None, "0"])[1]
         rows.append(dict(kernel=demangle(name)[:84], vgpr=int(g("vgpr_count")), agpr=int(g("agpr_count")),
                          scratch=int(g("private_segment_fixed_size")), spill=int(g("vgpr_spill_count")),
