@@ -748,6 +748,19 @@ def main():
         assert gathered is None or gathered.shape[0] == world * B
         regions.append(el)
     elapsed = float(np.median(regions))
+    # the same loop over a region ten times as long (N = 1): what a step costs once the empty pipeline's fill and its
+    # drain (a first coupling nothing overlaps: ~2.6 ms of a 20-step region) are amortised.  Reported next to `value`,
+    # never instead of it.
+    steady = None
+    if pre is not None and world == 1 and not args.no_legs:
+        ks = 10 * args.steps
+        long_regions = [timed_region(D, torch.cuda.synchronize, pool, args.warmup, ks, couple, model_step, draw, pre,
+                                     args.pipeline, dev, args.group, couple_group, ramp)[0] for _ in range(3)]
+        el = float(np.median(long_regions))
+        steady = {"steps": ks, "repeats": 3, "ms_per_step": el / ks * 1e3, "value": B * ks / el,
+                  "ms_per_step_all": [round(r / ks * 1e3, 4) for r in long_regions],
+                  "note": "same schedule, region of 10 x K steps (fill + drain of the pipeline amortised); "
+                          "`value` is the K-step region"}
     if pre is not None:
         pre.close()
     if main_stream is not None:
@@ -799,6 +812,7 @@ def main():
         "value_sequential": (B / seq_s) if seq_s else None,
         "ms_per_step_sequential": seq_s * 1e3 if seq_s else None,
         "ms_per_step_sequential_all": [round(x * 1e3, 4) for x in seq_all],
+        "steady_state": steady,
     }
     if world == 1 and not args.no_legs:
         with torch.cuda.stream(torch.cuda.Stream()):
