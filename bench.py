@@ -75,7 +75,25 @@ def synth_batches(B, d, n, seed, dev):
 
 
 # --------------------------------------------------------------------------- the timed loop
-def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, depth=0, group=1, couple_group=None, ramp=()):
+def job_sizes(count, group, ramp=(), tail=()):
+    """Sizes of the prefetch jobs that cover `count` steps: `ramp` first, `tail` last (dropped from its front when the
+    steps do not suffice), `group` in between (the job before the tail takes what is left)."""
+    sizes, left = [], count
+    for k in ramp:
+        if left <= 0:
+            break
+        sizes.append(min(k, left)); left -= sizes[-1]
+    tail = list(tail)
+    while tail and sum(tail) > left:
+        tail.pop(0)
+    mid = left - sum(tail)
+    while mid > 0:
+        sizes.append(min(group, mid)); mid -= sizes[-1]
+    return sizes + tail
+
+
+def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, depth=0, group=1, couple_group=None, ramp=(),
+              tail=()):
     """`count` steps starting at pool index `first`: every step = one coupling + one model update,
     all of them inside this call (a prefetch pipeline starts empty and is drained).  Returns the
     last (t, xt, ut).  Device agnostic: `couple(x0, x1, drawn)` and `model_step(t, xt, ut)` are the
@@ -83,7 +101,9 @@ def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, dep
     group > 1: the couplings of `group` consecutive minibatches are one prefetch job
     (`couple_group(batches, drawn_list)` -> one result per minibatch), `depth` such jobs in flight.
     ramp: group sizes of the FIRST jobs (then `group`): the pipeline starts empty inside the timed call, and the first
-    model step cannot start before the first job is back — a small first job shortens that fill."""
+    model step cannot start before the first job is back — a small first job shortens that fill.
+    tail: group sizes of the LAST jobs: the pipeline is drained inside the call too, and while the last job's chain of
+    launches runs nothing is left to overlap with it — small last jobs shorten that drain."""
     last = None
     if not depth or prefetcher is None:
         for k in range(count):
@@ -93,11 +113,11 @@ def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, dep
         return last
     inflight, submitted = collections.deque(), 0
     if group > 1 and couple_group is not None:
-        njobs = 0
+        njobs, plan = 0, job_sizes(count, group, ramp, tail)
 
         def submit_next():
             nonlocal submitted, njobs
-            k = min(ramp[njobs] if njobs < len(ramp) else group, count - submitted)
+            k = plan[njobs]
             njobs += 1
             batches = [pool[(first + submitted + q) % len(pool)] for q in range(k)]
             inflight.append(prefetcher.submit_group(batches, couple_group, draw)); submitted += k
@@ -121,13 +141,13 @@ def run_steps(pool, first, count, couple, model_step, draw, prefetcher=None, dep
 
 
 def timed_region(D, sync, pool, warmup, steps, couple, model_step, draw, prefetcher, depth, device=None, group=1,
-                 couple_group=None, ramp=()):
+                 couple_group=None, ramp=(), tail=()):
     """Warm-up, barrier + sync, K steps + ONE all-gather of the final samples, sync + barrier; the
     MAX over ranks of the elapsed time.  Returns (elapsed_s, gathered_final_xt)."""
-    run_steps(pool, 0, warmup, couple, model_step, draw, prefetcher, depth, group, couple_group, ramp)
+    run_steps(pool, 0, warmup, couple, model_step, draw, prefetcher, depth, group, couple_group, ramp, tail)
     D.barrier(); sync()
     t0 = time.perf_counter()
-    last = run_steps(pool, warmup, steps, couple, model_step, draw, prefetcher, depth, group, couple_group, ramp)
+    last = run_steps(pool, warmup, steps, couple, model_step, draw, prefetcher, depth, group, couple_group, ramp, tail)
     gathered = D.all_gather_samples(last[1]) if last is not None else None
     sync(); D.barrier()
     return D.max_over_ranks(time.perf_counter() - t0, device), gathered
@@ -602,6 +622,9 @@ def main():
     ap.add_argument("--ramp", default=os.environ.get("CFM_BENCH_RAMP", "1"),
                     help="comma-separated group sizes of the FIRST prefetch jobs of a run (then --group): the pipeline starts "
                          "empty inside the timed region, a small first job lets the first model step start sooner")
+    ap.add_argument("--tail", default=os.environ.get("CFM_BENCH_TAIL", "2,1"),
+                    help="comma-separated group sizes of the LAST prefetch jobs of a run: the pipeline is drained inside the "
+                         "timed region, small last jobs shorten the stretch in which nothing overlaps with the last chain")
     ap.add_argument("--model-step", default="fused", choices=["fused", "eager"],
                     help="fused: cfm_amd.RegressionStep (one C call: forward + MSE + backward, then the one-launch Adam); "
                          "eager: the reference's four lines on the autograd.Function path")
@@ -719,6 +742,7 @@ def main():
 
     pre = None
     ramp = tuple(int(x) for x in args.ramp.split(",") if x.strip()) if (args.pipeline and args.group > 1) else ()
+    tail = tuple(int(x) for x in args.tail.split(",") if x.strip()) if (args.pipeline and args.group > 1) else ()
     part, main_stream = None, None
     if args.pipeline and args.partition > 0:
         from cfm_amd.streams import ChipPartition
@@ -731,7 +755,7 @@ def main():
         # one-time costs per worker thread (stream, workspaces, the solver's captured launch programs for each job shape
         # the loops are going to submit) are paid before the warm-up steps, on every worker
         rs_np, rs_t = np.random.get_state(), torch.get_rng_state()
-        shapes = ({args.group} | set(ramp) | set(range(1, args.group))) if args.group > 1 else {1}
+        shapes = ({args.group} | set(ramp) | set(tail) | set(range(1, args.group))) if args.group > 1 else {1}
         for k in sorted(shapes - {0}, reverse=True):
             if args.group > 1:
                 pre.prime(lambda k=k: couple_group([pool[q % len(pool)] for q in range(k)], [draw() for _ in range(k)]))
@@ -744,7 +768,7 @@ def main():
     regions = []
     for _ in range(max(1, args.repeats)):
         el, gathered = timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple, model_step,
-                                    draw, pre, args.pipeline, dev, args.group, couple_group, ramp)
+                                    draw, pre, args.pipeline, dev, args.group, couple_group, ramp, tail)
         assert gathered is None or gathered.shape[0] == world * B
         regions.append(el)
     elapsed = float(np.median(regions))
@@ -755,7 +779,7 @@ def main():
     if pre is not None and world == 1 and not args.no_legs:
         ks = 10 * args.steps
         long_regions = [timed_region(D, torch.cuda.synchronize, pool, args.warmup, ks, couple, model_step, draw, pre,
-                                     args.pipeline, dev, args.group, couple_group, ramp)[0] for _ in range(3)]
+                                     args.pipeline, dev, args.group, couple_group, ramp, tail)[0] for _ in range(3)]
         el = float(np.median(long_regions))
         steady = {"steps": ks, "repeats": 3, "ms_per_step": el / ks * 1e3, "value": B * ks / el,
                   "ms_per_step_all": [round(r / ks * 1e3, 4) for r in long_regions],
@@ -801,7 +825,8 @@ def main():
                                     "cfm_assign_exact_batch_f32)" if args.group > 1 else ""))
                                 if args.pipeline else "sequential"),
                    "prefetch_jobs": args.pipeline, "prefetch_group": args.group if args.pipeline else 0,
-                   "prefetch_ramp": list(ramp),
+                   "prefetch_ramp": list(ramp), "prefetch_tail": list(tail),
+                   "prefetch_job_sizes": job_sizes(args.steps, args.group, ramp, tail) if (args.pipeline and args.group > 1) else None,
                    "chip_partition": ({"solver_cus": part.solver_cus, "dense_cus": part.dense_cus,
                                        "note": "CU-masked streams: the exact solver's launches on solver_cus, cost matrix "
                                                "/ sampling / model step on dense_cus"} if part is not None else None),

@@ -92,3 +92,17 @@ def test_ramped_first_jobs_keep_order_and_results():
     pre.close()
     assert log["stepped"] == seq
     assert log["groups"] == [1, 2, 4, 4, 1]
+
+
+def test_job_sizes_cover_the_steps_with_ramp_and_tail():
+    """bench.job_sizes: ramp first, tail last (dropped from its front when the steps do not suffice), `group` between."""
+    import bench
+    assert bench.job_sizes(20, 4, (1,), ()) == [1, 4, 4, 4, 4, 3]
+    assert bench.job_sizes(20, 4, (1,), (2, 1)) == [1, 4, 4, 4, 4, 2, 1]
+    assert bench.job_sizes(20, 4, (1, 2), (2, 1)) == [1, 2, 4, 4, 4, 2, 2, 1]
+    assert bench.job_sizes(20, 4) == [4] * 5
+    for count in range(1, 30):
+        for ramp in ((), (1,), (1, 3), (4,)):
+            for tail in ((), (1,), (2, 1), (3, 3)):
+                s = bench.job_sizes(count, 4, ramp, tail)
+                assert sum(s) == count and all(1 <= k <= 4 for k in s), (count, ramp, tail, s)
