@@ -1,0 +1,169 @@
+// Measurement aid (not part of the library; starting point of the next round): where does the direct-to-LDS fp32-MFMA
+// engine (csrc/gemm_glds.h) spend the 30 % of the matrix pipe it leaves idle at 110 TFLOP/s?
+//
+// Round 4 priced the pieces by leaving them out (no loads: +13 %; no LDS stores: +8.5 %; fragment reads, barrier: free)
+// and found both engines on the same plateau.  What was never measured: (a) what the memory path ALONE delivers for the
+// engine's access pattern (DMA + waits, no MFMA), (b) where a wave actually waits — for its DMAs (s_waitcnt vmcnt) or
+// for the slowest wave of its workgroup (s_barrier), (c) whether a deeper pipeline (3 / 4 stages in LDS, one workgroup
+// per CU) hides what two stages do not.  This program answers the three in one run (~10 s):
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/probe/glds_probe.hip -o tools/probe/glds_probe
+//   tools/probe/glds_probe [M N K]          (default 4096 4096 3136: the asymptotic shape of profiles/r4_gemm_probes.txt)
+//
+// Per variant: time, TFLOP/s, and (instrumented builds) the share of a wave's lifetime spent in the vmcnt wait and in the
+// barrier, from s_memtime around them.  MODE 0 results are checked against a float64 host product on sampled entries.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../conditional-flow-matching_amd/csrc/gemm_glds.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__device__ __forceinline__ unsigned long long pr_clk() { return __builtin_readcyclecounter(); }
+
+template <int NST> __device__ __forceinline__ void pr_wait_vm(bool later_stages_in_flight) {
+    // DMAs complete in order: with NST - 2 younger stages (8 DMAs per wave each) behind the one needed, vmcnt may stay
+    // at 8 (NST - 2); in the tail (no younger stage issued) everything outstanding is needed
+    if (NST == 2 || !later_stages_in_flight) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (NST == 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+}
+
+// MODE 0: the product loop     1: DMA + waits only (no MFMA, no fragment reads)     2: no DMA inside the loop
+template <int MODE, int NST, int WPC, bool STATS>
+__global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__ A, const float* __restrict__ B, int M, int N,
+                                                      int K, const float* __restrict__ zeros, float* __restrict__ C,
+                                                      unsigned long long* __restrict__ stats, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    {   // the 8 x 8 super-tile order of cost_gemm
+        const int G = 8;
+        const int per_band = G * tiles_n;
+        const int band = lid / per_band, r = lid - band * per_band;
+        const int rows_in_band = min(G, tiles_m - band * G);
+        const int fgt = rows_in_band * G;
+        const int gcol = r / fgt;
+        const int rr = r - gcol * fgt;
+        const int cols_in_group = min(G, tiles_n - gcol * G);
+        tm = band * G + rr / cols_in_group;
+        tn = gcol * G + rr % cols_in_group;
+    }
+    const int row0 = tm * GL_BM, col0 = tn * GL_BN;
+    GldsCore g;
+    g.zero();
+    g.bind(A, K, row0, M, B, K, col0, N);
+    unsigned long long t_vm = 0, t_bar = 0, t_start = 0;
+    if (STATS) t_start = pr_clk();
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s * GL_BK < K) g.issue(lds, s, s * GL_BK, K, zeros);
+    int st = 0, nx = NST - 1;                       // stage being consumed, stage buffer the next DMA goes to
+    for (int k0 = 0; k0 < K; k0 += GL_BK) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if (STATS) t0 = pr_clk();
+        pr_wait_vm<NST>(k0 + (NST - 2) * GL_BK < K && NST > 2);
+        if (STATS) t1 = pr_clk();
+        asm volatile("s_barrier" ::: "memory");
+        if (STATS) { t2 = pr_clk(); t_vm += t1 - t0; t_bar += t2 - t1; }
+        if (MODE != 2 && k0 + (NST - 1) * GL_BK < K) g.issue(lds, nx, k0 + (NST - 1) * GL_BK, K, zeros);
+        if (MODE != 1) g.compute(lds, st);
+        st = st + 1 == NST ? 0 : st + 1;
+        nx = nx + 1 == NST ? 0 : nx + 1;
+    }
+    if (STATS) {
+        const unsigned long long t_all = pr_clk() - t_start;
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* s = stats + 4 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+            s[0] = t_all; s[1] = t_vm; s[2] = t_bar; s[3] = 0;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = row0 + GldsCore::row_of(m, r);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gc = col0 + GldsCore::col_of(u);
+                if (gr < M && gc < N) C[(size_t)gr * N + gc] = g.acc[m][u][r];
+            }
+        }
+}
+
+struct Ctx { float *A, *B, *C, *zeros; unsigned long long* stats; int M, N, K, tm, tn; std::vector<float> hA, hB; };
+
+template <int MODE, int NST, int WPC, bool STATS>
+static int run(Ctx& c, const char* label, bool check) {
+    // one workgroup per CU is enforced through the LDS request (96 KiB of 160): registers alone would let two in
+    size_t ldsb = (size_t)NST * GL_STAGE_FLOATS * 4;
+    if (WPC == 1 && ldsb < 96 * 1024) ldsb = 96 * 1024;
+    auto kern = glds_probe<MODE, NST, WPC, STATS>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const int grid = c.tm * c.tn;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, 0, c.A, c.B, c.M, c.N, c.K, c.zeros, c.C, c.stats, c.tm, c.tn);
+    CK(hipDeviceSynchronize());
+    const int reps = 6;
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, 0, c.A, c.B, c.M, c.N, c.K, c.zeros, c.C, c.stats, c.tm, c.tn);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const double tf = 2.0 * c.M * c.N * c.K / (ms * 1e-3) / 1e12;
+    const double gb = (double)grid * (GL_BM + GL_BN) * c.K * 4.0 / 1e9;          // operand bytes the tiles request
+    printf("%-46s %8.1f us  %6.1f TFLOP/s (%4.1f %% of 157.3)  operand requests %5.2f TB/s", label, ms * 1e3, tf, tf / 1.573, gb / ms);
+    if (STATS) {
+        std::vector<unsigned long long> h((size_t)grid * 16);
+        CK(hipMemcpy(h.data(), c.stats, h.size() * 8, hipMemcpyDeviceToHost));
+        double all = 0, vm = 0, bar = 0;
+        for (size_t w = 0; w < (size_t)grid * 4; ++w) { all += h[4 * w]; vm += h[4 * w + 1]; bar += h[4 * w + 2]; }
+        printf("   wave lifetime %7.0f cycles: vmcnt wait %4.1f %%, barrier %4.1f %%", all / (grid * 4.0), 100 * vm / all, 100 * bar / all);
+    }
+    printf("\n");
+    if (check) {
+        std::vector<float> hC((size_t)c.M * c.N);
+        CK(hipMemcpy(hC.data(), c.C, hC.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int s = 0; s < 2048; ++s) {
+            const int i = (int)((s * 2654435761u) % (unsigned)c.M), j = (int)((s * 40503u + 17u) % (unsigned)c.N);
+            double ref = 0;
+            for (int k = 0; k < c.K; ++k) ref += (double)c.hA[(size_t)i * c.K + k] * (double)c.hB[(size_t)j * c.K + k];
+            const double err = fabs(ref - hC[(size_t)i * c.N + j]) / (fabs(ref) + 1.0);
+            if (err > worst) worst = err;
+        }
+        printf("    check (2048 sampled entries vs float64): worst relative error %.2e %s\n", worst, worst < 1e-4 ? "ok" : "WRONG");
+        if (!(worst < 1e-4)) return 2;
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    Ctx c;
+    c.M = argc > 3 ? atoi(argv[1]) : 4096; c.N = argc > 3 ? atoi(argv[2]) : 4096; c.K = argc > 3 ? atoi(argv[3]) : 3136;
+    if (c.K % 4) { printf("K must be a multiple of 4 (16-byte DMA pieces)\n"); return 1; }
+    c.tm = (c.M + GL_BM - 1) / GL_BM; c.tn = (c.N + GL_BN - 1) / GL_BN;
+    c.hA.resize((size_t)c.M * c.K); c.hB.resize((size_t)c.N * c.K);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& v : c.hA) v = rnd();
+    for (auto& v : c.hB) v = rnd();
+    CK(hipMalloc(&c.A, c.hA.size() * 4)); CK(hipMalloc(&c.B, c.hB.size() * 4)); CK(hipMalloc(&c.C, (size_t)c.M * c.N * 4));
+    CK(hipMalloc(&c.zeros, 256)); CK(hipMemset(c.zeros, 0, 256));
+    CK(hipMalloc(&c.stats, (size_t)c.tm * c.tn * 16 * 8));
+    CK(hipMemcpy(c.A, c.hA.data(), c.hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(c.B, c.hB.data(), c.hB.size() * 4, hipMemcpyHostToDevice));
+    printf("glds_probe: C[%d x %d] = A[%d x %d] . B[%d x %d]^T, %d tiles of 128 x 128, K steps of %d\n", c.M, c.N, c.M, c.K, c.N, c.K, c.tm * c.tn, GL_BK);
+    int rc = 0;
+    rc |= run<0, 2, 2, false>(c, "product loop, 2 stages, 2 workgroups / CU", true);
+    rc |= run<0, 2, 2, true>(c, "  the same, instrumented", false);
+    rc |= run<1, 2, 2, true>(c, "DMA + waits only (no MFMA), 2 stages, 2 / CU", false);
+    rc |= run<2, 2, 2, true>(c, "no DMA in the loop (MFMA + LDS reads only)", false);
+    rc |= run<0, 2, 1, true>(c, "product loop, 2 stages, 1 workgroup / CU", false);
+    rc |= run<0, 3, 1, false>(c, "product loop, 3 stages, 1 workgroup / CU", true);
+    rc |= run<0, 3, 1, true>(c, "  the same, instrumented", false);
+    rc |= run<1, 3, 1, true>(c, "DMA + waits only, 3 stages, 1 / CU", false);
+    rc |= run<0, 4, 1, false>(c, "product loop, 4 stages, 1 workgroup / CU", true);
+    rc |= run<0, 4, 1, true>(c, "  the same, instrumented", false);
+    return rc;
+}
