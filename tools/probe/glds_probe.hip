@@ -16,11 +16,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 #include "../../conditional-flow-matching_amd/csrc/gemm_glds.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-__device__ __forceinline__ unsigned long long pr_clk() { return __builtin_readcyclecounter(); }
+__device__ __forceinline__ unsigned long long pr_clk() { return __builtin_readcyclecounter(); }      // s_memtime
+__device__ __forceinline__ unsigned long long pr_rt() { return wall_clock64(); }                     // s_memrealtime: 100 MHz
 
 template <int NST> __device__ __forceinline__ void pr_wait_vm(bool later_stages_in_flight) {
     // DMAs complete in order: with NST - 2 younger stages (8 DMAs per wave each) behind the one needed, vmcnt may stay
@@ -54,8 +56,8 @@ __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__
     GldsCore g;
     g.zero();
     g.bind(A, K, row0, M, B, K, col0, N);
-    unsigned long long t_vm = 0, t_bar = 0, t_start = 0;
-    if (STATS) t_start = pr_clk();
+    unsigned long long t_vm = 0, t_bar = 0, t_start = 0, r_start = 0;
+    if (STATS) { t_start = pr_clk(); r_start = pr_rt(); }
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
         if (s * GL_BK < K) g.issue(lds, s, s * GL_BK, K, zeros);
@@ -73,10 +75,10 @@ __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__
         nx = nx + 1 == NST ? 0 : nx + 1;
     }
     if (STATS) {
-        const unsigned long long t_all = pr_clk() - t_start;
+        const unsigned long long t_all = pr_clk() - t_start, r_all = pr_rt() - r_start;
         if ((threadIdx.x & 63) == 0) {
-            unsigned long long* s = stats + 4 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
-            s[0] = t_all; s[1] = t_vm; s[2] = t_bar; s[3] = 0;
+            unsigned long long* s = stats + 8 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+            s[0] = t_all; s[1] = t_vm; s[2] = t_bar; s[3] = r_all; s[4] = r_start; s[5] = r_start + r_all;
         }
     }
 #pragma unroll
@@ -90,6 +92,32 @@ __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__
                 if (gr < M && gc < N) C[(size_t)gr * N + gc] = g.acc[m][u][r];
             }
         }
+}
+
+// the matrix pipe alone (registers only), operands constant (what tools/probe/mfma_peak measures) or changing from one
+// MFMA to the next (16 different register pairs per lane): does the sustained rate depend on the data?
+template <bool VARY>
+__global__ __launch_bounds__(256) void mfma_only(float* out, int iters, const float* __restrict__ src, unsigned long long* stats) {
+    gl_f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    float x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { x[u] = src[(threadIdx.x * 16 + 2 * u) & 4095]; y[u] = src[(threadIdx.x * 16 + 2 * u + 1) & 4095]; }
+    const unsigned long long t0 = pr_clk(), r0 = pr_rt();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float p = VARY ? x[u] : x[0], q = VARY ? y[u] : y[0];
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, q, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q, p, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, p, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(q, q, a3, 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = pr_clk() - t0, r1 = pr_rt() - r0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = t1; stats[1] = r1; }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    if (s == 12345.678f) out[0] = s;
 }
 
 struct Ctx { float *A, *B, *C, *zeros; unsigned long long* stats; int M, N, K, tm, tn; std::vector<float> hA, hB; };
@@ -114,11 +142,31 @@ static int run(Ctx& c, const char* label, bool check) {
     const double gb = (double)grid * (GL_BM + GL_BN) * c.K * 4.0 / 1e9;          // operand bytes the tiles request
     printf("%-46s %8.1f us  %6.1f TFLOP/s (%4.1f %% of 157.3)  operand requests %5.2f TB/s", label, ms * 1e3, tf, tf / 1.573, gb / ms);
     if (STATS) {
-        std::vector<unsigned long long> h((size_t)grid * 16);
+        std::vector<unsigned long long> h((size_t)grid * 32);
         CK(hipMemcpy(h.data(), c.stats, h.size() * 8, hipMemcpyDeviceToHost));
-        double all = 0, vm = 0, bar = 0;
-        for (size_t w = 0; w < (size_t)grid * 4; ++w) { all += h[4 * w]; vm += h[4 * w + 1]; bar += h[4 * w + 2]; }
-        printf("   wave lifetime %7.0f cycles: vmcnt wait %4.1f %%, barrier %4.1f %%", all / (grid * 4.0), 100 * vm / all, 100 * bar / all);
+        double all = 0, vm = 0, bar = 0, rt = 0;
+        unsigned long long first = ~0ull, last = 0;
+        std::vector<double> life, start, end;
+        for (size_t w = 0; w < (size_t)grid * 4; ++w) {
+            const unsigned long long* q = &h[8 * w];
+            all += q[0]; vm += q[1]; bar += q[2]; rt += q[3];
+            if (q[4] < first) first = q[4];
+            if (q[5] > last) last = q[5];
+        }
+        for (size_t w = 0; w < (size_t)grid * 4; w += 4) {      // wave 0 of every workgroup
+            const unsigned long long* q = &h[8 * w];
+            life.push_back(q[3] * 0.01); start.push_back((q[4] - first) * 0.01); end.push_back((q[5] - first) * 0.01);
+        }
+        std::sort(life.begin(), life.end()); std::sort(start.begin(), start.end()); std::sort(end.begin(), end.end());
+        const double span = (last - first) * 0.01;
+        printf("   wave lifetime %7.0f s_memtime ticks = %6.1f us (s_memtime runs at %5.3f GHz): vmcnt wait %4.1f %%, barrier %4.1f %%\n",
+               all / (grid * 4.0), rt / (grid * 4.0) * 0.01, all / (rt * 10.0), 100 * vm / all, 100 * bar / all);
+        auto pc = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+        printf("      K loops span %7.1f us of the %7.1f us launch; lifetimes min / 10 %% / median / 90 %% / max: %.0f / %.0f / %.0f / %.0f / %.0f us;"
+               " mean K loops alive %.0f of %d slots\n", span, ms * 1e3, life.front(), pc(life, .1), pc(life, .5), pc(life, .9), life.back(),
+               rt * 0.01 / 4.0 / span, WPC * 256);
+        printf("      K-loop starts at 25 / 50 / 51 / 75 / 100 %% of the workgroups: %.0f / %.0f / %.0f / %.0f / %.0f us;  ends at 25 / 50 / 75 / 100 %%: %.0f / %.0f / %.0f / %.0f us",
+               pc(start, .25), pc(start, .5), pc(start, .51), pc(start, .75), start.back(), pc(end, .25), pc(end, .5), pc(end, .75), end.back());
     }
     printf("\n");
     if (check) {
@@ -150,7 +198,7 @@ int main(int argc, char** argv) {
     for (auto& v : c.hB) v = rnd();
     CK(hipMalloc(&c.A, c.hA.size() * 4)); CK(hipMalloc(&c.B, c.hB.size() * 4)); CK(hipMalloc(&c.C, (size_t)c.M * c.N * 4));
     CK(hipMalloc(&c.zeros, 256)); CK(hipMemset(c.zeros, 0, 256));
-    CK(hipMalloc(&c.stats, (size_t)c.tm * c.tn * 16 * 8));
+    CK(hipMalloc(&c.stats, (size_t)c.tm * c.tn * 32 * 8));
     CK(hipMemcpy(c.A, c.hA.data(), c.hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(c.B, c.hB.data(), c.hB.size() * 4, hipMemcpyHostToDevice));
     printf("glds_probe: C[%d x %d] = A[%d x %d] . B[%d x %d]^T, %d tiles of 128 x 128, K steps of %d\n", c.M, c.N, c.M, c.K, c.N, c.K, c.tm * c.tn, GL_BK);
@@ -165,5 +213,26 @@ int main(int argc, char** argv) {
     rc |= run<1, 3, 1, true>(c, "DMA + waits only, 3 stages, 1 / CU", false);
     rc |= run<0, 4, 1, false>(c, "product loop, 4 stages, 1 workgroup / CU", true);
     rc |= run<0, 4, 1, true>(c, "  the same, instrumented", false);
+    // the same product on operands that are all zero: if the rate depends on the DATA (power), this one is faster
+    CK(hipMemset(c.A, 0, c.hA.size() * 4)); CK(hipMemset(c.B, 0, c.hB.size() * 4));
+    rc |= run<0, 2, 2, true>(c, "product loop, 2 stages, 2 / CU, ALL-ZERO operands", false);
+    rc |= run<0, 2, 1, true>(c, "product loop, 2 stages, 1 / CU, ALL-ZERO operands", false);
+    CK(hipMemcpy(c.A, c.hA.data(), 4096 * 4, hipMemcpyHostToDevice));
+    for (int vary = 0; vary < 2; ++vary)
+        for (int wps = 1; wps <= 2; ++wps) {
+            const int iters = 16384, grid = 256 * wps;
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            auto launch = [&]() {
+                if (vary) hipLaunchKernelGGL(mfma_only<true>, dim3(grid), dim3(256), 0, 0, c.C, iters, c.A, c.stats);
+                else hipLaunchKernelGGL(mfma_only<false>, dim3(grid), dim3(256), 0, 0, c.C, iters, c.A, c.stats);
+            };
+            launch(); CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0)); launch(); launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 2;
+            unsigned long long h[2]; CK(hipMemcpy(h, c.stats, 16, hipMemcpyDeviceToHost));
+            const double tf = (double)grid * 4 * iters * 32.0 * 4096.0 / (ms * 1e-3) / 1e12;
+            printf("MFMA only, %s operands, %d wave(s) / SIMD: %8.2f ms  %6.1f TFLOP/s   s_memtime at %5.3f GHz\n",
+                   vary ? "16 different" : "constant    ", wps, ms, tf, h[0] / (h[1] * 10.0));
+        }
     return rc;
 }
