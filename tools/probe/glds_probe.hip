@@ -32,8 +32,43 @@ template <int NST> __device__ __forceinline__ void pr_wait_vm(bool later_stages_
     else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
 }
 
+// The DMAs as inline assembly in the SGPR-base + 32-bit-lane-offset form.  Two reasons (found with this probe, round 4):
+//   * the compiler treats __builtin_amdgcn_global_load_lds as a write to LDS that any later ds_read may alias and puts an
+//     s_waitcnt vmcnt(0) in front of the first fragment read of EVERY K step — i.e. behind the DMAs of the NEXT stage that
+//     were issued a moment earlier: the engine of gemm_glds.h never overlaps a stage's loads with its own MFMAs, only
+//     with those of the other workgroup on the CU.  Assembly DMAs are invisible to that pass; the explicit
+//     s_waitcnt vmcnt(n) + s_barrier at the top of the K step is the ordering.
+//   * per DMA the builtin path spends ~12 instructions (64-bit add, zero-row selects, v_readfirstlane + s_mov m0 of an LDS
+//     address that is wave uniform anyway); here a stage advances by ONE scalar add per operand.
+// Requires M, N multiples of 128 and K a multiple of 32 (no zero rows / k tail): a probe, not the product engine.
+struct FastDma {
+    unsigned offa[4], offb[4];          // byte offset of this lane's 16 bytes from the operand base, at k0 = 0
+    unsigned la[4], lb[4];              // LDS byte address of the wave's piece q inside stage 0 (wave uniform)
+    __device__ __forceinline__ void bind(int lda, int row0, int ldb, int col0, float* lds) {
+        const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 8 * (wv + 4 * q) + (lane >> 3);
+            const int kq = (lane & 7) ^ ((r >> 1) & 7);
+            offa[q] = (unsigned)(((size_t)(row0 + r) * lda + 4 * kq) * 4);
+            offb[q] = (unsigned)(((size_t)(col0 + r) * ldb + 4 * kq) * 4);
+            la[q] = base + (unsigned)((wv + 4 * q) * 256 * 4);
+            lb[q] = la[q] + GL_BM * GL_BK * 4;
+        }
+    }
+    static __device__ __forceinline__ void dma(unsigned off, const float* base, unsigned ldsaddr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(ldsaddr) : "memory");
+    }
+    __device__ __forceinline__ void issue(const float* Ak, const float* Bk, int st) const {
+        const unsigned so = (unsigned)st * (GL_STAGE_FLOATS * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dma(offa[q], Ak, la[q] + so); dma(offb[q], Bk, lb[q] + so); }
+    }
+};
+
 // MODE 0: the product loop     1: DMA + waits only (no MFMA, no fragment reads)     2: no DMA inside the loop
-template <int MODE, int NST, int WPC, bool STATS>
+template <int MODE, int NST, int WPC, bool STATS, bool FAST = false, bool FAIR = false>
 __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__ A, const float* __restrict__ B, int M, int N,
                                                       int K, const float* __restrict__ zeros, float* __restrict__ C,
                                                       unsigned long long* __restrict__ stats, int tiles_m, int tiles_n) {
@@ -55,12 +90,13 @@ __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__
     const int row0 = tm * GL_BM, col0 = tn * GL_BN;
     GldsCore g;
     g.zero();
-    g.bind(A, K, row0, M, B, K, col0, N);
+    FastDma fd;
+    if (FAST) fd.bind(K, row0, K, col0, lds); else g.bind(A, K, row0, M, B, K, col0, N);
     unsigned long long t_vm = 0, t_bar = 0, t_start = 0, r_start = 0;
     if (STATS) { t_start = pr_clk(); r_start = pr_rt(); }
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
-        if (s * GL_BK < K) g.issue(lds, s, s * GL_BK, K, zeros);
+        if (s * GL_BK < K) { if (FAST) fd.issue(A + s * GL_BK, B + s * GL_BK, s); else g.issue(lds, s, s * GL_BK, K, zeros); }
     int st = 0, nx = NST - 1;                       // stage being consumed, stage buffer the next DMA goes to
     for (int k0 = 0; k0 < K; k0 += GL_BK) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0;
@@ -69,7 +105,13 @@ __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__
         if (STATS) t1 = pr_clk();
         asm volatile("s_barrier" ::: "memory");
         if (STATS) { t2 = pr_clk(); t_vm += t1 - t0; t_bar += t2 - t1; }
-        if (MODE != 2 && k0 + (NST - 1) * GL_BK < K) g.issue(lds, nx, k0 + (NST - 1) * GL_BK, K, zeros);
+        if (FAIR) {         // the two workgroups of a CU take turns at the higher issue priority (see the timeline of the plain loop)
+            if (((blockIdx.x >> 8) ^ (unsigned)(k0 >> 5)) & 1u) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0");
+        }
+        if (MODE != 2 && k0 + (NST - 1) * GL_BK < K) {
+            const int kn = k0 + (NST - 1) * GL_BK;
+            if (FAST) fd.issue(A + kn, B + kn, nx); else g.issue(lds, nx, kn, K, zeros);
+        }
         if (MODE != 1) g.compute(lds, st);
         st = st + 1 == NST ? 0 : st + 1;
         nx = nx + 1 == NST ? 0 : nx + 1;
@@ -122,12 +164,13 @@ __global__ __launch_bounds__(256) void mfma_only(float* out, int iters, const fl
 
 struct Ctx { float *A, *B, *C, *zeros; unsigned long long* stats; int M, N, K, tm, tn; std::vector<float> hA, hB; };
 
-template <int MODE, int NST, int WPC, bool STATS>
+template <int MODE, int NST, int WPC, bool STATS, bool FAST = false, bool FAIR = false>
 static int run(Ctx& c, const char* label, bool check) {
     // one workgroup per CU is enforced through the LDS request (96 KiB of 160): registers alone would let two in
     size_t ldsb = (size_t)NST * GL_STAGE_FLOATS * 4;
     if (WPC == 1 && ldsb < 96 * 1024) ldsb = 96 * 1024;
-    auto kern = glds_probe<MODE, NST, WPC, STATS>;
+    auto kern = glds_probe<MODE, NST, WPC, STATS, FAST, FAIR>;
+    if (FAST && (c.M % GL_BM || c.N % GL_BN || c.K % GL_BK)) { printf("%s: skipped (M, N, K not multiples of the tile)\n", label); return 0; }
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     const int grid = c.tm * c.tn;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -205,17 +248,20 @@ int main(int argc, char** argv) {
     int rc = 0;
     rc |= run<0, 2, 2, false>(c, "product loop, 2 stages, 2 workgroups / CU", true);
     rc |= run<0, 2, 2, true>(c, "  the same, instrumented", false);
+    rc |= run<0, 2, 2, false, true>(c, "assembly DMAs, 2 stages, 2 / CU", true);
+    rc |= run<0, 2, 2, true, true>(c, "  the same, instrumented", false);
+    rc |= run<0, 2, 2, true, true, true>(c, "assembly DMAs + alternating s_setprio, 2 / CU", false);
+    rc |= run<0, 2, 2, true, false, true>(c, "builtin DMAs + alternating s_setprio, 2 / CU", false);
+    rc |= run<0, 2, 1, true, true>(c, "assembly DMAs, 2 stages, 1 / CU", false);
+    rc |= run<0, 3, 1, false, true>(c, "assembly DMAs, 3 stages, 1 / CU", true);
+    rc |= run<0, 3, 1, true, true>(c, "  the same, instrumented", false);
     rc |= run<1, 2, 2, true>(c, "DMA + waits only (no MFMA), 2 stages, 2 / CU", false);
     rc |= run<2, 2, 2, true>(c, "no DMA in the loop (MFMA + LDS reads only)", false);
     rc |= run<0, 2, 1, true>(c, "product loop, 2 stages, 1 workgroup / CU", false);
-    rc |= run<0, 3, 1, false>(c, "product loop, 3 stages, 1 workgroup / CU", true);
-    rc |= run<0, 3, 1, true>(c, "  the same, instrumented", false);
-    rc |= run<1, 3, 1, true>(c, "DMA + waits only, 3 stages, 1 / CU", false);
-    rc |= run<0, 4, 1, false>(c, "product loop, 4 stages, 1 workgroup / CU", true);
-    rc |= run<0, 4, 1, true>(c, "  the same, instrumented", false);
     // the same product on operands that are all zero: if the rate depends on the DATA (power), this one is faster
     CK(hipMemset(c.A, 0, c.hA.size() * 4)); CK(hipMemset(c.B, 0, c.hB.size() * 4));
     rc |= run<0, 2, 2, true>(c, "product loop, 2 stages, 2 / CU, ALL-ZERO operands", false);
+    rc |= run<0, 2, 2, true, true>(c, "assembly DMAs, 2 stages, 2 / CU, ALL-ZERO operands", false);
     rc |= run<0, 2, 1, true>(c, "product loop, 2 stages, 1 / CU, ALL-ZERO operands", false);
     CK(hipMemcpy(c.A, c.hA.data(), 4096 * 4, hipMemcpyHostToDevice));
     for (int vary = 0; vary < 2; ++vary)
