@@ -9,7 +9,12 @@ mkdir -p "$HERE/obj"
 objs=""
 for f in abi cost sinkhorn sinkhorn_pts assign transport sample elem mlp mlp_train ode unbalanced; do
   src="$HERE/$f.hip"; obj="$HERE/obj/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/cfm_common.h" -nt "$obj" ] || [ "$HERE/gemm_core.h" -nt "$obj" ] || [ "$HERE/assign_sparse.h" -nt "$obj" ] || [ "$HERE/assign_small.h" -nt "$obj" ] || [ "$HERE/../../include/cfm_gfx950.h" -nt "$obj" ] || [ "$HERE/../../include/cfm_gfx950_tuning.h" -nt "$obj" ]; then
+  stale=0
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ]; then stale=1; fi
+  for h in "$HERE"/*.h "$HERE"/../../include/*.h; do      # every header of the library: a stale object is worse than a rebuild
+    if [ "$h" -nt "$obj" ]; then stale=1; fi
+  done
+  if [ $stale = 1 ]; then
     "$HIPCC" $FLAGS -c "$src" -o "$obj" &
   fi
   objs="$objs $obj"

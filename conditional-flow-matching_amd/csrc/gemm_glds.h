@@ -149,3 +149,70 @@ struct GldsCore {
         return wn * 64 + n * 32 + (lane & 31);
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second generation of the stage loads (measured with tools/probe/glds_probe.hip at the end of round 4, not yet used by a
+// product kernel — profiles/r4_glds_probe.txt):
+//   * the compiler treats __builtin_amdgcn_global_load_lds as an LDS write that any later ds_read may alias and puts an
+//     s_waitcnt vmcnt(0) in front of the first fragment read of EVERY K step — behind the DMAs of the NEXT stage, issued
+//     a moment earlier.  GldsCore::run therefore never overlaps a stage's loads with its own wave's MFMAs (a lone wave
+//     keeps the matrix pipe 61 % busy).  DMAs written as inline assembly are invisible to that pass; the ordering is the
+//     explicit s_waitcnt vmcnt + s_barrier at the top of the K step.  Lone wave: 74 %; 2 workgroups per CU, K = 3136:
+//     103 -> 114 TFLOP/s.
+//   * SGPR base + 32-bit lane offset addressing: a stage advances by ONE scalar add per operand, and the LDS address of a
+//     piece is wave uniform — 4 scalar instructions per DMA instead of ~12 (64-bit vector add, zero-row selects,
+//     v_readfirstlane + s_mov m0).
+//   * PADDED operands make every DMA unconditional: the operand has one more row than it has rows (index `nrows`, all
+//     zeros) and its rows are zero filled up to a multiple of GL_BK floats (row pitch >= that): lanes of rows beyond the
+//     operand read the zero row, and there is no k tail.
+//   * the two workgroups of a CU are served oldest first: the older one runs ~25 % faster, and with two rounds of tiles
+//     per CU half of the slots sit empty for the last 15 % of a launch.  Alternating the issue priority per K step
+//     (s_setprio, parity from the caller) lets both finish together: 114 -> 120 TFLOP/s.
+struct GldsDma {
+    unsigned offa[4], offb[4];          // byte offset of this lane's 16 bytes from the operand base at k0 = 0
+    unsigned la[4], lb[4];              // LDS byte address of the wave's piece q inside stage 0 (wave uniform)
+
+    // A: [M + 1][lda], B: [N + 1][ldb], zero row at index M / N, rows zero filled to a multiple of GL_BK
+    __device__ __forceinline__ void bind_padded(int lda, int row0, int M, int ldb, int col0, int N, float* lds) {
+        const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 8 * (wv + 4 * q) + (lane >> 3);
+            const int kq = (lane & 7) ^ ((r >> 1) & 7);
+            offa[q] = (unsigned)(((size_t)min(row0 + r, M) * lda + 4 * kq) * 4);
+            offb[q] = (unsigned)(((size_t)min(col0 + r, N) * ldb + 4 * kq) * 4);
+            la[q] = base + (unsigned)((wv + 4 * q) * 256 * 4);
+            lb[q] = la[q] + GL_BM * GL_BK * 4;
+        }
+    }
+    static __device__ __forceinline__ void dma(unsigned off, const float* base, unsigned ldsaddr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(ldsaddr) : "memory");
+    }
+    // stage `st` <- [k0, k0 + GL_BK) of both operands; Ak = A + k0, Bk = B + k0 (uniform)
+    __device__ __forceinline__ void issue(const float* Ak, const float* Bk, int st) const {
+        const unsigned so = (unsigned)st * (GL_STAGE_FLOATS * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dma(offa[q], Ak, la[q] + so); dma(offb[q], Bk, lb[q] + so); }
+    }
+};
+
+// Main loop over [0, Kp) on padded operands (Kp % GL_BK == 0).  prio_phase: 0 / 1 for the two workgroups that share a CU
+// (alternating s_setprio), -1: leave the priority alone.  lds: GL_LDS_BYTES of dynamic LDS.
+__device__ __forceinline__ void gl_run_padded(GldsCore& g, float* __restrict__ lds, const float* __restrict__ A, int lda, int row0,
+                                              int M, const float* __restrict__ B, int ldb, int col0, int N, int Kp, int prio_phase) {
+    GldsDma d;
+    d.bind_padded(lda, row0, M, ldb, col0, N, lds);
+    d.issue(A, B, 0);
+    int st = 0;
+    for (int k0 = 0; k0 < Kp; k0 += GL_BK) {
+        gl_wait_barrier();
+        if (prio_phase >= 0) {
+            if ((prio_phase ^ (k0 / GL_BK)) & 1) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0");
+        }
+        if (k0 + GL_BK < Kp) d.issue(A + k0 + GL_BK, B + k0 + GL_BK, st ^ 1);
+        g.compute(lds, st);
+        st ^= 1;
+    }
+    if (prio_phase >= 0) asm volatile("s_setprio 0");
+}

@@ -9,12 +9,14 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/probe/glds_probe.hip -o tools/probe/glds_probe
 //   tools/probe/glds_probe [M N K]          (default 4096 4096 3136: the asymptotic shape of profiles/r4_gemm_probes.txt)
+//   tools/probe/glds_probe padded           the header's second-generation loop (gl_run_padded) on padded operands, checked
 //
 // Per variant: time, TFLOP/s, and (instrumented builds) the share of a wave's lifetime spent in the vmcnt wait and in the
 // barrier, from s_memtime around them.  MODE 0 results are checked against a float64 host product on sampled entries.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include <algorithm>
 #include "../../conditional-flow-matching_amd/csrc/gemm_glds.h"
@@ -162,6 +164,90 @@ __global__ __launch_bounds__(256) void mfma_only(float* out, int iters, const fl
     if (s == 12345.678f) out[0] = s;
 }
 
+// the header's second-generation loop (gl_run_padded) on padded operands: any M, N, K
+template <bool FAIR>
+__global__ __launch_bounds__(256, 2) void glds_padded(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int Kp,
+                                                      float* __restrict__ C, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    {
+        const int G = 8;
+        const int per_band = G * tiles_n;
+        const int band = lid / per_band, r = lid - band * per_band;
+        const int rows_in_band = min(G, tiles_m - band * G);
+        const int fgt = rows_in_band * G;
+        const int gcol = r / fgt;
+        const int rr = r - gcol * fgt;
+        const int cols_in_group = min(G, tiles_n - gcol * G);
+        tm = band * G + rr / cols_in_group;
+        tn = gcol * G + rr % cols_in_group;
+    }
+    const int row0 = tm * GL_BM, col0 = tn * GL_BN;
+    GldsCore g;
+    g.zero();
+    gl_run_padded(g, lds, A, Kp, row0, M, B, Kp, col0, N, Kp, FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = row0 + GldsCore::row_of(m, r);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gc = col0 + GldsCore::col_of(u);
+                if (gr < M && gc < N) C[(size_t)gr * N + gc] = g.acc[m][u][r];
+            }
+        }
+}
+
+// pads, runs and checks one shape on glds_padded
+static int run_padded(int M, int N, int K) {
+    const int Kp = (K + GL_BK - 1) / GL_BK * GL_BK, tm = (M + GL_BM - 1) / GL_BM, tn = (N + GL_BN - 1) / GL_BN;
+    std::vector<float> hA((size_t)(M + 1) * Kp, 0.f), hB((size_t)(N + 1) * Kp, 0.f);
+    unsigned s = 777u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (int i = 0; i < M; ++i) for (int k = 0; k < K; ++k) hA[(size_t)i * Kp + k] = rnd();
+    for (int j = 0; j < N; ++j) for (int k = 0; k < K; ++k) hB[(size_t)j * Kp + k] = rnd();
+    float *A, *B, *C;
+    CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&B, hB.size() * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
+    CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    int rc = 0;
+    for (int fair = 0; fair < 2; ++fair) {
+        auto launch = [&]() {
+            if (fair) hipLaunchKernelGGL(glds_padded<true>, dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn);
+            else hipLaunchKernelGGL(glds_padded<false>, dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn);
+        };
+        CK(hipFuncSetAttribute((const void*)glds_padded<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES));
+        CK(hipFuncSetAttribute((const void*)glds_padded<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES));
+        CK(hipMemset(C, 0xff, (size_t)M * N * 4));
+        launch(); launch(); CK(hipDeviceSynchronize());
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const int reps = 10;
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) launch();
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        std::vector<float> hC((size_t)M * N);
+        CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int t = 0; t < 4096; ++t) {
+            // the last rows / columns (edge tiles) are sampled as densely as the interior
+            const int i = t & 1 ? M - 1 - (int)((t * 2654435761u) % 200u) % M : (int)((t * 2654435761u) % (unsigned)M);
+            const int j = t & 2 ? N - 1 - (int)((t * 40503u + 17u) % 200u) % N : (int)((t * 40503u + 17u) % (unsigned)N);
+            double ref = 0;
+            for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)i * Kp + k] * (double)hB[(size_t)j * Kp + k];
+            const double err = fabs(ref - hC[(size_t)i * N + j]) / (fabs(ref) + 1.0);
+            if (!(err <= worst)) worst = err;
+        }
+        printf("gl_run_padded %5d x %5d x %5d (K padded to %d)%s: %8.1f us  %6.1f TFLOP/s   worst relative error of 4096 samples %.2e %s\n",
+               M, N, K, Kp, fair ? ", alternating s_setprio" : "                        ", ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, worst,
+               worst < 1e-4 ? "ok" : "WRONG");
+        if (!(worst < 1e-4)) rc = 2;
+    }
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
+    return rc;
+}
+
 struct Ctx { float *A, *B, *C, *zeros; unsigned long long* stats; int M, N, K, tm, tn; std::vector<float> hA, hB; };
 
 template <int MODE, int NST, int WPC, bool STATS, bool FAST = false, bool FAIR = false>
@@ -230,6 +316,13 @@ static int run(Ctx& c, const char* label, bool check) {
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "padded")) {      // glds_probe padded: the header's gl_run_padded on three shapes
+        int rc = run_padded(4096, 4096, 784);          // C3
+        rc |= run_padded(4000, 4090, 777);             // edge tiles in both directions, a k tail inside the padding
+        rc |= run_padded(4096, 4096, 3136);
+        rc |= run_padded(130, 300, 36);
+        return rc;
+    }
     Ctx c;
     c.M = argc > 3 ? atoi(argv[1]) : 4096; c.N = argc > 3 ? atoi(argv[2]) : 4096; c.K = argc > 3 ? atoi(argv[3]) : 3136;
     if (c.K % 4) { printf("K must be a multiple of 4 (16-byte DMA pieces)\n"); return 1; }
@@ -250,7 +343,8 @@ int main(int argc, char** argv) {
     rc |= run<0, 2, 2, true>(c, "  the same, instrumented", false);
     rc |= run<0, 2, 2, false, true>(c, "assembly DMAs, 2 stages, 2 / CU", true);
     rc |= run<0, 2, 2, true, true>(c, "  the same, instrumented", false);
-    rc |= run<0, 2, 2, true, true, true>(c, "assembly DMAs + alternating s_setprio, 2 / CU", false);
+    rc |= run<0, 2, 2, false, true, true>(c, "assembly DMAs + alternating s_setprio, 2 / CU", true);
+    rc |= run<0, 2, 2, true, true, true>(c, "  the same, instrumented", false);
     rc |= run<0, 2, 2, true, false, true>(c, "builtin DMAs + alternating s_setprio, 2 / CU", false);
     rc |= run<0, 2, 1, true, true>(c, "assembly DMAs, 2 stages, 1 / CU", false);
     rc |= run<0, 3, 1, false, true>(c, "assembly DMAs, 3 stages, 1 / CU", true);
