@@ -229,14 +229,32 @@ __global__ __launch_bounds__(256) void cost_center(const float* __restrict__ x0,
 // nrm[i] = |fl(x0_i - mu)|^2 (i < B0), nrm[B0 + j] = |fl(x1_j - mu)|^2: one wave per row
 // xc (may be NULL): the centred rows fl(x - mu) themselves, [B0 + B1][d] — the operands of the direct-to-LDS product
 // (cost_gemm_glds), which cannot subtract on the way in; the same fp32 values the register-staged engine forms.
+// COST_GLDS_V2 (compile-time experiment, default 0; build it with tools/probe/try_glds_v2.sh): the centred copies in the
+// PADDED layout gl_run_padded wants — xc0 [(B0 + 1)][dp], xc1 [(B1 + 1)][dp] behind it, dp = d rounded up to GL_BK, the
+// k padding and the extra row of each zero — so that every DMA of the product is unconditional (gemm_glds.h).
+#ifndef COST_GLDS_V2
+#define COST_GLDS_V2 0
+#endif
 __global__ __launch_bounds__(256) void cost_norms(const float* __restrict__ x0, const float* __restrict__ x1,
                                                   int B0, int B1, int d, const float* __restrict__ mu,
                                                   float* __restrict__ nrm, float* __restrict__ xc) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+#if COST_GLDS_V2
+    const int dp = (d + GL_BK - 1) / GL_BK * GL_BK;
+    if (xc && row >= B0 + B1 && row < B0 + B1 + 2) {          // the two zero rows
+        float* z = xc + (size_t)(row == B0 + B1 ? B0 : B0 + 1 + B1) * dp;
+        for (int k = lane; k < dp; k += 64) z[k] = 0.f;
+    }
+#endif
     if (row >= B0 + B1) return;
     const float* p = row < B0 ? x0 + (size_t)row * d : x1 + (size_t)(row - B0) * d;
+#if COST_GLDS_V2
+    float* pc = xc ? xc + (size_t)(row < B0 ? row : row + 1) * dp : nullptr;
+    if (pc) for (int k = d + lane; k < dp; k += 64) pc[k] = 0.f;
+#else
     float* pc = xc ? xc + (size_t)row * d : nullptr;
+#endif
     float s = 0.f;
     int k = lane;
     for (; k + 64 * 7 < d; k += 64 * 8) {                 // 8 trips' loads in flight, the chain in k order as before
@@ -374,6 +392,9 @@ __global__ __launch_bounds__(256, COST_MINW) void cost_gemm(const float* __restr
 // The same product on the direct-to-LDS engine (gemm_glds.h): operands = the centred clouds cost_norms wrote (xc0, xc1),
 // same k order, same epilogue arithmetic — the matrix is bit-equal to cost_gemm's.  x0 / x1: the original clouds, read
 // only by the recomputation of cancelling entries.  64 KiB of dynamic LDS, two workgroups per CU.
+#ifndef COST_GLDS_FAIR
+#define COST_GLDS_FAIR 1
+#endif
 __global__ __launch_bounds__(256, 2) void cost_gemm_glds(const float* __restrict__ xc0, const float* __restrict__ xc1,
                                                          const float* __restrict__ x0, const float* __restrict__ x1,
                                                          int B0, int B1, int d, const float* __restrict__ nrm,
@@ -398,7 +419,14 @@ __global__ __launch_bounds__(256, 2) void cost_gemm_glds(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63;
     GldsCore g;
     g.zero();
+#if COST_GLDS_V2
+    {   // xc0 / xc1 are padded ([B + 1][dp]); the two workgroups of a CU alternate their issue priority (COST_GLDS_FAIR)
+        const int dp = (d + GL_BK - 1) / GL_BK * GL_BK;
+        gl_run_padded(g, glds_lds, xc0, dp, row0, B0, xc1, dp, col0, B1, dp, COST_GLDS_FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
+    }
+#else
     g.run(glds_lds, xc0, d, row0, B0, xc1, d, col0, B1, d, zeros);
+#endif
     gl_wait_barrier();                                   // every wave is done with the last stage
     float* An = glds_lds; float* Bn = glds_lds + GL_BM;
     if (tid < GL_BM) An[tid] = (row0 + tid < B0) ? nrm[row0 + tid] : 0.f;
@@ -505,7 +533,11 @@ static inline size_t cost_ws_head_floats(int B0, int B1, int d) {
 }
 static bool cost_use_glds();
 extern "C" size_t cfm_cost_ws_bytes_internal(int B0, int B1, int d) {
+#if COST_GLDS_V2
+    const size_t centred = cost_use_glds() ? ((size_t)B0 + (size_t)B1 + 2) * (size_t)((d + GL_BK - 1) / GL_BK * GL_BK) : 0;
+#else
     const size_t centred = (cost_use_glds() && d % 4 == 0) ? ((size_t)B0 + (size_t)B1) * (size_t)d : 0;
+#endif
     return sizeof(float) * (cost_ws_head_floats(B0, B1, d) + centred) + 256;
 }
 static bool cost_use_mfma(int B0, int B1, int d) {
@@ -531,16 +563,29 @@ static int cost_mfma(const float* x0, const float* x1, int B0, int B1, int d, fl
     float* zeros = nrm + (((size_t)B0 + (size_t)B1 + 3) & ~(size_t)3);
     float* xc = zeros + 16;
     const bool vec = (d % 4 == 0) && (((uintptr_t)x0 & 15) == 0) && (((uintptr_t)x1 & 15) == 0);
+#if COST_GLDS_V2
+    const bool glds = cost_use_glds();          // the padded copies take any d and any alignment of the clouds
+#else
     const bool glds = vec && cost_use_glds();
+#endif
     hipLaunchKernelGGL(cost_center, dim3((d + 63) / 64), dim3(256), 0, st, x0, x1, B0, B1, d, mu);
+#if COST_GLDS_V2
+    hipLaunchKernelGGL(cost_norms, dim3((B0 + B1 + 2 + 3) / 4), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, glds ? xc : nullptr);
+#else
     hipLaunchKernelGGL(cost_norms, dim3((B0 + B1 + 3) / 4), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, glds ? xc : nullptr);
+#endif
     // (256 x 128 tiles — 8 MFMA tiles per wave, one resident round at B = 4096 — were measured at
     //  549 us against 368 us for 128 x 128: the accumulators leave two waves per SIMD no room.)
     const int tm = (B0 + 127) / 128, tn = (B1 + 127) / 128;
     if (glds) {
         hipLaunchKernelGGL(cost_zero16, dim3(1), dim3(64), 0, st, zeros);
+#if COST_GLDS_V2
+        hipLaunchKernelGGL(cost_gemm_glds, dim3(tm * tn), dim3(256), GL_LDS_BYTES, st, xc,
+                           xc + (size_t)(B0 + 1) * (size_t)((d + GL_BK - 1) / GL_BK * GL_BK), x0, x1, B0, B1, d, nrm, M, tm, tn, zeros);
+#else
         hipLaunchKernelGGL(cost_gemm_glds, dim3(tm * tn), dim3(256), GL_LDS_BYTES, st, xc, xc + (size_t)B0 * d, x0, x1, B0, B1, d,
                            nrm, M, tm, tn, zeros);
+#endif
     } else if (vec) hipLaunchKernelGGL((cost_gemm<128, true>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, M, tm, tn);
     else     hipLaunchKernelGGL((cost_gemm<128, false>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, M, tm, tn);
     return cfm_status();

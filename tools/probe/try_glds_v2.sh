@@ -1,0 +1,31 @@
+#!/bin/bash
+# First GPU call of the next round (≈ 2 min on the box): the cost matrix on the second-generation direct-to-LDS loop
+# (csrc/gemm_glds.h: gl_run_padded; csrc/cost.hip: COST_GLDS_V2) against the default engine.
+#   1. build the variant libraries HERE (no GPU needed):   bash tools/probe/try_glds_v2.sh build
+#   2. on the GPU box (gpurun):                             bash tools/probe/try_glds_v2.sh run
+# `run` checks bit-equality of the cost matrices (tests/test_gpu_glds.py against the variant library) and times cost /
+# forward / regression step at the C3 shapes (tools/gemm_quick.py) for: the product library, the variant with and without
+# the alternating issue priority.  Adoption = make COST_GLDS_V2 and CFM_COST_GLDS the defaults, then the full GPU suite.
+set -e
+R="$(cd "$(dirname "$0")/../.." && pwd)"
+case "$1" in
+  build)
+    bash "$R/tools/probe/build_variant_all.sh" gv2 "-DCOST_GLDS_V2=1" cost
+    bash "$R/tools/probe/build_variant_all.sh" gv2nofair "-DCOST_GLDS_V2=1 -DCOST_GLDS_FAIR=0" cost
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off "$R/tools/probe/glds_probe.hip" -o "$R/tools/probe/glds_probe"
+    ;;
+  run)
+    cd "$R"; mkdir -p gpurun_out
+    {
+      timeout 60 tools/probe/glds_probe padded
+      for V in gv2 gv2nofair; do
+        echo "== bit-equality with the default engine, variant $V"
+        CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 300 python -m pytest tests/test_gpu_glds.py -q -x -p no:cacheprovider 2>&1 | tail -3
+      done
+      echo "== timings (C3 shapes)"
+      timeout 120 python tools/gemm_quick.py
+      for V in gv2 gv2nofair; do CFM_COST_GLDS=1 CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 120 python tools/gemm_quick.py; done
+    } 2>&1 | tee gpurun_out/try_glds_v2.txt
+    ;;
+  *) echo "usage: $0 build | run"; exit 2;;
+esac
