@@ -35,6 +35,14 @@
 #ifndef GC_DBG
 #define GC_DBG 0
 #endif
+// GC_FAIR=1 (experiment, default 0): the two workgroups that share a CU (block b and b + 256 of a 1-D grid) alternate
+// their issue priority K step by K step.  A CU serves its resident workgroups oldest first: of two that start together one
+// runs ~25 % faster, and with two rounds of tiles per CU half of the slots are empty for the last 15 % of a launch
+// (tools/probe/glds_probe.hip, profiles/r4_glds_probe.txt: 114 -> 120 TFLOP/s on the direct-to-LDS loop, not reproduced in
+// a second form of the same loop).  Results do not depend on it.
+#ifndef GC_FAIR
+#define GC_FAIR 0
+#endif
 typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gc_f32x2 __attribute__((ext_vector_type(2)));
 typedef float gc_f32x4 __attribute__((ext_vector_type(4)));
@@ -318,6 +326,9 @@ struct GemmCore {
         for (; k0 + BK < k_end; k0 += BK) {
             float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
             post(Ac, k0);
+#if GC_FAIR
+            if (((blockIdx.x >> 8) ^ (unsigned)((k0 - k_begin) / BK)) & 1u) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0");
+#endif
             step<true>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob,
                        [&]() { if (k0 + 2 * BK < k_end) { oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); pre.a(oa, k0 + 2 * BK); } },
                        [&]() { if (k0 + 2 * BK < k_end) { ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end); pre.b(ob, k0 + 2 * BK); } });
@@ -327,6 +338,9 @@ struct GemmCore {
         {
             float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
             post(Ac, k0);
+#if GC_FAIR
+            asm volatile("s_setprio 0");
+#endif
             step<false>(Ac, Bc, nullptr, nullptr, oa, ob, []() {}, []() {});
         }
     }

@@ -12,6 +12,7 @@ case "$1" in
   build)
     bash "$R/tools/probe/build_variant_all.sh" gv2 "-DCOST_GLDS_V2=1" cost
     bash "$R/tools/probe/build_variant_all.sh" gv2nofair "-DCOST_GLDS_V2=1 -DCOST_GLDS_FAIR=0" cost
+    bash "$R/tools/probe/build_variant_all.sh" gcfair "-DGC_FAIR=1" cost mlp mlp_train      # the register-staged core with alternating priority
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off "$R/tools/probe/glds_probe.hip" -o "$R/tools/probe/glds_probe"
     ;;
   run)
@@ -25,6 +26,7 @@ case "$1" in
       echo "== timings (C3 shapes)"
       timeout 120 python tools/gemm_quick.py
       for V in gv2 gv2nofair; do CFM_COST_GLDS=1 CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 120 python tools/gemm_quick.py; done
+      CFM_LIB_PATH=tools/probe/libcfm_gcfair.so timeout 120 python tools/gemm_quick.py
     } 2>&1 | tee gpurun_out/try_glds_v2.txt
     ;;
   *) echo "usage: $0 build | run"; exit 2;;
