@@ -138,6 +138,126 @@ __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__
         }
 }
 
+// PIPELINED K-step boundary (next round's candidate; compiled and ISA-checked at the end of round 4, never run):
+// the product loop drains the matrix pipe at every K step — wait, barrier, DMA issue, then eight fragment reads nothing
+// covers (a lone wave keeps the pipe 74 % busy even with assembly DMAs).  Here the LAST k-quad of stage s is computed
+// AFTER the barrier of step s + 1: its fragments are already in registers (the barrier only protects the LDS buffer), and
+// its eight MFMAs (512 cycles) cover the first fragment reads of stage s + 1 and — ILV — the issue of the eight DMAs of
+// stage s + 2, placed one behind each MFMA.  Same k order per output as every other loop here.
+struct PipeFrag { float4 a0, a1, b0, b1; };
+template <int WPC, bool ILV, bool FAIR>
+__global__ __launch_bounds__(256, WPC) void glds_pipe(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int K,
+                                                     float* __restrict__ C, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    {
+        const int G = 8;
+        const int per_band = G * tiles_n;
+        const int band = lid / per_band, r = lid - band * per_band;
+        const int rows_in_band = min(G, tiles_m - band * G);
+        const int fgt = rows_in_band * G;
+        const int gcol = r / fgt;
+        const int rr = r - gcol * fgt;
+        const int cols_in_group = min(G, tiles_n - gcol * G);
+        tm = band * G + rr / cols_in_group;
+        tn = gcol * G + rr % cols_in_group;
+    }
+    const int row0 = tm * GL_BM, col0 = tn * GL_BN;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
+    const bool hi = lane >= 32;
+    const int fr = lane & 31, sw = (fr >> 1) & 7;
+    GldsCore g;
+    g.zero();
+    FastDma fd;
+    fd.bind(K, row0, K, col0, lds);
+    const int nsteps = K / GL_BK;
+    auto rd = [&](int st, int q) {
+        const float* As = lds + st * GL_STAGE_FLOATS + (wm * 64 + fr) * GL_BK;
+        const float* Bs = lds + st * GL_STAGE_FLOATS + GL_BM * GL_BK + (wn * 64 + fr) * GL_BK;
+        const int so = 4 * (q ^ sw);
+        PipeFrag f;
+        f.a0 = *reinterpret_cast<const float4*>(As + so); f.a1 = *reinterpret_cast<const float4*>(As + 32 * GL_BK + so);
+        f.b0 = *reinterpret_cast<const float4*>(Bs + so); f.b1 = *reinterpret_cast<const float4*>(Bs + 32 * GL_BK + so);
+        return f;
+    };
+    // the 8 MFMAs of a k-quad; dma(i): hook run behind MFMA i (the interleaved DMA issue)
+    auto mm = [&](const PipeFrag& t, auto dma) {
+        const float a00 = hi ? t.a0.y : t.a0.x, a01 = hi ? t.a1.y : t.a1.x, b00 = hi ? t.b0.y : t.b0.x, b01 = hi ? t.b1.y : t.b1.x;
+        const float a10 = hi ? t.a0.w : t.a0.z, a11 = hi ? t.a1.w : t.a1.z, b10 = hi ? t.b0.w : t.b0.z, b11 = hi ? t.b1.w : t.b1.z;
+        g.acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b00, g.acc[0][0], 0, 0, 0); dma(0);
+        g.acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b01, g.acc[0][1], 0, 0, 0); dma(1);
+        g.acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, b00, g.acc[1][0], 0, 0, 0); dma(2);
+        g.acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, b01, g.acc[1][1], 0, 0, 0); dma(3);
+        g.acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, b10, g.acc[0][0], 0, 0, 0); dma(4);
+        g.acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, b11, g.acc[0][1], 0, 0, 0); dma(5);
+        g.acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b10, g.acc[1][0], 0, 0, 0); dma(6);
+        g.acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b11, g.acc[1][1], 0, 0, 0); dma(7);
+    };
+    auto none = [](int) {};
+    fd.issue(A, B, 0);
+    if (nsteps > 1) { fd.issue(A + GL_BK, B + GL_BK, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    PipeFrag t = rd(0, 0);
+    // ONE body in the loop, the last stage peeled behind it, no branch around an MFMA: accumulators that reach a K step
+    // over two paths are copied (round 4; the first form of this loop moved 64 registers per step).
+    // The DMAs of the loop's last trip have no stage left to fetch: they fetch the last stage once more into the buffer
+    // nobody reads again (drained by the vmcnt(0) behind the loop).
+    for (int s = 0; s + 1 < nsteps; ++s) {
+        const int st = s & 1;
+        if (FAIR) { if (((blockIdx.x >> 8) ^ (unsigned)s) & 1u) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0"); }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const PipeFrag n = rd(st, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(t, none);
+            t = n;
+        }
+        // stage s + 1 has landed (issued a whole step ago); this wave's reads of stage s are complete (lgkmcnt); behind
+        // the barrier nobody reads stage s any more: its buffer takes stage s + 2
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int sn = min(s + 2, nsteps - 1);
+        const float* An = A + (size_t)sn * GL_BK; const float* Bn = B + (size_t)sn * GL_BK;
+        if (!ILV) fd.issue(An, Bn, st);
+        const PipeFrag n = rd(st ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ILV) {
+            const unsigned so = (unsigned)st * (GL_STAGE_FLOATS * 4);
+            mm(t, [&](int i) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (i & 1) FastDma::dma(fd.offb[i >> 1], Bn, fd.lb[i >> 1] + so); else FastDma::dma(fd.offa[i >> 1], An, fd.la[i >> 1] + so);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else mm(t, none);
+        t = n;
+    }
+    {
+        const int st = (nsteps - 1) & 1;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const PipeFrag n = rd(st, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(t, none);
+            t = n;
+        }
+        mm(t, none);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may outlive the workgroup's LDS allocation
+    if (FAIR) asm volatile("s_setprio 0");
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = row0 + GldsCore::row_of(m, r);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gc = col0 + GldsCore::col_of(u);
+                if (gr < M && gc < N) C[(size_t)gr * N + gc] = g.acc[m][u][r];
+            }
+        }
+}
+
 // the matrix pipe alone (registers only), operands constant (what tools/probe/mfma_peak measures) or changing from one
 // MFMA to the next (16 different register pairs per lane): does the sustained rate depend on the data?
 template <bool VARY>
@@ -315,6 +435,38 @@ static int run(Ctx& c, const char* label, bool check) {
     return 0;
 }
 
+template <int WPC, bool ILV, bool FAIR>
+static int run_pipe(Ctx& c, const char* label) {
+    if (c.M % GL_BM || c.N % GL_BN || c.K % GL_BK) { printf("%s: skipped (M, N, K not multiples of the tile)\n", label); return 0; }
+    size_t ldsb = GL_LDS_BYTES;
+    if (WPC == 1) ldsb = 96 * 1024;
+    auto kern = glds_pipe<WPC, ILV, FAIR>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const int grid = c.tm * c.tn;
+    auto launch = [&]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn); };
+    CK(hipMemset(c.C, 0xff, (size_t)c.M * c.N * 4));
+    launch(); launch(); CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 6;
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) launch();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const double tf = 2.0 * c.M * c.N * c.K / (ms * 1e-3) / 1e12;
+    std::vector<float> hC((size_t)c.M * c.N);
+    CK(hipMemcpy(hC.data(), c.C, hC.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int t = 0; t < 2048; ++t) {
+        const int i = (int)((t * 2654435761u) % (unsigned)c.M), j = (int)((t * 40503u + 17u) % (unsigned)c.N);
+        double ref = 0;
+        for (int k = 0; k < c.K; ++k) ref += (double)c.hA[(size_t)i * c.K + k] * (double)c.hB[(size_t)j * c.K + k];
+        const double err = fabs(ref - hC[(size_t)i * c.N + j]) / (fabs(ref) + 1.0);
+        if (!(err <= worst)) worst = err;
+    }
+    printf("%-58s %8.1f us  %6.1f TFLOP/s (%4.1f %% of 157.3)   check %.2e %s\n", label, ms * 1e3, tf, tf / 1.573, worst, worst < 1e-4 ? "ok" : "WRONG");
+    return worst < 1e-4 ? 0 : 2;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "padded")) {      // glds_probe padded: the header's gl_run_padded on three shapes
         int rc = run_padded(4096, 4096, 784);          // C3
@@ -349,6 +501,11 @@ int main(int argc, char** argv) {
     rc |= run<0, 2, 1, true, true>(c, "assembly DMAs, 2 stages, 1 / CU", false);
     rc |= run<0, 3, 1, false, true>(c, "assembly DMAs, 3 stages, 1 / CU", true);
     rc |= run<0, 3, 1, true, true>(c, "  the same, instrumented", false);
+    rc |= run_pipe<2, false, false>(c, "pipelined K-step boundary, assembly DMAs, 2 / CU");
+    rc |= run_pipe<2, true, false>(c, "  + the next stage's DMAs between the MFMAs, 2 / CU");
+    rc |= run_pipe<2, true, true>(c, "  + alternating s_setprio, 2 / CU");
+    rc |= run_pipe<1, false, false>(c, "pipelined K-step boundary, 1 / CU");
+    rc |= run_pipe<1, true, false>(c, "  + the next stage's DMAs between the MFMAs, 1 / CU");
     rc |= run<1, 2, 2, true>(c, "DMA + waits only (no MFMA), 2 stages, 2 / CU", false);
     rc |= run<2, 2, 2, true>(c, "no DMA in the loop (MFMA + LDS reads only)", false);
     rc |= run<0, 2, 1, true>(c, "product loop, 2 stages, 1 workgroup / CU", false);
