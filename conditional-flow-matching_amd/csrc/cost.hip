@@ -395,6 +395,9 @@ __global__ __launch_bounds__(256, COST_MINW) void cost_gemm(const float* __restr
 #ifndef COST_GLDS_FAIR
 #define COST_GLDS_FAIR 1
 #endif
+#ifndef COST_GLDS_LOOP
+#define COST_GLDS_LOOP 1      // 1: gl_run_padded_pipe (pipelined K-step boundary), 0: gl_run_padded
+#endif
 __global__ __launch_bounds__(256, 2) void cost_gemm_glds(const float* __restrict__ xc0, const float* __restrict__ xc1,
                                                          const float* __restrict__ x0, const float* __restrict__ x1,
                                                          int B0, int B1, int d, const float* __restrict__ nrm,
@@ -422,7 +425,11 @@ __global__ __launch_bounds__(256, 2) void cost_gemm_glds(const float* __restrict
 #if COST_GLDS_V2
     {   // xc0 / xc1 are padded ([B + 1][dp]); the two workgroups of a CU alternate their issue priority (COST_GLDS_FAIR)
         const int dp = (d + GL_BK - 1) / GL_BK * GL_BK;
+#if COST_GLDS_LOOP
+        gl_run_padded_pipe(g, glds_lds, xc0, dp, row0, B0, xc1, dp, col0, B1, dp, COST_GLDS_FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
+#else
         gl_run_padded(g, glds_lds, xc0, dp, row0, B0, xc1, dp, col0, B1, dp, COST_GLDS_FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
+#endif
     }
 #else
     g.run(glds_lds, xc0, d, row0, B0, xc1, d, col0, B1, d, zeros);

@@ -216,3 +216,83 @@ __device__ __forceinline__ void gl_run_padded(GldsCore& g, float* __restrict__ l
     }
     if (prio_phase >= 0) asm volatile("s_setprio 0");
 }
+
+// The same loop with a PIPELINED K-step boundary (tools/probe/glds_probe.hip: glds_pipe; 4096 x 4096 x 3136, two workgroups
+// per CU: 112.6 -> 125.5 TFLOP/s, checked): gl_run_padded drains the matrix pipe at every K step — wait, barrier, DMA
+// issue, then eight fragment reads nothing covers.  Here the LAST k-quad of stage s is computed AFTER the barrier of step
+// s + 1: its fragments are in registers by then (the barrier only protects the LDS buffer), and its eight MFMAs cover the
+// first fragment reads of stage s + 1.  (Issuing the DMAs of stage s + 2 one behind each of those MFMAs was slower with two
+// workgroups per CU — 112.9 — and faster with one.)  ONE body in the loop, the last stage peeled behind it, no branch
+// around an MFMA: accumulators that reach a K step over two paths get copied.  The DMAs of the
+// loop's last trip have no stage left to fetch: they fetch the last stage once more into the buffer nobody reads again
+// and are drained before the function returns (no DMA may outlive the workgroup's LDS allocation).  Same k order per
+// output: bitwise the results of GldsCore::run.
+struct GlFrag { float4 a0, a1, b0, b1; };
+__device__ __forceinline__ GlFrag gl_read_frag(const float* __restrict__ lds, int st, int q) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
+    const int fr = lane & 31, so = 4 * (q ^ ((fr >> 1) & 7));
+    const float* As = lds + st * GL_STAGE_FLOATS + (wm * 64 + fr) * GL_BK;
+    const float* Bs = lds + st * GL_STAGE_FLOATS + GL_BM * GL_BK + (wn * 64 + fr) * GL_BK;
+    GlFrag f;
+    f.a0 = *reinterpret_cast<const float4*>(As + so); f.a1 = *reinterpret_cast<const float4*>(As + 32 * GL_BK + so);
+    f.b0 = *reinterpret_cast<const float4*>(Bs + so); f.b1 = *reinterpret_cast<const float4*>(Bs + 32 * GL_BK + so);
+    return f;
+}
+__device__ __forceinline__ void gl_mfma8(GldsCore& g, const GlFrag& t) {
+    const bool hi = (threadIdx.x & 63) >= 32;
+    const float a00 = hi ? t.a0.y : t.a0.x, a01 = hi ? t.a1.y : t.a1.x, b00 = hi ? t.b0.y : t.b0.x, b01 = hi ? t.b1.y : t.b1.x;
+    const float a10 = hi ? t.a0.w : t.a0.z, a11 = hi ? t.a1.w : t.a1.z, b10 = hi ? t.b0.w : t.b0.z, b11 = hi ? t.b1.w : t.b1.z;
+    g.acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b00, g.acc[0][0], 0, 0, 0);
+    g.acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b01, g.acc[0][1], 0, 0, 0);
+    g.acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, b00, g.acc[1][0], 0, 0, 0);
+    g.acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, b01, g.acc[1][1], 0, 0, 0);
+    g.acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, b10, g.acc[0][0], 0, 0, 0);
+    g.acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, b11, g.acc[0][1], 0, 0, 0);
+    g.acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b10, g.acc[1][0], 0, 0, 0);
+    g.acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b11, g.acc[1][1], 0, 0, 0);
+}
+__device__ __forceinline__ void gl_run_padded_pipe(GldsCore& g, float* __restrict__ lds, const float* __restrict__ A, int lda, int row0,
+                                                   int M, const float* __restrict__ B, int ldb, int col0, int N, int Kp, int prio_phase) {
+    GldsDma d;
+    d.bind_padded(lda, row0, M, ldb, col0, N, lds);
+    const int nsteps = Kp / GL_BK;
+    if (nsteps <= 0) return;
+    d.issue(A, B, 0);
+    if (nsteps > 1) { d.issue(A + GL_BK, B + GL_BK, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    GlFrag t = gl_read_frag(lds, 0, 0);
+    for (int s = 0; s + 1 < nsteps; ++s) {
+        const int st = s & 1;
+        if (prio_phase >= 0) { if ((prio_phase ^ s) & 1) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0"); }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const GlFrag n = gl_read_frag(lds, st, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            gl_mfma8(g, t);
+            t = n;
+        }
+        // stage s + 1 has landed (issued a whole step ago); this wave's reads of stage s are complete (lgkmcnt); behind
+        // the barrier nobody reads stage s any more: its buffer takes stage s + 2
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int sn = min(s + 2, nsteps - 1);
+        d.issue(A + (size_t)sn * GL_BK, B + (size_t)sn * GL_BK, st);
+        const GlFrag n = gl_read_frag(lds, st ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        gl_mfma8(g, t);                              // the last k-quad of stage s, behind the barrier of step s + 1
+        t = n;
+    }
+    {
+        const int st = (nsteps - 1) & 1;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const GlFrag n = gl_read_frag(lds, st, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            gl_mfma8(g, t);
+            t = n;
+        }
+        gl_mfma8(g, t);
+    }
+    if (prio_phase >= 0) asm volatile("s_setprio 0");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}

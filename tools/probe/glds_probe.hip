@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void mfma_only(float* out, int iters, const fl
 }
 
 // the header's second-generation loop (gl_run_padded) on padded operands: any M, N, K
-template <bool FAIR>
+template <bool FAIR, bool PIPE>
 __global__ __launch_bounds__(256, 2) void glds_padded(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int Kp,
                                                       float* __restrict__ C, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256, 2) void glds_padded(const float* __restrict__ 
     const int row0 = tm * GL_BM, col0 = tn * GL_BN;
     GldsCore g;
     g.zero();
-    gl_run_padded(g, lds, A, Kp, row0, M, B, Kp, col0, N, Kp, FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
+    if (PIPE) gl_run_padded_pipe(g, lds, A, Kp, row0, M, B, Kp, col0, N, Kp, FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
+    else gl_run_padded(g, lds, A, Kp, row0, M, B, Kp, col0, N, Kp, FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -332,13 +333,18 @@ static int run_padded(int M, int N, int K) {
     CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&B, hB.size() * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
     CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
     int rc = 0;
-    for (int fair = 0; fair < 2; ++fair) {
+    CK(hipFuncSetAttribute((const void*)glds_padded<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)glds_padded<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)glds_padded<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)glds_padded<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES));
+    for (int var = 0; var < 4; ++var) {
+        const int fair = var & 1, pipe = var >> 1;
         auto launch = [&]() {
-            if (fair) hipLaunchKernelGGL(glds_padded<true>, dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn);
-            else hipLaunchKernelGGL(glds_padded<false>, dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn);
+            if (pipe) { if (fair) hipLaunchKernelGGL((glds_padded<true, true>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn);
+                        else hipLaunchKernelGGL((glds_padded<false, true>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn); }
+            else { if (fair) hipLaunchKernelGGL((glds_padded<true, false>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn);
+                   else hipLaunchKernelGGL((glds_padded<false, false>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn); }
         };
-        CK(hipFuncSetAttribute((const void*)glds_padded<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES));
-        CK(hipFuncSetAttribute((const void*)glds_padded<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES));
         CK(hipMemset(C, 0xff, (size_t)M * N * 4));
         launch(); launch(); CK(hipDeviceSynchronize());
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -359,8 +365,8 @@ static int run_padded(int M, int N, int K) {
             const double err = fabs(ref - hC[(size_t)i * N + j]) / (fabs(ref) + 1.0);
             if (!(err <= worst)) worst = err;
         }
-        printf("gl_run_padded %5d x %5d x %5d (K padded to %d)%s: %8.1f us  %6.1f TFLOP/s   worst relative error of 4096 samples %.2e %s\n",
-               M, N, K, Kp, fair ? ", alternating s_setprio" : "                        ", ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, worst,
+        printf("%s %5d x %5d x %5d (K padded to %d)%s: %8.1f us  %6.1f TFLOP/s   worst relative error of 4096 samples %.2e %s\n",
+               pipe ? "gl_run_padded_pipe" : "gl_run_padded     ", M, N, K, Kp, fair ? ", alternating s_setprio" : "                        ", ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, worst,
                worst < 1e-4 ? "ok" : "WRONG");
         if (!(worst < 1e-4)) rc = 2;
     }
@@ -473,6 +479,8 @@ int main(int argc, char** argv) {
         rc |= run_padded(4000, 4090, 777);             // edge tiles in both directions, a k tail inside the padding
         rc |= run_padded(4096, 4096, 3136);
         rc |= run_padded(130, 300, 36);
+        rc |= run_padded(128, 128, 32);              // one K step: the pipelined loop's degenerate case
+        rc |= run_padded(256, 384, 64);              // two K steps
         return rc;
     }
     Ctx c;

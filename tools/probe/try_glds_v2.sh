@@ -12,6 +12,7 @@ case "$1" in
   build)
     bash "$R/tools/probe/build_variant_all.sh" gv2 "-DCOST_GLDS_V2=1" cost
     bash "$R/tools/probe/build_variant_all.sh" gv2nofair "-DCOST_GLDS_V2=1 -DCOST_GLDS_FAIR=0" cost
+    bash "$R/tools/probe/build_variant_all.sh" gv2plain "-DCOST_GLDS_V2=1 -DCOST_GLDS_FAIR=0 -DCOST_GLDS_LOOP=0" cost
     bash "$R/tools/probe/build_variant_all.sh" gcfair "-DGC_FAIR=1" cost mlp mlp_train      # the register-staged core with alternating priority
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off "$R/tools/probe/glds_probe.hip" -o "$R/tools/probe/glds_probe"
     ;;
@@ -21,13 +22,13 @@ case "$1" in
       timeout 60 tools/probe/glds_probe padded
       timeout 60 tools/probe/glds_probe            # incl. the pipelined K-step boundary (glds_pipe): written at the end of round 4, never run
       timeout 60 tools/probe/glds_probe 4096 4096 800
-      for V in gv2 gv2nofair; do
+      for V in gv2 gv2nofair gv2plain; do
         echo "== bit-equality with the default engine, variant $V"
         CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 300 python -m pytest tests/test_gpu_glds.py -q -x -p no:cacheprovider 2>&1 | tail -3
       done
       echo "== timings (C3 shapes)"
       timeout 120 python tools/gemm_quick.py
-      for V in gv2 gv2nofair; do CFM_COST_GLDS=1 CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 120 python tools/gemm_quick.py; done
+      for V in gv2 gv2nofair gv2plain; do CFM_COST_GLDS=1 CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 120 python tools/gemm_quick.py; done
       CFM_LIB_PATH=tools/probe/libcfm_gcfair.so timeout 120 python tools/gemm_quick.py
     } 2>&1 | tee gpurun_out/try_glds_v2.txt
     ;;
