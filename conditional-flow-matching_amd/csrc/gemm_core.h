@@ -43,6 +43,14 @@
 #ifndef GC_FAIR
 #define GC_FAIR 0
 #endif
+// GC_PIPE=1 (experiment, default 0; same bits): PIPELINED K-step boundary.  A K step ends with a barrier and the next one
+// starts with fragment reads nothing covers: the matrix pipe drains once per step (tools/probe/glds_probe.hip measured the
+// same pattern on the direct-to-LDS loop: 112.6 -> 125.5 TFLOP/s when it is removed).  Here the MFMAs of a step's LAST
+// fragment group are deferred: its fragments are in registers before the barrier, the MFMAs run right behind the next
+// step's first fragment reads.  Per output the k order is unchanged.
+#ifndef GC_PIPE
+#define GC_PIPE 0
+#endif
 typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gc_f32x2 __attribute__((ext_vector_type(2)));
 typedef float gc_f32x4 __attribute__((ext_vector_type(4)));
@@ -198,6 +206,7 @@ struct GemmCore {
 
     gc_f32x16 acc[M16 ? 1 : MT][M16 ? 1 : NT];
     gc_f32x4 acc16[2][2];
+    float pend_a[2][2], pend_b[2][2];       // GC_PIPE: fragments of the deferred group (two k-pairs / k-quads x two blocks)
 
     __device__ __forceinline__ void zero() {
         if (M16) {
@@ -224,7 +233,9 @@ struct GemmCore {
     // SIMD (one 128 x 64 tile per CU at the C3 layer shapes) then spends the step issuing MFMAs back to back: the
     // stores / loads go out in the 64-cycle shadows of the matrix pipe.  Fragment reads run two k-pair groups ahead
     // (a group = two k-pairs = one ds_read2 per operand = 2 MT NT MFMAs).
-    template <bool NEXT, typename OA, typename OB, typename FetchA, typename FetchB>
+    // PEND_IN: the deferred group of the PREVIOUS step is computed first, behind this step's first fragment reads;
+    // PEND_OUT: this step's last group is deferred (its fragments go to pend_a / pend_b).  Both false: the plain step.
+    template <bool NEXT, bool PEND_IN, bool PEND_OUT, typename OA, typename OB, typename FetchA, typename FetchB>
     __device__ __forceinline__ void step(const float* __restrict__ As, const float* __restrict__ Bs,
                                          float* __restrict__ An, float* __restrict__ Bn, OA& oa, OB& ob, FetchA fetch_a,
                                          FetchB fetch_b) {
@@ -252,15 +263,30 @@ struct GemmCore {
             rd(0); rd(1);
             if (NG > 1) { rd(2); rd(3); }
             __builtin_amdgcn_sched_barrier(0);
+            if (PEND_IN) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int nn = 0; nn < 2; ++nn)
+                            acc16[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(pend_a[h][m], pend_b[h][nn], acc16[m][nn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                mm(2 * g);
+                const bool defer = PEND_OUT && g == NG - 1;
+                if (!defer) mm(2 * g);
                 if (NEXT && g == 0) { oa.stash(An); if (GC_FETCH_MODE == 2) fetch_a(); }
                 if (NEXT && g == 1) ob.stash(Bn);
                 if (NEXT && NG == 1 && g == 0) ob.stash(Bn);
                 if (NEXT && GC_FETCH_MODE == 2 && g == (NG > 1 ? 1 : 0)) fetch_b();
                 if (NEXT && GC_FETCH_MODE != 2 && g == (GC_FETCH_MODE == 1 ? (NG > 1 ? 1 : 0) : (NG > 2 ? 2 : NG - 1))) { fetch_a(); fetch_b(); }
-                mm(2 * g + 1);
+                if (!defer) mm(2 * g + 1);
+                else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { pend_a[h][0] = a[2 * g + h][0]; pend_a[h][1] = a[2 * g + h][1]; pend_b[h][0] = b[2 * g + h][0]; pend_b[h][1] = b[2 * g + h][1]; }
+                }
                 if (g + 2 < NG) { rd(2 * g + 4); rd(2 * g + 5); }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -287,8 +313,29 @@ struct GemmCore {
         rd(0); rd(1);
         if (NG > 1) { rd(2); rd(3); }
         __builtin_amdgcn_sched_barrier(0);
+        if (PEND_IN) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn)
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(pend_a[h][m], pend_b[h][nn], acc[m][nn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
+            if (PEND_OUT && g == NG - 1) {       // deferred: the fragments wait in registers for the next step (nothing else is scheduled in the last group when NG >= 4)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { pend_a[h][0] = a[2 * g + h][0]; pend_a[h][1] = a[2 * g + h][1]; pend_b[h][0] = b[2 * g + h][0]; pend_b[h][1] = b[2 * g + h][1]; }
+                if (NEXT && !(GC_DBG & 2) && g == 0) { oa.stash(An); if (GC_FETCH_MODE == 2) fetch_a(); }
+                if (NEXT && !(GC_DBG & 2) && g == 1) ob.stash(Bn);
+                if (NEXT && !(GC_DBG & 2) && NG == 1 && g == 0) ob.stash(Bn);
+                if (NEXT && !(GC_DBG & 1) && GC_FETCH_MODE == 2 && g == (NG > 1 ? 1 : 0)) fetch_b();
+                if (NEXT && !(GC_DBG & 1) && GC_FETCH_MODE != 2 && g == (GC_FETCH_MODE == 1 ? (NG > 1 ? 1 : 0) : (NG > 2 ? 2 : NG - 1))) { fetch_a(); fetch_b(); }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             mm((GC_DBG & 4) ? 0 : 2 * g);
             if (NEXT && !(GC_DBG & 2) && g == 0) { oa.stash(An); if (GC_FETCH_MODE == 2) fetch_a(); }
             if (NEXT && !(GC_DBG & 2) && g == 1) ob.stash(Bn);
@@ -323,13 +370,31 @@ struct GemmCore {
         // accumulator file on entry AND exit of every K step (64 + 64 v_accvgpr moves per step at 128 x 128:
         // tools/isa_report.py), a quarter of the step's issue slots with the matrix pipe idle behind them.
         int k0 = k_begin;
+        // GC_PIPE: the deferred group needs a fragment group to itself (NG >= 2 groups per step: every tile shape in use)
+        constexpr bool PIPE_BODY = GC_PIPE && ((M16 ? BK / 8 : BK / 4) >= 2);
+#if GC_PIPE
+        if (PIPE_BODY) {
+            if (k0 + BK < k_end) {                   // the first step: nothing deferred comes in, its last group goes out
+                float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
+                post(Ac, k0);
+                step<true, false, true>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob,
+                           [&]() { if (k0 + 2 * BK < k_end) { oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); pre.a(oa, k0 + 2 * BK); } },
+                           [&]() { if (k0 + 2 * BK < k_end) { ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end); pre.b(ob, k0 + 2 * BK); } });
+                __syncthreads();
+                st ^= 1; k0 += BK;
+            } else {                                 // a single step: the deferred group that comes in is all zeros (adds + 0 to + 0)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { pend_a[h][0] = pend_a[h][1] = 0.f; pend_b[h][0] = pend_b[h][1] = 0.f; }
+            }
+        }
+#endif
         for (; k0 + BK < k_end; k0 += BK) {
             float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
             post(Ac, k0);
 #if GC_FAIR
             if (((blockIdx.x >> 8) ^ (unsigned)((k0 - k_begin) / BK)) & 1u) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0");
 #endif
-            step<true>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob,
+            step<true, PIPE_BODY, PIPE_BODY>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob,
                        [&]() { if (k0 + 2 * BK < k_end) { oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); pre.a(oa, k0 + 2 * BK); } },
                        [&]() { if (k0 + 2 * BK < k_end) { ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end); pre.b(ob, k0 + 2 * BK); } });
             if (!(GC_DBG & 8)) __syncthreads();
@@ -341,7 +406,7 @@ struct GemmCore {
 #if GC_FAIR
             asm volatile("s_setprio 0");
 #endif
-            step<false>(Ac, Bc, nullptr, nullptr, oa, ob, []() {}, []() {});
+            step<false, PIPE_BODY, false>(Ac, Bc, nullptr, nullptr, oa, ob, []() {}, []() {});
         }
     }
 

@@ -14,6 +14,8 @@ case "$1" in
     bash "$R/tools/probe/build_variant_all.sh" gv2nofair "-DCOST_GLDS_V2=1 -DCOST_GLDS_FAIR=0" cost
     bash "$R/tools/probe/build_variant_all.sh" gv2plain "-DCOST_GLDS_V2=1 -DCOST_GLDS_FAIR=0 -DCOST_GLDS_LOOP=0" cost
     bash "$R/tools/probe/build_variant_all.sh" gcfair "-DGC_FAIR=1" cost mlp mlp_train      # the register-staged core with alternating priority
+    bash "$R/tools/probe/build_variant_all.sh" gcpipe "-DGC_PIPE=1" cost mlp mlp_train ode   # ... with the pipelined K-step boundary (same bits by construction)
+    bash "$R/tools/probe/build_variant_all.sh" gcpipefair "-DGC_PIPE=1 -DGC_FAIR=1" cost mlp mlp_train ode
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off "$R/tools/probe/glds_probe.hip" -o "$R/tools/probe/glds_probe"
     ;;
   run)
@@ -29,7 +31,9 @@ case "$1" in
       echo "== timings (C3 shapes)"
       timeout 120 python tools/gemm_quick.py
       for V in gv2 gv2nofair gv2plain; do CFM_COST_GLDS=1 CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 120 python tools/gemm_quick.py; done
-      CFM_LIB_PATH=tools/probe/libcfm_gcfair.so timeout 120 python tools/gemm_quick.py
+      for V in gcfair gcpipe gcpipefair; do CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 120 python tools/gemm_quick.py; done
+      echo "== the dense-product tests on the pipelined register-staged core (bit-exactness against the references they hold)"
+      CFM_LIB_PATH=tools/probe/libcfm_gcpipe.so timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_train.py tests/test_gpu_glds.py tests/test_gpu_fullsize.py tests/test_gpu_golden.py tests/test_gpu_round2.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3
     } 2>&1 | tee gpurun_out/try_glds_v2.txt
     ;;
   *) echo "usage: $0 build | run"; exit 2;;
