@@ -32,6 +32,8 @@ case "$1" in
       timeout 120 python tools/gemm_quick.py
       for V in gv2 gv2nofair gv2plain; do CFM_COST_GLDS=1 CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 120 python tools/gemm_quick.py; done
       for V in gcfair gcpipe gcpipefair; do CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 120 python tools/gemm_quick.py; done
+      # the layers on 128 x 64 tiles (one workgroup per CU: the lone-wave regime the pipelined boundary helps most)
+      CFM_GEMM_TILE=1 timeout 120 python tools/gemm_quick.py; CFM_GEMM_TILE=1 CFM_LIB_PATH=tools/probe/libcfm_gcpipe.so timeout 120 python tools/gemm_quick.py
       echo "== the dense-product tests on the pipelined register-staged core (bit-exactness against the references they hold)"
       CFM_LIB_PATH=tools/probe/libcfm_gcpipe.so timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_train.py tests/test_gpu_glds.py tests/test_gpu_fullsize.py tests/test_gpu_golden.py tests/test_gpu_round2.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3
     } 2>&1 | tee gpurun_out/try_glds_v2.txt
