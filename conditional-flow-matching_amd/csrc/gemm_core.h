@@ -45,7 +45,8 @@
 #endif
 // GC_PIPE=1 (experiment, default 0; same bits): PIPELINED K-step boundary.  A K step ends with a barrier and the next one
 // starts with fragment reads nothing covers: the matrix pipe drains once per step (tools/probe/glds_probe.hip measured the
-// same pattern on the direct-to-LDS loop: 112.6 -> 125.5 TFLOP/s when it is removed).  Here the MFMAs of a step's LAST
+// same pattern on the direct-to-LDS loop: 112.6 -> 125.5 TFLOP/s when it is removed in one form of that loop, no gain in
+// another — to be measured with interleaved repeats).  Here the MFMAs of a step's LAST
 // fragment group are deferred: its fragments are in registers before the barrier, the MFMAs run right behind the next
 // step's first fragment reads.  Per output the k order is unchanged.
 #ifndef GC_PIPE

@@ -218,7 +218,8 @@ __device__ __forceinline__ void gl_run_padded(GldsCore& g, float* __restrict__ l
 }
 
 // The same loop with a PIPELINED K-step boundary (tools/probe/glds_probe.hip: glds_pipe; 4096 x 4096 x 3136, two workgroups
-// per CU: 112.6 -> 125.5 TFLOP/s, checked): gl_run_padded drains the matrix pipe at every K step — wait, barrier, DMA
+// per CU: 112.6 -> 125.5 TFLOP/s in the probe's own form, 114.5 -> 113.9 in this one — same loop body, another process; the
+// chip's clock moves by 10 % with what ran before, so the gain is NOT established yet): gl_run_padded drains the matrix pipe at every K step — wait, barrier, DMA
 // issue, then eight fragment reads nothing covers.  Here the LAST k-quad of stage s is computed AFTER the barrier of step
 // s + 1: its fragments are in registers by then (the barrier only protects the LDS buffer), and its eight MFMAs cover the
 // first fragment reads of stage s + 1.  (Issuing the DMAs of stage s + 2 one behind each of those MFMAs was slower with two
