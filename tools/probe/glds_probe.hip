@@ -9,6 +9,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/probe/glds_probe.hip -o tools/probe/glds_probe
 //   tools/probe/glds_probe [M N K]          (default 4096 4096 3136: the asymptotic shape of profiles/r4_gemm_probes.txt)
+//   tools/probe/glds_probe ab [rounds [M N K]]   interleaved A/B of every uninstrumented loop, with each launch's core clock
 //   tools/probe/glds_probe padded           the header's second-generation loop (gl_run_padded) on padded operands, checked
 //
 // Per variant: time, TFLOP/s, and (instrumented builds) the share of a wave's lifetime spent in the vmcnt wait and in the
@@ -19,12 +20,19 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#include <functional>
 #include "../../conditional-flow-matching_amd/csrc/gemm_glds.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 __device__ __forceinline__ unsigned long long pr_clk() { return __builtin_readcyclecounter(); }      // s_memtime
 __device__ __forceinline__ unsigned long long pr_rt() { return wall_clock64(); }                     // s_memrealtime: 100 MHz
+
+// one lane of the launch stamps both clocks at the start and at the end of its K loop: the effective core clock of THIS launch
+// (s_memtime ticks per 10 ns of s_memrealtime) without instrumenting the loop
+__device__ __forceinline__ void pr_stamp(unsigned long long* clk, int which) {
+    if (clk && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { clk[2 * which] = pr_clk(); clk[2 * which + 1] = pr_rt(); }
+}
 
 template <int NST> __device__ __forceinline__ void pr_wait_vm(bool later_stages_in_flight) {
     // DMAs complete in order: with NST - 2 younger stages (8 DMAs per wave each) behind the one needed, vmcnt may stay
@@ -95,7 +103,9 @@ __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__
     FastDma fd;
     if (FAST) fd.bind(K, row0, K, col0, lds); else g.bind(A, K, row0, M, B, K, col0, N);
     unsigned long long t_vm = 0, t_bar = 0, t_start = 0, r_start = 0;
+    unsigned long long* const clk = STATS ? nullptr : stats + (size_t)gridDim.x * 32;      // (behind the per-wave records)
     if (STATS) { t_start = pr_clk(); r_start = pr_rt(); }
+    pr_stamp(clk, 0);
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
         if (s * GL_BK < K) { if (FAST) fd.issue(A + s * GL_BK, B + s * GL_BK, s); else g.issue(lds, s, s * GL_BK, K, zeros); }
@@ -118,6 +128,7 @@ __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__
         st = st + 1 == NST ? 0 : st + 1;
         nx = nx + 1 == NST ? 0 : nx + 1;
     }
+    pr_stamp(clk, 1);
     if (STATS) {
         const unsigned long long t_all = pr_clk() - t_start, r_all = pr_rt() - r_start;
         if ((threadIdx.x & 63) == 0) {
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256, WPC) void glds_probe(const float* __restrict__
 struct PipeFrag { float4 a0, a1, b0, b1; };
 template <int WPC, bool ILV, bool FAIR>
 __global__ __launch_bounds__(256, WPC) void glds_pipe(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int K,
-                                                     float* __restrict__ C, int tiles_m, int tiles_n) {
+                                                     float* __restrict__ C, int tiles_m, int tiles_n, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
@@ -195,6 +206,7 @@ __global__ __launch_bounds__(256, WPC) void glds_pipe(const float* __restrict__ 
         g.acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b11, g.acc[1][1], 0, 0, 0); dma(7);
     };
     auto none = [](int) {};
+    pr_stamp(clk, 0);
     fd.issue(A, B, 0);
     if (nsteps > 1) { fd.issue(A + GL_BK, B + GL_BK, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(256, WPC) void glds_pipe(const float* __restrict__ 
         mm(t, none);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may outlive the workgroup's LDS allocation
+    pr_stamp(clk, 1);
     if (FAIR) asm volatile("s_setprio 0");
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(256) void mfma_only(float* out, int iters, const fl
 // the header's second-generation loop (gl_run_padded) on padded operands: any M, N, K
 template <bool FAIR, bool PIPE>
 __global__ __launch_bounds__(256, 2) void glds_padded(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int Kp,
-                                                      float* __restrict__ C, int tiles_m, int tiles_n) {
+                                                      float* __restrict__ C, int tiles_m, int tiles_n, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
@@ -306,8 +319,10 @@ __global__ __launch_bounds__(256, 2) void glds_padded(const float* __restrict__ 
     const int row0 = tm * GL_BM, col0 = tn * GL_BN;
     GldsCore g;
     g.zero();
+    pr_stamp(clk, 0);
     if (PIPE) gl_run_padded_pipe(g, lds, A, Kp, row0, M, B, Kp, col0, N, Kp, FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
     else gl_run_padded(g, lds, A, Kp, row0, M, B, Kp, col0, N, Kp, FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
+    pr_stamp(clk, 1);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -340,10 +355,10 @@ static int run_padded(int M, int N, int K) {
     for (int var = 0; var < 4; ++var) {
         const int fair = var & 1, pipe = var >> 1;
         auto launch = [&]() {
-            if (pipe) { if (fair) hipLaunchKernelGGL((glds_padded<true, true>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn);
-                        else hipLaunchKernelGGL((glds_padded<false, true>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn); }
-            else { if (fair) hipLaunchKernelGGL((glds_padded<true, false>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn);
-                   else hipLaunchKernelGGL((glds_padded<false, false>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn); }
+            if (pipe) { if (fair) hipLaunchKernelGGL((glds_padded<true, true>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn, (unsigned long long*)nullptr);
+                        else hipLaunchKernelGGL((glds_padded<false, true>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn, (unsigned long long*)nullptr); }
+            else { if (fair) hipLaunchKernelGGL((glds_padded<true, false>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn, (unsigned long long*)nullptr);
+                   else hipLaunchKernelGGL((glds_padded<false, false>), dim3(tm * tn), dim3(256), GL_LDS_BYTES, 0, A, B, M, N, Kp, C, tm, tn, (unsigned long long*)nullptr); }
         };
         CK(hipMemset(C, 0xff, (size_t)M * N * 4));
         launch(); launch(); CK(hipDeviceSynchronize());
@@ -449,7 +464,7 @@ static int run_pipe(Ctx& c, const char* label) {
     auto kern = glds_pipe<WPC, ILV, FAIR>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     const int grid = c.tm * c.tn;
-    auto launch = [&]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn); };
+    auto launch = [&]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn, (unsigned long long*)nullptr); };
     CK(hipMemset(c.C, 0xff, (size_t)c.M * c.N * 4));
     launch(); launch(); CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -473,6 +488,64 @@ static int run_pipe(Ctx& c, const char* label) {
     return worst < 1e-4 ? 0 : 2;
 }
 
+// Interleaved A/B of the uninstrumented loops: every variant is timed `rounds` times, round-robin, so that the chip's power
+// state (its clock moves by 10 % with what ran before: run F of profiles/r4_glds_probe.txt) hits all of them alike.
+// Per variant: median / min / max of the launch time, TFLOP/s of the median, median core clock of the stamped launches.
+struct AbVar { const char* label; std::function<void()> launch; std::vector<double> us, ghz; };
+static int run_ab(Ctx& c, int rounds) {
+    if (c.M % GL_BM || c.N % GL_BN || c.K % GL_BK) { printf("ab: M, N, K must be multiples of the tile\n"); return 1; }
+    const int grid = c.tm * c.tn;
+    unsigned long long* clk = c.stats + (size_t)grid * 32;
+    const size_t l2 = GL_LDS_BYTES;
+    std::vector<AbVar> v;
+#define AB_ATTR(K_) CK(hipFuncSetAttribute((const void*)(K_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2))
+    {
+        auto k0 = glds_probe<0, 2, 2, false>;             AB_ATTR(k0);
+        auto k1 = glds_probe<0, 2, 2, false, true>;       AB_ATTR(k1);
+        auto k2 = glds_probe<0, 2, 2, false, true, true>; AB_ATTR(k2);
+        auto k3 = glds_pipe<2, false, false>;             AB_ATTR(k3);
+        auto k4 = glds_pipe<2, false, true>;              AB_ATTR(k4);
+        auto k5 = glds_pipe<2, true, false>;              AB_ATTR(k5);
+        auto k6 = glds_padded<false, false>;              AB_ATTR(k6);
+        auto k7 = glds_padded<true, false>;               AB_ATTR(k7);
+        auto k8 = glds_padded<false, true>;               AB_ATTR(k8);
+        auto k9 = glds_padded<true, true>;                AB_ATTR(k9);
+        v.push_back({"builtin DMAs (the engine as the product has it)", [=, &c]() { hipLaunchKernelGGL(k0, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.zeros, c.C, c.stats, c.tm, c.tn); }});
+        v.push_back({"assembly DMAs", [=, &c]() { hipLaunchKernelGGL(k1, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.zeros, c.C, c.stats, c.tm, c.tn); }});
+        v.push_back({"assembly DMAs + alternating s_setprio", [=, &c]() { hipLaunchKernelGGL(k2, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.zeros, c.C, c.stats, c.tm, c.tn); }});
+        v.push_back({"pipelined boundary (probe form)", [=, &c]() { hipLaunchKernelGGL(k3, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn, clk); }});
+        v.push_back({"pipelined boundary + alternating s_setprio", [=, &c]() { hipLaunchKernelGGL(k4, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn, clk); }});
+        v.push_back({"pipelined boundary, DMAs between the MFMAs", [=, &c]() { hipLaunchKernelGGL(k5, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn, clk); }});
+        v.push_back({"header: gl_run_padded", [=, &c]() { hipLaunchKernelGGL(k6, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn, clk); }});
+        v.push_back({"header: gl_run_padded + alternating s_setprio", [=, &c]() { hipLaunchKernelGGL(k7, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn, clk); }});
+        v.push_back({"header: gl_run_padded_pipe", [=, &c]() { hipLaunchKernelGGL(k8, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn, clk); }});
+        v.push_back({"header: gl_run_padded_pipe + alternating s_setprio", [=, &c]() { hipLaunchKernelGGL(k9, dim3(grid), dim3(256), l2, 0, c.A, c.B, c.M, c.N, c.K, c.C, c.tm, c.tn, clk); }});
+    }
+#undef AB_ATTR
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto& x : v) { x.launch(); x.launch(); }
+    CK(hipDeviceSynchronize());
+    const int reps = 4;
+    for (int r = 0; r < rounds; ++r)
+        for (auto& x : v) {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < reps; ++i) x.launch();
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long h[4]; CK(hipMemcpy(h, clk, 32, hipMemcpyDeviceToHost));
+            x.us.push_back(ms / reps * 1e3);
+            x.ghz.push_back((double)(h[2] - h[0]) / ((double)(h[3] - h[1]) * 10.0));
+        }
+    printf("interleaved A/B, %d rounds of %d launches per variant (%d x %d x %d):\n", rounds, reps, c.M, c.N, c.K);
+    for (auto& x : v) {
+        std::sort(x.us.begin(), x.us.end()); std::sort(x.ghz.begin(), x.ghz.end());
+        const double med = x.us[x.us.size() / 2];
+        printf("  %-52s median %7.1f us (%7.1f .. %7.1f)  %6.1f TFLOP/s   clock %5.3f GHz (%5.3f .. %5.3f)\n", x.label, med, x.us.front(), x.us.back(),
+               2.0 * c.M * c.N * c.K / (med * 1e-6) / 1e12, x.ghz[x.ghz.size() / 2], x.ghz.front(), x.ghz.back());
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "padded")) {      // glds_probe padded: the header's gl_run_padded on three shapes
         int rc = run_padded(4096, 4096, 784);          // C3
@@ -484,20 +557,24 @@ int main(int argc, char** argv) {
         return rc;
     }
     Ctx c;
+    const bool ab = argc > 1 && !strcmp(argv[1], "ab");              // glds_probe ab [rounds [M N K]]
+    const int ab_rounds = (ab && argc > 2) ? atoi(argv[2]) : 7;
+    if (ab) { const int shift = argc > 2 ? 2 : 1; argc -= shift; argv += shift; }      // what follows: [M N K]
     c.M = argc > 3 ? atoi(argv[1]) : 4096; c.N = argc > 3 ? atoi(argv[2]) : 4096; c.K = argc > 3 ? atoi(argv[3]) : 3136;
     if (c.K % 4) { printf("K must be a multiple of 4 (16-byte DMA pieces)\n"); return 1; }
     c.tm = (c.M + GL_BM - 1) / GL_BM; c.tn = (c.N + GL_BN - 1) / GL_BN;
-    c.hA.resize((size_t)c.M * c.K); c.hB.resize((size_t)c.N * c.K);
+    c.hA.assign((size_t)(c.M + 1) * c.K, 0.f); c.hB.assign((size_t)(c.N + 1) * c.K, 0.f);      // (one more row of zeros: the padded layout)
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
-    for (auto& v : c.hA) v = rnd();
-    for (auto& v : c.hB) v = rnd();
+    for (size_t i = 0; i < (size_t)c.M * c.K; ++i) c.hA[i] = rnd();
+    for (size_t i = 0; i < (size_t)c.N * c.K; ++i) c.hB[i] = rnd();
     CK(hipMalloc(&c.A, c.hA.size() * 4)); CK(hipMalloc(&c.B, c.hB.size() * 4)); CK(hipMalloc(&c.C, (size_t)c.M * c.N * 4));
     CK(hipMalloc(&c.zeros, 256)); CK(hipMemset(c.zeros, 0, 256));
-    CK(hipMalloc(&c.stats, (size_t)c.tm * c.tn * 32 * 8));
+    CK(hipMalloc(&c.stats, ((size_t)c.tm * c.tn * 32 + 8) * 8));
     CK(hipMemcpy(c.A, c.hA.data(), c.hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(c.B, c.hB.data(), c.hB.size() * 4, hipMemcpyHostToDevice));
     printf("glds_probe: C[%d x %d] = A[%d x %d] . B[%d x %d]^T, %d tiles of 128 x 128, K steps of %d\n", c.M, c.N, c.M, c.K, c.N, c.K, c.tm * c.tn, GL_BK);
+    if (ab) return run_ab(c, ab_rounds);
     int rc = 0;
     rc |= run<0, 2, 2, false>(c, "product loop, 2 stages, 2 workgroups / CU", true);
     rc |= run<0, 2, 2, true>(c, "  the same, instrumented", false);

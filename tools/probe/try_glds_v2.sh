@@ -22,8 +22,9 @@ case "$1" in
     cd "$R"; mkdir -p gpurun_out
     {
       timeout 60 tools/probe/glds_probe padded
-      timeout 60 tools/probe/glds_probe            # incl. the pipelined K-step boundary (glds_pipe): written at the end of round 4, never run
-      timeout 60 tools/probe/glds_probe 4096 4096 800
+      timeout 60 tools/probe/glds_probe ab 9          # interleaved A/B of every loop, with each launch's clock: which gains are real?
+      timeout 60 tools/probe/glds_probe ab 9 4096 4096 800
+      timeout 60 tools/probe/glds_probe               # timelines and wait shares of the instrumented variants
       for V in gv2 gv2nofair gv2plain; do
         echo "== bit-equality with the default engine, variant $V"
         CFM_LIB_PATH=tools/probe/libcfm_$V.so timeout 300 python -m pytest tests/test_gpu_glds.py -q -x -p no:cacheprovider 2>&1 | tail -3
