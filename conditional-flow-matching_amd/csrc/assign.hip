@@ -1230,7 +1230,11 @@ __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds
 
 // ----------------------------------------------------------------- step ------
 // What the bidder count of the previous round means for the next one (epsilon phases, epsilon = 0 rounds, hand-over).
-__device__ __forceinline__ void auc_decide(AucCtl& C, const AsgState* st, int cnt, int n) {
+// (the parameter source is a template argument: the state block itself, or the snapshot of it asg_step takes with its
+//  first batch of loads when built with ASG_PREFETCH_CTL)
+struct AucParams { int round_cap, arr_cap; double theta, eps_last, stop_frac, stop_early; };
+template <typename S>
+__device__ __forceinline__ void auc_decide(AucCtl& C, const S* st, int cnt, int n) {
     C.row_scans += cnt;
     const int tag_next = (C.tag % 254) + 1;
     if (C.mode == MODE_AUCTION) {
@@ -1339,6 +1343,20 @@ __device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode
 // ONE wide kernel for every chip-wide step (modes UMIN0 .. CERT): the host replays it without knowing
 // which step comes next.  LDS (modes are exclusive): bid rounds — prices [n] fp64 + owner rows [n]
 // int; relax — 16 KiB of merge buffers; MS_FINISH — 2 n ints for the path walks; the rest < 8 KiB.
+#ifndef ASG_PREFETCH_CTL
+#define ASG_PREFETCH_CTL 0
+#endif
+// the first 128 bytes of AsgState (its line 0), read as one block
+struct AsgHead {
+    int mode, n, error, certified;
+    const float* Mptr;
+    int* out_perm; int* out_cert; double* out_cost; int* out_stats;
+    int tag, rb;
+    int round, phase, stop, arr_round, round_cap, arr_cap, sparse, handoff;
+    double eps, eps_last, theta, stop_frac;
+};
+static_assert(sizeof(AsgHead) == 128 && offsetof(AsgHead, rb) == offsetof(AsgState, rb) && offsetof(AsgHead, stop_frac) == offsetof(AsgState, stop_frac)
+              && offsetof(AsgHead, round_cap) == offsetof(AsgState, round_cap) && offsetof(AsgHead, Mptr) == offsetof(AsgState, Mptr), "AsgHead mirrors line 0 of AsgState");
 __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, size_t stride) {
     extern __shared__ __attribute__((aligned(16))) char step_lds[];
     const AsgWs w = asg_shift(w0, stride * blockIdx.y);
@@ -1376,23 +1394,61 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
         my_bc = w.bidcol[blockIdx.x + gridDim.x * threadIdx.x];
     uint2 pre_e = make_uint2(0xffffffffu, 0u); double pre_T = -INFINITY;       // the row's bid list (see bid_from_list)
     if (w.cl != nullptr && wave_gid < n_host) { pre_e = w.cl[(size_t)wave_gid * ASG_BL + lane]; pre_T = w.cT[wave_gid]; }
+#if ASG_PREFETCH_CTL
+#define ASG_STF(f) H.f
+#else
+#define ASG_STF(f) st->f
+#endif
+#if !ASG_PREFETCH_CTL
     int mode = st->mode;
     gfp M = ASG_GLOBAL(st->Mptr);
+#endif
+#if ASG_PREFETCH_CTL
+    // (experiment, default 0) the round's control record and all four bidder counters are requested with the first batch:
+    // as the code stands `C = ctl[par & 1]` waits for `mode`, and `bidcnt[(C.r - 1) & 3]` for C — two more dependent L2
+    // round trips on the critical path of every round.  ctl[par & 1] and bidcnt[(r - 1) & 3] were written by the previous
+    // launch and are not touched by this one (it writes ctl[(par & 1) ^ 1], zeroes slot (r + 1) & 3, adds to slot r & 3).
+    // ... and so does every field of the state block the round reads (mode, error, rb, the caps and factors auc_decide
+    // looks at): as the code stands each of them is its own dependent round trip (error after mode, round_cap after the
+    // bidder count, ...) — six in a typical round where one would do.
+    const AsgHead H = *reinterpret_cast<const AsgHead*>(st);
+    const double pre_stop_early = st->stop_early;
+    AucCtl preC = w.auc->ctl[par & 1];
+    int pre_cnt0 = asg_ld(&w.auc->bidcnt[0]), pre_cnt1 = asg_ld(&w.auc->bidcnt[1]);
+    int pre_cnt2 = asg_ld(&w.auc->bidcnt[2]), pre_cnt3 = asg_ld(&w.auc->bidcnt[3]);
+    asm volatile("" : "+v"(pre_cnt0), "+v"(pre_cnt1), "+v"(pre_cnt2), "+v"(pre_cnt3) :: "memory");
+    int mode = H.mode;
+    gfp M = ASG_GLOBAL(H.Mptr);
+    const AucParams AP{H.round_cap, H.arr_cap, H.theta, H.eps_last, H.stop_frac, pre_stop_early};
+#endif
     asm volatile("" : "+v"(pre_bc), "+v"(pre_bc1), "+v"(pre_bc2), "+v"(pre_bc3), "+v"(my_bc), "+v"(pre_e.x), "+v"(pre_T), "+v"(kst[0].x), "+v"(kst[KP - 1].x) : "s"(mode) : "memory");   // all of it in flight
-    if (mode > MODE_CERT || st->error) return;
+    if (mode > MODE_CERT || ASG_STF(error)) return;
     const int n = n_host;
     unsigned payload = 0;
     // bid rounds: every workgroup decides for itself what this launch is (see AucCtl)
     AucCtl C;
     const bool bidding = (mode == MODE_AUCTION || mode == MODE_ARR);
     if (bidding) {
+#if ASG_PREFETCH_CTL
+        C = preC;
+#else
         C = w.auc->ctl[par & 1];
+#endif
         if (C.r > 0) {
             // bidders of the previous round in the low 16 bits, those served from their lists above (lists: n <= SP_NMAX)
+#if ASG_PREFETCH_CTL
+            const int sl = (C.r - 1) & 3;
+            const int raw = sl == 0 ? pre_cnt0 : sl == 1 ? pre_cnt1 : sl == 2 ? pre_cnt2 : pre_cnt3;
+#else
             const int raw = asg_ld(&w.auc->bidcnt[(C.r - 1) & 3]);
+#endif
             const bool lists = (w.cl != nullptr);
             const int nl = lists ? (raw >> 16) : 0;
+#if ASG_PREFETCH_CTL
+            auc_decide(C, &AP, lists ? (raw & 0xffff) : raw, n);
+#else
             auc_decide(C, st, lists ? (raw & 0xffff) : raw, n);
+#endif
             C.pad[0] += nl;          // row_scans: the bids (row evaluations); pad[0]: those served from the list (512 bytes each)
         }
         mode = C.mode;
@@ -1414,7 +1470,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
     if (mode == MODE_AUCTION || mode == MODE_ARR) {
         double* p_lds = reinterpret_cast<double*>(step_lds);
         int* r_lds = reinterpret_cast<int*>(step_lds + (size_t)((n + 1) & ~1) * sizeof(double));
-        const double eps = C.eps; const int tag = C.tag, rb = st->rb;
+        const double eps = C.eps; const int tag = C.tag, rb = ASG_STF(rb);
         const int rnd = (mode == MODE_ARR) ? min(C.arr_round + 1, (1 << ASG_RND_BITS) - 1) : 0;
         if (threadIdx.x == 0) { sh[0] = 0; sh[1] = 0; }
         if (stage_p) {

@@ -16,6 +16,9 @@ case "$1" in
     bash "$R/tools/probe/build_variant_all.sh" gcfair "-DGC_FAIR=1" cost mlp mlp_train      # the register-staged core with alternating priority
     bash "$R/tools/probe/build_variant_all.sh" gcpipe "-DGC_PIPE=1" cost mlp mlp_train ode   # ... with the pipelined K-step boundary (same bits by construction)
     bash "$R/tools/probe/build_variant_all.sh" gcpipefair "-DGC_PIPE=1 -DGC_FAIR=1" cost mlp mlp_train ode
+    # the bid rounds with the state block, the control record and the bidder counters in the FIRST batch of loads (assign.hip:
+    # ASG_PREFETCH_CTL; the default code spends ~6 dependent round trips on them per round where one would do)
+    bash "$R/tools/probe/build_variant_all.sh" asgpf "-DASG_PREFETCH_CTL=1" assign
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off "$R/tools/probe/glds_probe.hip" -o "$R/tools/probe/glds_probe"
     ;;
   run)
@@ -39,5 +42,17 @@ case "$1" in
       CFM_LIB_PATH=tools/probe/libcfm_gcpipe.so timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_train.py tests/test_gpu_glds.py tests/test_gpu_fullsize.py tests/test_gpu_golden.py tests/test_gpu_round2.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3
     } 2>&1 | tee gpurun_out/try_glds_v2.txt
     ;;
-  *) echo "usage: $0 build | run"; exit 2;;
+  run2)
+    # second call: the exact solver with ASG_PREFETCH_CTL — its tests, then solve_ms / avg_launch_us / ms_per_step next to the product's
+    cd "$R"; mkdir -p gpurun_out
+    {
+      CFM_LIB_PATH=tools/probe/libcfm_asgpf.so timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_assign_batch.py tests/test_gpu_fullsize.py tests/test_gpu_round2.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3
+      for L in "" tools/probe/libcfm_asgpf.so; do
+        CFM_LIB_PATH=$L timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']
+print('$L' or 'product', 'ms_per_step', round(d['ms_per_step'],4), 'seq', round(d['ms_per_step_sequential'],3), 'solve_ms', round(r['solve_ms'],3), 'avg_launch_us', round(r['avg_launch_us'],2), 'steady', round(d['steady_state']['ms_per_step'],4))"
+      done
+    } 2>&1 | tee gpurun_out/try_asgpf.txt
+    ;;
+  *) echo "usage: $0 build | run | run2"; exit 2;;
 esac
