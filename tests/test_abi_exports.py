@@ -68,3 +68,21 @@ def test_tuning_header_lists_every_extra_export(lib_built):
     for n in names:
         assert hasattr(lib, n), n
     assert not set(names) & set(_declared())
+
+
+def test_experiment_switches_are_off_in_the_product_build():
+    """Every compile-time experiment of the kernels (prepared, not yet measured) defaults to 0 — the product
+    library is built without any -D flag (csrc/build.sh) — except the two that only select WHICH experimental loop a
+    COST_GLDS_V2 build takes."""
+    csrc = os.path.join(ROOT, "conditional-flow-matching_amd", "csrc")
+    want = {"gemm_core.h": {"GC_FAIR": "0", "GC_PIPE": "0", "GC_DBG": "0", "GC_FETCH_MODE": "0"},
+            "cost.hip": {"COST_GLDS_V2": "0"}, "assign.hip": {"ASG_PREFETCH_CTL": "0"}, "gemm_glds.h": {"GL_DBG": "0"}}
+    for fname, macros in want.items():
+        src = open(os.path.join(csrc, fname)).read()
+        for name, val in macros.items():
+            m = re.search(r"#ifndef %s\s*\n#define %s (\S+)" % (name, name), src)
+            assert m and m.group(1) == val, (fname, name, m and m.group(1))
+    build = open(os.path.join(csrc, "build.sh")).read()
+    assert "-D" not in build.replace("$CFM_EXTRA_FLAGS", "")
+    r = __import__("subprocess").run(["bash", "-n", os.path.join(ROOT, "tools", "probe", "try_glds_v2.sh")], capture_output=True)
+    assert r.returncode == 0, r.stderr
