@@ -154,37 +154,59 @@ def timed_region(D, sync, pool, warmup, steps, couple, model_step, draw, prefetc
 
 
 # --------------------------------------------------------------------------- side legs (rank 0, N = 1)
-def sinkhorn_leg(dev, cfg, reg, iters=200):
-    """Sinkhorn iterations/s (one iteration = one g-update + one f-update = two LSE passes over M).
+def _sk_state(r):
+    """The solver's own state block after a solve (first 48 bytes of its workspace: csrc/sinkhorn.hip SkState)."""
+    s = r.ws[:48].cpu()
+    i, d = s[:16].view(torch.int32), s[16:48].view(torch.float64)
+    return {"iters_done": int(i[1]), "fp64_exp_engaged": bool(int(i[3])), "last_err": float(d[2])}
+
+
+def _sk_windows(fn, iters, nwin):
+    """nwin timed windows of `iters` iterations each (HIP events on the current stream), after a first-touch pass; every
+    window with the solver's state after it — a slow window can then be told from a regime switch (the kernels move to
+    fp64 exp once the marginal violation nears the fp32 noise floor) or an early stop."""
+    fn(20); torch.cuda.synchronize()
+    out = []
+    for _ in range(nwin):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = fn(iters); e1.record(); torch.cuda.synchronize()
+        st = _sk_state(r)
+        out.append({"ms": e0.elapsed_time(e1), **st})
+    return out
+
+
+def sinkhorn_leg(dev, cfg, reg, iters=200, nwin=7):
+    """Sinkhorn iterations/s (one iteration = one g-update + one f-update = two LSE passes over M): the MEDIAN of `nwin`
+    windows of `iters` iterations, every window in the line with the iterations it really ran and whether the fp64-exp
+    regime engaged; on its own stream (the legacy default stream joins with whatever the earlier legs left behind).
     d <= 8 (C2) is measured on the solver OTPlanSampler takes there — variant B, the cost entry recomputed on
     the fly, no B^2 traffic — and reported against the SAME algorithmic bytes, labelled; the
     matrix-streaming solver's rate on the same input is kept next to it."""
     import cfm_amd.optimal_transport as ot
     import cfm_oracle as oracle
     x0, x1 = oracle.config_inputs(cfg)
-    a, b = x0.to(dev), x1.to(dev)
-    M = ot.cost_matrix(a, b)
     points = x0.shape[1] <= 8
+    with torch.cuda.stream(torch.cuda.Stream()):
+        a, b = x0.to(dev), x1.to(dev)
+        M = ot.cost_matrix(a, b)
+        win_stream = _sk_windows(lambda n: ot.sinkhorn_log(M, reg, max_iter=n, stop_thr=0.0), iters, nwin)
+        win = _sk_windows(lambda n: ot.sinkhorn_log_points(a, b, M, reg, max_iter=n, stop_thr=0.0), iters, nwin) if points else win_stream
+        torch.cuda.synchronize()
 
-    def timed(fn):
-        fn(20)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(iters); e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1)
-    ms_stream = timed(lambda n: ot.sinkhorn_log(M, reg, max_iter=n, stop_thr=0.0))
-    ms = timed(lambda n: ot.sinkhorn_log_points(a, b, M, reg, max_iter=n, stop_thr=0.0)) if points else ms_stream
+    def rate(ws):          # iterations really run / time, window by window; then the median
+        return float(np.median([w["iters_done"] / (w["ms"] * 1e-3) for w in ws]))
+    its, its_stream = rate(win), rate(win_stream)
+    rates = [w["iters_done"] / (w["ms"] * 1e-3) for w in win]
     B0, B1 = M.shape
     per_iter_bytes = 2 * 4 * B0 * B1 + 16 * B0
-    gbs = per_iter_bytes * iters / (ms * 1e-3) / 1e9
+    gbs = per_iter_bytes * its / 1e9
     note = ("2 LSE passes over the fp32 cost matrix per iteration; the %d MiB matrix is %s" %
             (4 * B0 * B1 >> 20, "Infinity-Cache resident (256 MiB)" if 4 * B0 * B1 <= (200 << 20) else "HBM streamed"))
     if points:
         note = ("variant B: the cost entry is recomputed from the coordinates inside both LSE passes, so NO matrix "
                 "bytes move; achieved = the algorithmic 2 x 4 x B^2 bytes per iteration / time (it may exceed the "
                 "HBM peak: it is an equivalent rate, the kernel is VALU / exp bound); matrix-streaming solver on the "
-                "same input: %.0f it/s" % (iters / (ms_stream * 1e-3)))
+                "same input: %.0f it/s" % its_stream)
     # HBM bytes per iteration from the committed counter passes (profiles/rNN_sk_pmc_summary.json: rocprofv3 --pmc
     # FETCH_SIZE x2 + WRITE_SIZE over tools/sk_probe.py), next to the algorithmic figure
     traffic = None
@@ -194,9 +216,14 @@ def sinkhorn_leg(dev, cfg, reg, iters=200):
         traffic_stream = pmc.get(f"{cfg}_streaming_hbm_bytes_per_iteration")
     except Exception:  # noqa: BLE001
         traffic_stream = None
-    return {"config": f"{cfg}: B={B0}, d={x0.shape[1]}, eps={reg}", "sinkhorn_iters_per_s": iters / (ms * 1e-3),
-            "ms_per_iter": ms / iters, "variant": "points (on-the-fly cost)" if points else "matrix streaming",
-            "sinkhorn_iters_per_s_matrix_streaming": iters / (ms_stream * 1e-3),
+    return {"config": f"{cfg}: B={B0}, d={x0.shape[1]}, eps={reg}", "sinkhorn_iters_per_s": its,
+            "ms_per_iter": 1e3 / its, "variant": "points (on-the-fly cost)" if points else "matrix streaming",
+            "windows": len(win), "iters_per_window": iters,
+            "iters_per_s_all": [round(x, 1) for x in rates], "spread_rel": (max(rates) - min(rates)) / its,
+            "iters_done_all": [w["iters_done"] for w in win],
+            "fp64_exp_engaged_all": [w["fp64_exp_engaged"] for w in win], "last_err": win[-1]["last_err"],
+            "sinkhorn_iters_per_s_matrix_streaming": its_stream,
+            "matrix_streaming_iters_per_s_all": [round(w["iters_done"] / (w["ms"] * 1e-3), 1) for w in win_stream],
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_matrix_streaming": traffic_stream,
                          "bytes_per_iter": per_iter_bytes, "note": note}}
@@ -659,20 +686,6 @@ def main():
     import cfm_amd.optimal_transport as ot
 
     lib_ = _lib.load()
-    if os.environ.get("CFM_ASG_BLOCKS"):     # experiment knob: grid cap of the assignment's wide kernel
-        lib_.cfm_assign_set_wide_blocks(int(os.environ["CFM_ASG_BLOCKS"]))
-    if os.environ.get("CFM_ASG_ARR"):        # experiment knob: number of epsilon = 0 rounds
-        lib_.cfm_assign_set_params(0, 0, 0, -1, 0, int(os.environ["CFM_ASG_ARR"]), 0)
-    if os.environ.get("CFM_ASG_STOP_EARLY"): # experiment knob: phase cut of every epsilon phase but the last
-        lib_.cfm_assign_set_stop_early(float(os.environ["CFM_ASG_STOP_EARLY"]))
-    if os.environ.get("CFM_ASG_EPS_LAST"):   # experiment knob: last epsilon as a fraction of the cost range
-        lib_.cfm_assign_set_params(0, 0, float(os.environ["CFM_ASG_EPS_LAST"]), -1, 0, -1, 0)
-    if os.environ.get("CFM_ASG_THETA"):      # experiment knob: epsilon scaling factor
-        lib_.cfm_assign_set_params(float(os.environ["CFM_ASG_THETA"]), 0, 0, -1, 0, -1, 0)
-    if os.environ.get("CFM_ASG_BULK"):       # experiment knob: launches enqueued before the first poll
-        lib_.cfm_assign_set_bulk(int(os.environ["CFM_ASG_BULK"]), 1024)
-    if os.environ.get("CFM_ASG_DENSE"):      # experiment knob: no candidate-list solver
-        lib_.cfm_assign_set_mode(0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the HIP path: it needs an MI355X (no CPU fallback exists)")
     rank, local, world = D.init_from_env()
@@ -800,6 +813,62 @@ def main():
             run_steps(pool, args.warmup, n_seq, couple, model_step, draw)
             torch.cuda.synchronize(); seq_all.append((time.perf_counter() - ts) / n_seq)
         seq_s = float(np.median(seq_all))
+    # the same two loops through the PUBLIC entry points, verbatim (VERDICT r4 Next #6b): the reference's line
+    # `t, xt, ut = FM.sample_location_and_conditional_flow(x0, x1)` (conditional_flow_matching.py:241-272;
+    # train_cifar10.py:141-149) in the sequential loop, FM.sample_location_and_conditional_flow_group in the pipelined one
+    # (the host RNG is then consumed inside the calls — on the worker threads in the pipelined loop).  Both are first
+    # asserted BIT-EQUAL to the hand-composed couple() / couple_group() the headline schedule runs, from one RNG state.
+    public = None
+    if world == 1 and args.pipeline and args.group > 1 and not args.no_legs:
+        def rng_get():
+            return np.random.get_state(), torch.get_rng_state(), torch.cuda.get_rng_state(dev)
+
+        def rng_set(st):
+            np.random.set_state(st[0]); torch.set_rng_state(st[1]); torch.cuda.set_rng_state(st[2], dev)
+        st0 = rng_get()
+        ref1 = couple(*pool[0], draw())
+        rng_set(st0)
+        pub1 = fm.sample_location_and_conditional_flow(*pool[0])
+        gb = [pool[q % len(pool)] for q in range(args.group)]
+        rng_set(st0)
+        refg = couple_group(gb, [draw() for _ in gb])
+        rng_set(st0)
+        pubg = fm.sample_location_and_conditional_flow_group(gb)
+        torch.cuda.synchronize()
+        bit_equal = all(torch.equal(a, b) for a, b in zip(ref1, pub1)) and \
+            all(torch.equal(a, b) for ra, rb in zip(refg, pubg) for a, b in zip(ra, rb))
+        rng_set(st0)
+
+        def couple_pub(x0, x1, _drawn):
+            return fm.sample_location_and_conditional_flow(x0, x1)
+
+        def couple_group_pub(batches, _drawn):
+            return fm.sample_location_and_conditional_flow_group(batches)
+        no_draw = lambda: None      # noqa: E731
+        n_seq = min(20, args.steps)
+        run_steps(pool, 0, 2, couple_pub, model_step, no_draw)
+        pub_seq = []
+        for _ in range(max(1, args.repeats)):
+            torch.cuda.synchronize(); ts = time.perf_counter()
+            run_steps(pool, args.warmup, n_seq, couple_pub, model_step, no_draw)
+            torch.cuda.synchronize(); pub_seq.append((time.perf_counter() - ts) / n_seq)
+        from cfm_amd.prefetch import CouplingPrefetcher
+        pre2 = CouplingPrefetcher(fm, dev, workers=args.pipeline, priority=args.priority)
+        for k in sorted(({args.group} | set(ramp) | set(tail) | set(range(1, args.group))) - {0}, reverse=True):
+            pre2.prime(lambda k=k: couple_group_pub([pool[q % len(pool)] for q in range(k)], None))
+        pub_regions = [timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple_pub, model_step, no_draw,
+                                    pre2, args.pipeline, dev, args.group, couple_group_pub, ramp, tail)[0]
+                       for _ in range(max(1, args.repeats))]
+        pre2.close()
+        pe, ps = float(np.median(pub_regions)), float(np.median(pub_seq))
+        public = {"bit_equal_to_headline_composition": bool(bit_equal),
+                  "value_pipelined": B * args.steps / pe, "ms_per_step_pipelined": pe / args.steps * 1e3,
+                  "ms_per_step_pipelined_all": [round(r / args.steps * 1e3, 4) for r in pub_regions],
+                  "value_sequential": B / ps, "ms_per_step_sequential": ps * 1e3,
+                  "ms_per_step_sequential_all": [round(x * 1e3, 4) for x in pub_seq],
+                  "note": "sequential: FM.sample_location_and_conditional_flow(x0, x1) per step, verbatim the reference's "
+                          "training line; pipelined: FM.sample_location_and_conditional_flow_group(batches) on the prefetch "
+                          "workers (same schedule as `value`; the host RNG is drawn inside the calls)"}
     if part is not None:
         part.close()
 
@@ -838,6 +907,7 @@ def main():
         "ms_per_step_sequential": seq_s * 1e3 if seq_s else None,
         "ms_per_step_sequential_all": [round(x * 1e3, 4) for x in seq_all],
         "steady_state": steady,
+        "value_public_api": public,
     }
     if world == 1 and not args.no_legs:
         with torch.cuda.stream(torch.cuda.Stream()):

@@ -262,12 +262,8 @@ __device__ __forceinline__ AsgWs asg_shift(const AsgWs& w0, size_t off) {
     return w;
 }
 
-#ifndef MS_YMAX
 #define MS_YMAX 4
-#endif
-#ifndef MS_SPLIT_MIN
 #define MS_SPLIT_MIN 256
-#endif
 // MS_YMAX: a big relax round is split over this many workgroups per column group
 // MS_SPLIT_MIN: ... when it has more than this many entries
 
@@ -417,9 +413,7 @@ __device__ __forceinline__ int asg_key_row(unsigned long long key, int rb) {
 }
 
 // --------------------------------------------------------- wide: auction -----
-#ifndef WT
 #define WT 1024   // threads of the wide kernels (16 waves)
-#endif
 #define WIDE_PLDS_MAX 8192   // prices are staged into LDS for the bid rounds up to this n
 // One wave per bidding row.  r_k = c_ik + p_k (fp64).  Top-2 over the row.
 struct Top2 { double b; double s; int j; };
@@ -516,7 +510,7 @@ __device__ __forceinline__ void bid_commit(gfp M, const AsgWs& w, Top2 best, int
 // best is the row's best, and min(second in the list, T) is a lower bound of its second best — exact when the second is
 // <= T, otherwise a smaller (still valid: any increment in [eps, second - best + eps] keeps eps-complementary
 // slackness) bid.  b > T: the row is scanned, which refreshes its list.  MODE_UMIN0 sets T = -inf (stale lists of the
-// previous solve).  Measured at C3 (tools/proto/proto22.py): 47.5 k bids, 11.7 k of them full scans.
+// previous solve).  Measured at C3 (a round-3 host prototype): 47.5 k bids, 11.7 k of them full scans.
 __device__ __forceinline__ bool bid_from_list(gfp M, const AsgWs& w, const double* p_lds, bool use_lds, uint2 e, double T,
                                               int i, int n, double eps, int tag, int rb, int rnd) {
     if (!(T > -INFINITY)) return false;                  // (uniform: one T per row)
@@ -526,9 +520,7 @@ __device__ __forceinline__ bool bid_from_list(gfp M, const AsgWs& w, const doubl
     Top2 lb;
     lb.b = okc ? (double)__uint_as_float(e.y) + pj : INFINITY;
     lb.s = T; lb.j = okc ? (int)e.x : 0x7fffffff;
-#ifndef ASG_BL_PARTIAL
 #define ASG_BL_PARTIAL 0
-#endif
     const double bmin = asg_wave_min_d(lb.b);
     if (!(bmin <= T)) return false;
     if (!ASG_BL_PARTIAL) {
@@ -553,9 +545,7 @@ __device__ __forceinline__ void bid_list_store(gfp M, const AsgWs& w, const Top2
     if ((threadIdx.x & 63) == 0) w.cT[i] = T;
 }
 
-#ifndef ASG_BL_ON
 #define ASG_BL_ON 1
-#endif
 // The bid of ONE unmatched row by one wave: from its bid list if that decides it (e / T: the list entry of this lane
 // and the bound), else a scan of the row, which refreshes the list.  Returns 1 (a bid) + 0x10000 if the list served it.
 __device__ __forceinline__ int bid_row(gfp M, const AsgWs& w, const double* p_lds, int i, uint2 e, double T, bool stage_p,
@@ -1230,11 +1220,9 @@ __device__ int ctrl_ms_finish(const AsgWs& w, AsgState* st, int* lds_a, int* lds
 
 // ----------------------------------------------------------------- step ------
 // What the bidder count of the previous round means for the next one (epsilon phases, epsilon = 0 rounds, hand-over).
-// (the parameter source is a template argument: the state block itself, or the snapshot of it asg_step takes with its
-//  first batch of loads when built with ASG_PREFETCH_CTL)
+// (the parameters come from the snapshot of the state block asg_step takes with its first batch of loads)
 struct AucParams { int round_cap, arr_cap; double theta, eps_last, stop_frac, stop_early; };
-template <typename S>
-__device__ __forceinline__ void auc_decide(AucCtl& C, const S* st, int cnt, int n) {
+__device__ __forceinline__ void auc_decide(AucCtl& C, const AucParams* st, int cnt, int n) {
     C.row_scans += cnt;
     const int tag_next = (C.tag % 254) + 1;
     if (C.mode == MODE_AUCTION) {
@@ -1343,9 +1331,6 @@ __device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode
 // ONE wide kernel for every chip-wide step (modes UMIN0 .. CERT): the host replays it without knowing
 // which step comes next.  LDS (modes are exclusive): bid rounds — prices [n] fp64 + owner rows [n]
 // int; relax — 16 KiB of merge buffers; MS_FINISH — 2 n ints for the path walks; the rest < 8 KiB.
-#ifndef ASG_PREFETCH_CTL
-#define ASG_PREFETCH_CTL 0
-#endif
 // the first 128 bytes of AsgState (its line 0), read as one block
 struct AsgHead {
     int mode, n, error, certified;
@@ -1394,23 +1379,13 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
         my_bc = w.bidcol[blockIdx.x + gridDim.x * threadIdx.x];
     uint2 pre_e = make_uint2(0xffffffffu, 0u); double pre_T = -INFINITY;       // the row's bid list (see bid_from_list)
     if (w.cl != nullptr && wave_gid < n_host) { pre_e = w.cl[(size_t)wave_gid * ASG_BL + lane]; pre_T = w.cT[wave_gid]; }
-#if ASG_PREFETCH_CTL
-#define ASG_STF(f) H.f
-#else
-#define ASG_STF(f) st->f
-#endif
-#if !ASG_PREFETCH_CTL
-    int mode = st->mode;
-    gfp M = ASG_GLOBAL(st->Mptr);
-#endif
-#if ASG_PREFETCH_CTL
-    // (experiment, default 0) the round's control record and all four bidder counters are requested with the first batch:
-    // as the code stands `C = ctl[par & 1]` waits for `mode`, and `bidcnt[(C.r - 1) & 3]` for C — two more dependent L2
-    // round trips on the critical path of every round.  ctl[par & 1] and bidcnt[(r - 1) & 3] were written by the previous
-    // launch and are not touched by this one (it writes ctl[(par & 1) ^ 1], zeroes slot (r + 1) & 3, adds to slot r & 3).
-    // ... and so does every field of the state block the round reads (mode, error, rb, the caps and factors auc_decide
-    // looks at): as the code stands each of them is its own dependent round trip (error after mode, round_cap after the
-    // bidder count, ...) — six in a typical round where one would do.
+    // The round's control data — the first 128 bytes of the state block (mode, error, rb, the caps and factors auc_decide
+    // looks at), the control record ctl[par & 1] and all four bidder counters — is requested with the first batch too.
+    // Read where they are used, each of them is its own dependent round trip to the memory-side cache (error after mode,
+    // the record after mode, the counter after the record, round_cap after the counter, ...): six in a typical round
+    // where one does (round 5: lone C3 solve 2.57 -> 2.43 ms, pipelined step 1.24 -> 1.20 ms; profiles/r5_experiments.txt).
+    // ctl[par & 1] and bidcnt[(r - 1) & 3] were written by the previous launch and are not touched by this one (it writes
+    // ctl[(par & 1) ^ 1], zeroes slot (r + 1) & 3, adds to slot r & 3).
     const AsgHead H = *reinterpret_cast<const AsgHead*>(st);
     const double pre_stop_early = st->stop_early;
     AucCtl preC = w.auc->ctl[par & 1];
@@ -1420,35 +1395,22 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
     int mode = H.mode;
     gfp M = ASG_GLOBAL(H.Mptr);
     const AucParams AP{H.round_cap, H.arr_cap, H.theta, H.eps_last, H.stop_frac, pre_stop_early};
-#endif
     asm volatile("" : "+v"(pre_bc), "+v"(pre_bc1), "+v"(pre_bc2), "+v"(pre_bc3), "+v"(my_bc), "+v"(pre_e.x), "+v"(pre_T), "+v"(kst[0].x), "+v"(kst[KP - 1].x) : "s"(mode) : "memory");   // all of it in flight
-    if (mode > MODE_CERT || ASG_STF(error)) return;
+    if (mode > MODE_CERT || H.error) return;
     const int n = n_host;
     unsigned payload = 0;
     // bid rounds: every workgroup decides for itself what this launch is (see AucCtl)
     AucCtl C;
     const bool bidding = (mode == MODE_AUCTION || mode == MODE_ARR);
     if (bidding) {
-#if ASG_PREFETCH_CTL
         C = preC;
-#else
-        C = w.auc->ctl[par & 1];
-#endif
         if (C.r > 0) {
             // bidders of the previous round in the low 16 bits, those served from their lists above (lists: n <= SP_NMAX)
-#if ASG_PREFETCH_CTL
             const int sl = (C.r - 1) & 3;
             const int raw = sl == 0 ? pre_cnt0 : sl == 1 ? pre_cnt1 : sl == 2 ? pre_cnt2 : pre_cnt3;
-#else
-            const int raw = asg_ld(&w.auc->bidcnt[(C.r - 1) & 3]);
-#endif
             const bool lists = (w.cl != nullptr);
             const int nl = lists ? (raw >> 16) : 0;
-#if ASG_PREFETCH_CTL
             auc_decide(C, &AP, lists ? (raw & 0xffff) : raw, n);
-#else
-            auc_decide(C, st, lists ? (raw & 0xffff) : raw, n);
-#endif
             C.pad[0] += nl;          // row_scans: the bids (row evaluations); pad[0]: those served from the list (512 bytes each)
         }
         mode = C.mode;
@@ -1470,7 +1432,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
     if (mode == MODE_AUCTION || mode == MODE_ARR) {
         double* p_lds = reinterpret_cast<double*>(step_lds);
         int* r_lds = reinterpret_cast<int*>(step_lds + (size_t)((n + 1) & ~1) * sizeof(double));
-        const double eps = C.eps; const int tag = C.tag, rb = ASG_STF(rb);
+        const double eps = C.eps; const int tag = C.tag, rb = H.rb;
         const int rnd = (mode == MODE_ARR) ? min(C.arr_round + 1, (1 << ASG_RND_BITS) - 1) : 0;
         if (threadIdx.x == 0) { sh[0] = 0; sh[1] = 0; }
         if (stage_p) {
@@ -1701,9 +1663,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     // its rows bid or not; measured at n = 4096: 8 problems 9.1 ms with 256 workgroups each, 6.5 ms with 64); the rounds
     // then take the queue form (wide_bid_queue)
     const int floor_blocks = nb > 1 ? (n + ASG_BQ - 1) / ASG_BQ : (n + 63) / 64;
-#ifndef ASG_BATCH_WGS
 #define ASG_BATCH_WGS 256
-#endif
     if (nb > 1 && wide_blocks > ASG_BATCH_WGS / nb) wide_blocks = ASG_BATCH_WGS / nb;
     if (wide_blocks < floor_blocks) wide_blocks = floor_blocks;      // (the queue form takes ASG_BQ rows per workgroup)
     if (wide_blocks < 1) wide_blocks = 1;
@@ -1742,9 +1702,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     // A batch pays for every problem that is not yet at its list build when the first build + solver pair comes by: it
     // is built and solved by the NEXT chunk, behind the others' solver (~1.9 ms at n = 4096).  The steps before the
     // build vary by ~+-6 between problems: 24 instead of 10 steps in front of the pair (a no-op step costs 3-5 us).
-#ifndef ASG_BATCH_CHUNK
 #define ASG_BATCH_CHUNK 24
-#endif
     if (nb > 1 && chunk < ASG_BATCH_CHUNK) chunk = ASG_BATCH_CHUNK;
     const int bulk = ((n >= P.bulk_min_n) ? P.bulk : 0) & ~1;
     AsgGraph& G = asg_graph_slot(ws, n, nb, s);
@@ -1899,10 +1857,8 @@ extern "C" int cfm_assign_exact_batch_f32(const float* const* M, int nb, int B, 
     // less of the chip from the other jobs and the dense products.  Measured in the C3 pipelined loop (round 4,
     // CFM_ASG_BLOCKS sweep, same box): 256 / 64 / 32 / 16 per problem for the odd-sized jobs: 1.201 / 1.163 / 1.162 /
     // 1.276 ms per step; a lone solve prefers the wide grid (3.30 vs 3.68 ms sequential): cfm_assign_exact_f32 keeps it.
-#ifndef ASG_TP_WGS
 #define ASG_TP_WGS 64
-#endif
-    if (P.wide_blocks_cap == 0 || P.wide_blocks_cap > ASG_TP_WGS) P.wide_blocks_cap = ASG_TP_WGS;
+    if (P.wide_blocks_cap == 0) P.wide_blocks_cap = ASG_TP_WGS;      // (an explicit cfm_assign_set_wide_blocks cap is the caller's: never overridden)
     const size_t stride = cfm_align_up(asg_ws_bytes(B), 256);
     int rc = 0;
     for (int b0 = 0; b0 < nb && rc == 0; b0 += ASG_BATCH_MAX) {

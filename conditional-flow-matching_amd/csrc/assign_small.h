@@ -282,7 +282,7 @@ __global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mra
                     // Uncapped, a round is as long as its most loaded wave, and 27 bidders over 16 waves put 4-5 on
                     // one of them.  Measured over 7 instances (n = 64 .. 256): cap 1: 4.88 ms in total, cap 3: 4.91,
                     // uncapped: 5.64; the fair share ceil(unmatched / 16): 6.4; a barrier-free asynchronous auction
-                    // (same critical path, emulated in tools/proto/asg_small_async_sim.py) was as fast as cap 1 but
+                    // (same critical path, emulated in a round-3 host simulation) was as fast as cap 1 but
                     // not deterministic on tied costs.  Jacobi rounds on a price snapshot: the same result every run.
                     const int cap = P.bid_cap;
                     unsigned left = mk;

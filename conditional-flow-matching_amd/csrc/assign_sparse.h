@@ -22,9 +22,6 @@
 // the fp64 certificate pass over the whole matrix still closes the solve.
 #pragma once
 
-#ifndef ASG_BUILD_VEC
-#define ASG_BUILD_VEC 1
-#endif
 #define SP_K 64
 #define SP_NMAX 4096
 #define SP_NOCOL 0xffffu
@@ -132,11 +129,7 @@ __device__ __forceinline__ void wide_build(gfp M, const AsgWs& w, const AsgState
     const int nt = (n + 63) / 64;
     float* r = reinterpret_cast<float*>(lds) + (size_t)wv * nt * 64 + lane;   // r[t * 64]
     const int wave_gid = wv * gridDim.x + blockIdx.x, n_waves = gridDim.x * SP_BUILD_WAVES;
-#if ASG_BUILD_VEC
     const bool fastb = ((n & 1023) == 0) && n > SP_K;     // n <= SP_NMAX = 4096: at most 16 float4 per lane
-#else
-    const bool fastb = false;
-#endif
     for (int i = wave_gid; i < n; i += n_waves) {
         gfp row = M + (size_t)i * n;
         float lmin = INFINITY;
@@ -246,11 +239,7 @@ __device__ __forceinline__ void wide_build(gfp M, const AsgWs& w, const AsgState
 // would make every barrier wait for the list prefetches issued for the NEXT batch; inside the
 // solver loop all cross-wave traffic is LDS (M, the candidate lists and cT are read-only).
 __device__ __forceinline__ void sp_sync() {
-#ifdef SP_FULLSYNC
-    __syncthreads();
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 // wave64 DPP primitives (row_shr within 16-lane rows, then row_bcast 15 / 31)
@@ -475,10 +464,6 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
         if (on[q]) cl[q] = w.cl[(size_t)ii[q] * SP_K + lane];
     }
     FB_TICK(0);
-#ifndef SP_SLOT_BLOCKS
-#define SP_SLOT_BLOCKS 1
-#endif
-#if SP_SLOT_BLOCKS
     // stages 4 - 6, one self-contained block per entry slot (no defaults carried across slots: the staged form below
     // spends a third of its instructions on moves / selects for slots that are off — and this kernel is issue bound;
     // the LDS round trips of a slot are covered by the other three waves of its SIMD)
@@ -511,64 +496,6 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
             }
         }
     }
-#else
-    // stage 4: prices / labels of the candidates; price of the matched column, or the root's u
-#pragma unroll
-    for (int q = 0; q < SP_E; ++q) {
-        pj[q] = 0.0; pk[q] = 0.0; dc[q] = 0.0; use[q] = false; kk[q] = 0;
-        if (on[q]) {
-            const unsigned col = cl[q].x;
-            use[q] = col != SP_NOCOL && (int)col != jj[q];
-            kk[q] = use[q] ? (int)col : 0;
-            pk[q] = L.p[kk[q]];
-            dc[q] = L.dist[kk[q]];
-            pj[q] = root[q] ? L.ru[slot[q]] : L.p[jj[q]];
-        }
-    }
-    // stage 5: candidates
-#pragma unroll
-    for (int q = 0; q < SP_E; ++q) {
-        cd[q] = 0.0;
-        if (on[q]) {
-            double rj = sp_rfl_d(pj[q]);
-            if (!root[q]) {
-                const unsigned long long hit = __ballot((int)cl[q].x == jj[q]);
-                float cij;
-                if (hit) cij = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)cl[q].y, __ffsll((long long)hit) - 1));
-                else cij = M[(size_t)ii[q] * n + jj[q]];
-                rj = (double)cij + rj;                          // = u_i: the matched edge is tight
-            }
-            cd[q] = sp_cand(pk[q], __uint_as_float(cl[q].y), rj, bs[q]);
-        }
-    }
-    // stage 6: lower the labels, keep the predecessor keys (all atomics in flight before the first result is used)
-    unsigned long long oldb[SP_E]; bool low[SP_E];
-#pragma unroll
-    for (int q = 0; q < SP_E; ++q) {
-        oldb[q] = 0ull; low[q] = false;
-        if (on[q]) {
-            low[q] = use[q] && cd[q] < dc[q] && cd[q] < dfree;      // labels >= the radius can never matter
-            if (low[q]) {
-                const unsigned long long nb = (unsigned long long)__double_as_longlong(cd[q]);
-                oldb[q] = atomicMin((unsigned long long*)&L.dist[kk[q]], nb);
-                atomicMin(&L.pkey[kk[q]], (nb & ~SP_ROWMASK) | (unsigned long long)(unsigned)ii[q]);
-            }
-        }
-    }
-    // the lanes that lowered a label: tree hint, dense mark, and an assigned column goes to the pending list
-    unsigned ow[SP_E];
-#pragma unroll
-    for (int q = 0; q < SP_E; ++q) {
-        ow[q] = SP_NOCOL;
-        if (on[q]) {
-            low[q] = low[q] && oldb[q] > (unsigned long long)__double_as_longlong(cd[q]);
-            if (low[q]) { ow[q] = L.owner[kk[q]]; L.ddone[kk[q]] = 0; L.slot[kk[q]] = (unsigned char)slot[q]; }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < SP_E; ++q)
-        if (on[q] && low[q]) { if (ow[q] != SP_NOCOL) sp_file(L, kk[q], cd[q], plcur, far_thr); else L.ri[SP_RI_FREECHG] = 1; }
-#endif
     FB_TICK(1);
     sp_sync();
     FB_TICK(2);
@@ -589,18 +516,14 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
 // Publishes nS, the new list length and far_thr; every thread returns the same adapted delta.
 // The solver is instruction-issue bound, so only as many waves as the list needs take part (thread <-> entry, up to
 // SP_IPT entries per thread for lists beyond 1024): the others go straight to the barriers.
-#ifndef SP_FARMULT
 #define SP_FARMULT 3.0   // the near list holds the labels within this many windows of the smallest one (measured: 3 -> 1.82 ms, 5 -> 1.96, 8 -> 1.92 of solver time at C3)
-#endif
 #define SP_RI_WANT 16    // 16 per-wave selection counts
 #define SP_RI_KEEP 96    // 16 per-wave keep counts
 // (round 3, after the cycle counters: the 16 waves no longer reduce the partial minima / counts redundantly and there
 //  are no prefix scans over the waves — a wave adds its partials to three LDS words with atomics, and takes its block of
 //  the scan list / the kept list with ONE returning atomic add each; the order of the lists is arbitrary anyway.  Two
 //  barriers instead of three, and the kept-list counter IS the append counter of the next pending list.)
-#ifndef SP_TLO
 #define SP_TLO (SP_CAP / 2)   // the window doubles while a batch holds fewer entries than this
-#endif
 #define SP_RD_CMIN 52    // bit patterns (labels >= +0 order like integers): smallest / largest live pending label
 #define SP_RD_CMAX 53
 #define SP_RI_CNP 69     // live pending entries
@@ -729,7 +652,7 @@ __device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double
 // which keeps them feasible and makes every accepted path tight.  One phase costs the depth of one search and
 // retires several rows: at n = 4096 the 25 - 30 rows left by the auction go in about five phases / 280 batches,
 // against 65 chip-wide relax rounds + 370 batches when the forest ran on the dense matrix and only the last six
-// rows came here one by one (tools/proto/proto18.py).
+// rows came here one by one (a round-3 host prototype).
 __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, char* lds) {
 #ifdef SP_PROFILE
     long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/cfm_gfx950.h"
+#include "../../include/cfm_gfx950_tuning.h"   // every export is declared in one of the two headers (-fvisibility=hidden)
 
 #define CFM_WAVE 64
 

@@ -7,9 +7,9 @@
 // cancelling entry recomputed in the direct form.
 //
 // Three kernels:
-//   cost_gemm    : d >= 64, B0, B1 >= 256.  v_mfma_f32_32x32x2_f32, 128x128 tile per workgroup;
-//                  measured max relative error 2-5e-7 against fp64 (direct form: 0.5-2e-6),
-//                  368 us at B = 4096, d = 784 (direct: 574 us).  See the section below.
+//   cost_gemm_glds : d >= 64, B0, B1 >= 256.  v_mfma_f32_32x32x2_f32, 128x128 tile per workgroup, operands DMA'd
+//                  straight into LDS (gemm_glds.h); measured max relative error 2-5e-7 against fp64 (direct
+//                  form: 0.5-2e-6), 247 us at B = 4096, d = 784 (direct: 574 us).  See the section below.
 //   cost_small_d : d <= 8.  Output-write bound (4*B0*B1 bytes): each lane owns
 //                  four consecutive columns whose x1 rows live in registers,
 //                  loops over a strip of rows (x0 row is wave-uniform) and
@@ -21,7 +21,6 @@
 //                  8x8 super-tiles of workgroups per XCD so both operand panels
 //                  stay in that XCD's 4 MiB L2.
 #include "cfm_common.h"
-#include "gemm_core.h"
 #include "gemm_glds.h"
 #include <stdlib.h>
 
@@ -226,35 +225,24 @@ __global__ __launch_bounds__(256) void cost_center(const float* __restrict__ x0,
     if (g == 0 && c < d) mu[c] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)(n0 + n1);
 }
 
-// nrm[i] = |fl(x0_i - mu)|^2 (i < B0), nrm[B0 + j] = |fl(x1_j - mu)|^2: one wave per row
-// xc (may be NULL): the centred rows fl(x - mu) themselves, [B0 + B1][d] — the operands of the direct-to-LDS product
-// (cost_gemm_glds), which cannot subtract on the way in; the same fp32 values the register-staged engine forms.
-// COST_GLDS_V2 (compile-time experiment, default 0; build it with tools/probe/try_glds_v2.sh): the centred copies in the
-// PADDED layout gl_run_padded wants — xc0 [(B0 + 1)][dp], xc1 [(B1 + 1)][dp] behind it, dp = d rounded up to GL_BK, the
-// k padding and the extra row of each zero — so that every DMA of the product is unconditional (gemm_glds.h).
-#ifndef COST_GLDS_V2
-#define COST_GLDS_V2 0
-#endif
+// nrm[i] = |fl(x0_i - mu)|^2 (i < B0), nrm[B0 + j] = |fl(x1_j - mu)|^2: one wave per row; and the centred rows
+// fl(x - mu) themselves in the PADDED layout the direct-to-LDS product wants (gemm_glds.h): xc0 [(B0 + 1)][dp],
+// xc1 [(B1 + 1)][dp] behind it, dp = d rounded up to GL_BK, the k padding and the extra row of each zero — so that every
+// DMA of the product is unconditional (any d, any alignment of the clouds).
 __global__ __launch_bounds__(256) void cost_norms(const float* __restrict__ x0, const float* __restrict__ x1,
                                                   int B0, int B1, int d, const float* __restrict__ mu,
                                                   float* __restrict__ nrm, float* __restrict__ xc) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-#if COST_GLDS_V2
     const int dp = (d + GL_BK - 1) / GL_BK * GL_BK;
-    if (xc && row >= B0 + B1 && row < B0 + B1 + 2) {          // the two zero rows
+    if (row >= B0 + B1 && row < B0 + B1 + 2) {                // the two zero rows
         float* z = xc + (size_t)(row == B0 + B1 ? B0 : B0 + 1 + B1) * dp;
         for (int k = lane; k < dp; k += 64) z[k] = 0.f;
     }
-#endif
     if (row >= B0 + B1) return;
     const float* p = row < B0 ? x0 + (size_t)row * d : x1 + (size_t)(row - B0) * d;
-#if COST_GLDS_V2
-    float* pc = xc ? xc + (size_t)(row < B0 ? row : row + 1) * dp : nullptr;
-    if (pc) for (int k = d + lane; k < dp; k += 64) pc[k] = 0.f;
-#else
-    float* pc = xc ? xc + (size_t)row * d : nullptr;
-#endif
+    float* pc = xc + (size_t)(row < B0 ? row : row + 1) * dp;
+    for (int k = d + lane; k < dp; k += 64) pc[k] = 0.f;
     float s = 0.f;
     int k = lane;
     for (; k + 64 * 7 < d; k += 64 * 8) {                 // 8 trips' loads in flight, the chain in k order as before
@@ -262,147 +250,26 @@ __global__ __launch_bounds__(256) void cost_norms(const float* __restrict__ x0, 
 #pragma unroll
         for (int t = 0; t < 8; ++t) { xv[t] = p[k + 64 * t]; mv[t] = mu[k + 64 * t]; }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const float tt = xv[t] - mv[t]; s = fmaf(tt, tt, s); if (pc) pc[k + 64 * t] = tt; }
+        for (int t = 0; t < 8; ++t) { const float tt = xv[t] - mv[t]; s = fmaf(tt, tt, s); pc[k + 64 * t] = tt; }
     }
     for (; k < d; k += 64) {
         const float t = p[k] - mu[k];
         s = fmaf(t, t, s);
-        if (pc) pc[k] = t;
+        pc[k] = t;
     }
     s = wave_sum_f(s);
     if (lane == 0) nrm[row] = s;
 }
 
-// 128 x 128 output tile per workgroup on the shared tile engine (gemm_core.h): both clouds K-contiguous,
-// centred by mu on the way into LDS.
-// hook of the tile engine: the common centre mu[k] is subtracted from both clouds on their way into LDS
-struct CostCentre {
-    const float* mu; int d;
-    template <typename OA> __device__ __forceinline__ void a(OA& oa, int k0) const { oa.sub_k(mu, k0, d); }
-    template <typename OB> __device__ __forceinline__ void b(OB& ob, int k0) const { ob.sub_k(mu, k0, d); }
-};
-
-#ifndef COST_BK
-#define COST_BK 16       // K depth of a stage (tuning switch)
-#endif
-#ifndef COST_MINW
-#define COST_MINW 1      // minimum waves per SIMD the register allocation must leave room for (tuning switch)
-#endif
-template <int BM, bool VEC>
-__global__ __launch_bounds__(256, COST_MINW) void cost_gemm(const float* __restrict__ x0, const float* __restrict__ x1,
-                                                 int B0, int B1, int d, const float* __restrict__ mu,
-                                                 const float* __restrict__ nrm, float* __restrict__ M,
-                                                 int tiles_m, int tiles_n) {
-    constexpr int BN = 128, BK = COST_BK;
-    using Core = GemmCore<BM, BN, BK, false, false, VEC, VEC>;
-    __shared__ __attribute__((aligned(16))) float lds[Core::LDS_FLOATS];
-
-    // XCD-aware super-tile order (as cost_tiled): each XCD walks 8x8 groups of tiles
-    unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    {
-        const int G = 8;
-        const int per_band = G * tiles_n;
-        const int band = lid / per_band, r = lid - band * per_band;
-        const int rows_in_band = min(G, tiles_m - band * G);
-        const int fgt = rows_in_band * G;
-        const int gcol = r / fgt;
-        const int rr = r - gcol * fgt;
-        const int cols_in_group = min(G, tiles_n - gcol * G);
-        tm = band * G + rr / cols_in_group;
-        tn = gcol * G + rr % cols_in_group;
-    }
-    const int row0 = tm * BM, col0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-
-    Core g;
-    g.zero();
-    g.run(lds, x0, d, row0, B0, x1, d, col0, B1, 0, d, CostCentre{mu, d}, GcNoPost());
-
-    // ---- epilogue: |a|^2 + |b|^2 - 2 a.b, clamped; entries that cancel are recomputed directly by their wave ----
-    __syncthreads();                                   // every wave is done with the last stage
-    float* An = lds; float* Bn = lds + BM;
-    if (tid < BM) An[tid] = (row0 + tid < B0) ? nrm[row0 + tid] : 0.f;
-    if (tid < BN) Bn[tid] = (col0 + tid < B1) ? nrm[B0 + col0 + tid] : 0.f;
-    __syncthreads();
-    constexpr int NT = Core::EU, MT = Core::EM, ER = Core::ER;
-    const int cl = Core::col_lo();
-    const float ny[2] = {Bn[cl], Bn[cl + NT - 1]};
-    const bool pair = NT == 2 && (B1 & 1) == 0 && col0 + cl + 1 < B1;
-    // Per block of ER rows (one accumulator row block): all entries first, ONE ballot asking whether any of them
-    // cancels (round 3: a ballot + branch pair in front of every entry, 128 per wave; at the reference's shapes no
-    // entry ever cancels), the per-entry recomputation only then, and the stores.
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        float v[ER][2];
-        bool anybad = false;
-#pragma unroll
-        for (int r = 0; r < ER; ++r) {
-            const int rl = Core::row_of(m, r);
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                const float sum = An[rl] + ny[u];
-                const float x = fmaxf(fmaf(-2.f, g.at(m, u, r), sum), 0.f);
-                anybad |= (row0 + rl < B0 && col0 + cl + u < B1 && x < 0.125f * sum);
-                v[r][u] = x;
-            }
-        }
-        if (__ballot(anybad) != 0ull) {                       // wave uniform, rare
-#pragma unroll
-            for (int r = 0; r < ER; ++r) {
-                const int gr = row0 + Core::row_of(m, r);
-#pragma unroll
-                for (int u = 0; u < NT; ++u) {
-                    const int gc = col0 + cl + u;
-                    const float sum = An[Core::row_of(m, r)] + ny[u];
-                    // cancellation: this wave recomputes the entry in the direct form
-                    unsigned long long mask = __ballot(gr < B0 && gc < B1 && v[r][u] < 0.125f * sum);
-                    while (mask) {
-                        const int l = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        const int gi = __shfl(gr, l, 64), gj = __shfl(gc, l, 64);
-                        const float* pa = x0 + (size_t)gi * d;
-                        const float* pb = x1 + (size_t)gj * d;
-                        float p = 0.f;
-                        for (int k = lane; k < d; k += 64) {
-                            const float t = pa[k] - pb[k];
-                            p = fmaf(t, t, p);
-                        }
-                        p = wave_sum_f(p);
-                        if (lane == l) v[r][u] = p;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < ER; ++r) {
-            const int gr = row0 + Core::row_of(m, r);
-            if (gr < B0) {
-                float* po = M + (size_t)gr * B1 + col0 + cl;
-                if (pair) *reinterpret_cast<float2*>(po) = make_float2(v[r][0], v[r][NT - 1]);
-                else {
-#pragma unroll
-                    for (int u = 0; u < NT; ++u) if (col0 + cl + u < B1) po[u] = v[r][u];
-                }
-            }
-        }
-    }
-}
-
-// The same product on the direct-to-LDS engine (gemm_glds.h): operands = the centred clouds cost_norms wrote (xc0, xc1),
-// same k order, same epilogue arithmetic — the matrix is bit-equal to cost_gemm's.  x0 / x1: the original clouds, read
-// only by the recomputation of cancelling entries.  64 KiB of dynamic LDS, two workgroups per CU.
-#ifndef COST_GLDS_FAIR
-#define COST_GLDS_FAIR 1
-#endif
-#ifndef COST_GLDS_LOOP
-#define COST_GLDS_LOOP 1      // 1: gl_run_padded_pipe (pipelined K-step boundary), 0: gl_run_padded
-#endif
+// 128 x 128 output tile per workgroup on the direct-to-LDS engine (gemm_glds.h): operands = the centred, padded clouds
+// cost_norms wrote (xc0, xc1).  Epilogue: |a|^2 + |b|^2 - 2 a.b, clamped; entries that cancel (below 1/8 of the norm
+// sum: duplicated / nearly identical points) are recomputed in the direct form by their wave from the ORIGINAL clouds
+// x0 / x1.  64 KiB of dynamic LDS, two workgroups per CU.  C3 (4096 x 4096 x 784): 247 us = 106 TFLOP/s (round 4's
+// register-staged engine: 266 us; profiles/r5_experiments.txt).
 __global__ __launch_bounds__(256, 2) void cost_gemm_glds(const float* __restrict__ xc0, const float* __restrict__ xc1,
                                                          const float* __restrict__ x0, const float* __restrict__ x1,
                                                          int B0, int B1, int d, const float* __restrict__ nrm,
-                                                         float* __restrict__ M, int tiles_m, int tiles_n,
-                                                         const float* __restrict__ zeros) {
+                                                         float* __restrict__ M, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float glds_lds[];
     unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
@@ -422,18 +289,10 @@ __global__ __launch_bounds__(256, 2) void cost_gemm_glds(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63;
     GldsCore g;
     g.zero();
-#if COST_GLDS_V2
-    {   // xc0 / xc1 are padded ([B + 1][dp]); the two workgroups of a CU alternate their issue priority (COST_GLDS_FAIR)
-        const int dp = (d + GL_BK - 1) / GL_BK * GL_BK;
-#if COST_GLDS_LOOP
-        gl_run_padded_pipe(g, glds_lds, xc0, dp, row0, B0, xc1, dp, col0, B1, dp, COST_GLDS_FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
-#else
-        gl_run_padded(g, glds_lds, xc0, dp, row0, B0, xc1, dp, col0, B1, dp, COST_GLDS_FAIR ? (int)((blockIdx.x >> 8) & 1u) : -1);
-#endif
+    {
+        const int dp = (d + GL_BK - 1) / GL_BK * GL_BK;      // xc0 / xc1 are padded: [B + 1][dp]
+        gl_run_padded_pipe(g, glds_lds, xc0, dp, row0, B0, xc1, dp, col0, B1, dp);
     }
-#else
-    g.run(glds_lds, xc0, d, row0, B0, xc1, d, col0, B1, d, zeros);
-#endif
     gl_wait_barrier();                                   // every wave is done with the last stage
     float* An = glds_lds; float* Bn = glds_lds + GL_BM;
     if (tid < GL_BM) An[tid] = (row0 + tid < B0) ? nrm[row0 + tid] : 0.f;
@@ -531,70 +390,32 @@ static void launch_small(const float* x0, const float* x1, int B0, int B1, float
     hipLaunchKernelGGL(cost_small_d<D>, grid, dim3(256), 0, st, x0, x1, B0, B1, M, rows_per_block);
 }
 
-// Gram form on the matrix cores for d >= 64 and at least a 2 x 2 grid of tiles (ws: mu [d padded],
-// norms [B0 + B1]); 0 = not taken.
-// ws: mu [d padded to 64] | norms [B0 + B1, padded to 4] | 16 floats of zeros | centred rows [(B0 + B1) x d] (the
-// operands of the direct-to-LDS product; d % 4 == 0 only)
+// Gram form on the matrix cores for d >= 64 and at least a 2 x 2 grid of tiles; 0 = not taken.
+// ws: mu [d padded to 64] | norms [B0 + B1, padded to 4] | centred, padded clouds [(B0 + 1) + (B1 + 1)][dp]
 static inline size_t cost_ws_head_floats(int B0, int B1, int d) {
-    return (size_t)((d + 63) & ~63) + (((size_t)B0 + (size_t)B1 + 3) & ~(size_t)3) + 16;
+    return (size_t)((d + 63) & ~63) + (((size_t)B0 + (size_t)B1 + 3) & ~(size_t)3);
 }
-static bool cost_use_glds();
+static inline size_t cost_dp(int d) { return (size_t)((d + GL_BK - 1) / GL_BK * GL_BK); }
 extern "C" size_t cfm_cost_ws_bytes_internal(int B0, int B1, int d) {
-#if COST_GLDS_V2
-    const size_t centred = cost_use_glds() ? ((size_t)B0 + (size_t)B1 + 2) * (size_t)((d + GL_BK - 1) / GL_BK * GL_BK) : 0;
-#else
-    const size_t centred = (cost_use_glds() && d % 4 == 0) ? ((size_t)B0 + (size_t)B1) * (size_t)d : 0;
-#endif
+    const size_t centred = ((size_t)B0 + (size_t)B1 + 2) * cost_dp(d);
     return sizeof(float) * (cost_ws_head_floats(B0, B1, d) + centred) + 256;
 }
 static bool cost_use_mfma(int B0, int B1, int d) {
-    static int off = -1;
-    if (off < 0) { const char* e = getenv("CFM_COST_MFMA"); off = (e && e[0] == '0') ? 1 : 0; }
-    return !off && d >= 64 && B0 >= 256 && B1 >= 256;
+    // (the engine addresses an operand with 32-bit byte offsets: clouds beyond 4 GiB take the VALU tiles)
+    return d >= 64 && B0 >= 256 && B1 >= 256 && ((size_t)(B0 > B1 ? B0 : B1) + 1) * cost_dp(d) * 4 < (1ull << 32);
 }
-// CFM_COST_GLDS=1: the direct-to-LDS engine (gemm_glds.h) for the cost matrix; default: the register-staged engine.
-// The matrix has the same bits either way (asserted by tests/test_gpu_glds.py); measured in round 4 at 4096 x 4096:
-// d = 784 274.4 vs 279.6 us, d = 3136 111.5 vs 110.5 TFLOP/s — a tie, for 25 MB more scratch (the centred copies), so it
-// stays the experiment it was built as (profiles/r4_gemm_probes.txt: neither load path is what holds the product at 70 %
-// of the matrix pipe).
-static bool cost_use_glds() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("CFM_COST_GLDS"); on = (e && e[0] == '1') ? 1 : 0; }
-    return on != 0;
-}
-__global__ void cost_zero16(float* z) { if (threadIdx.x < 16) z[threadIdx.x] = 0.f; }
 static int cost_mfma(const float* x0, const float* x1, int B0, int B1, int d, float* M, void* ws,
                      hipStream_t st) {
     float* mu = reinterpret_cast<float*>(ws);
     float* nrm = mu + ((d + 63) & ~63);
-    float* zeros = nrm + (((size_t)B0 + (size_t)B1 + 3) & ~(size_t)3);
-    float* xc = zeros + 16;
-    const bool vec = (d % 4 == 0) && (((uintptr_t)x0 & 15) == 0) && (((uintptr_t)x1 & 15) == 0);
-#if COST_GLDS_V2
-    const bool glds = cost_use_glds();          // the padded copies take any d and any alignment of the clouds
-#else
-    const bool glds = vec && cost_use_glds();
-#endif
+    float* xc = nrm + (((size_t)B0 + (size_t)B1 + 3) & ~(size_t)3);
     hipLaunchKernelGGL(cost_center, dim3((d + 63) / 64), dim3(256), 0, st, x0, x1, B0, B1, d, mu);
-#if COST_GLDS_V2
-    hipLaunchKernelGGL(cost_norms, dim3((B0 + B1 + 2 + 3) / 4), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, glds ? xc : nullptr);
-#else
-    hipLaunchKernelGGL(cost_norms, dim3((B0 + B1 + 3) / 4), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, glds ? xc : nullptr);
-#endif
+    hipLaunchKernelGGL(cost_norms, dim3((B0 + B1 + 2 + 3) / 4), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, xc);
     // (256 x 128 tiles — 8 MFMA tiles per wave, one resident round at B = 4096 — were measured at
     //  549 us against 368 us for 128 x 128: the accumulators leave two waves per SIMD no room.)
     const int tm = (B0 + 127) / 128, tn = (B1 + 127) / 128;
-    if (glds) {
-        hipLaunchKernelGGL(cost_zero16, dim3(1), dim3(64), 0, st, zeros);
-#if COST_GLDS_V2
-        hipLaunchKernelGGL(cost_gemm_glds, dim3(tm * tn), dim3(256), GL_LDS_BYTES, st, xc,
-                           xc + (size_t)(B0 + 1) * (size_t)((d + GL_BK - 1) / GL_BK * GL_BK), x0, x1, B0, B1, d, nrm, M, tm, tn, zeros);
-#else
-        hipLaunchKernelGGL(cost_gemm_glds, dim3(tm * tn), dim3(256), GL_LDS_BYTES, st, xc, xc + (size_t)B0 * d, x0, x1, B0, B1, d,
-                           nrm, M, tm, tn, zeros);
-#endif
-    } else if (vec) hipLaunchKernelGGL((cost_gemm<128, true>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, M, tm, tn);
-    else     hipLaunchKernelGGL((cost_gemm<128, false>), dim3(tm * tn), dim3(256), 0, st, x0, x1, B0, B1, d, mu, nrm, M, tm, tn);
+    hipLaunchKernelGGL(cost_gemm_glds, dim3(tm * tn), dim3(256), GL_LDS_BYTES, st, xc, xc + (size_t)(B0 + 1) * cost_dp(d), x0, x1,
+                       B0, B1, d, nrm, M, tm, tn);
     return cfm_status();
 }
 

@@ -1,5 +1,6 @@
 // gemm_core.h — the fp32-MFMA tile engine shared by every dense product of the path (gfx950):
-//   mlp_layer (MLP forward, mlp.hip), gemm_f32_mfma (dgrad / wgrad, mlp_train.hip), cost_gemm (cost.hip).
+//   mlp_layer (MLP forward, mlp.hip), gemm_f32_mfma (dgrad / wgrad, mlp_train.hip).  (The cost matrix runs on the
+//   direct-to-LDS engine, gemm_glds.h.)
 //
 //   C tile [BM x BN] += sum_k A(i, k) . B(k, j)   on v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an ascending-k
 //   fmaf chain per output, whatever the tile shape — the k order below never changes).
@@ -23,35 +24,13 @@
 #pragma once
 #include "cfm_common.h"
 
-// where in a K step the global loads of the stage after next are issued (tuning switch; results do not depend on it):
-//   0: both operands behind the third MFMA group (round 3)    1: both behind the second group, right after the B stash
-//   2: each operand right behind its own stash (A in group 0, B in group 1): the longest flight time
-#ifndef GC_FETCH_MODE
-#define GC_FETCH_MODE 0
-#endif
-// timing probes (tools/probe/build_variant_all.sh; the results are WRONG with any of them set): which part of a K step
-// keeps the matrix pipe idle?  bit 0: no global loads in the loop, bit 1: no LDS stores, bit 2: fragments read once
-// per step only, bit 3: no barrier
-#ifndef GC_DBG
-#define GC_DBG 0
-#endif
-// GC_FAIR=1 (experiment, default 0): the two workgroups that share a CU (block b and b + 256 of a 1-D grid) alternate
-// their issue priority K step by K step.  A CU serves its resident workgroups oldest first: of two that start together one
-// runs ~25 % faster, and with two rounds of tiles per CU half of the slots are empty for the last 15 % of a launch
-// (tools/probe/glds_probe.hip, profiles/r4_glds_probe.txt: 114 -> 120 TFLOP/s on the direct-to-LDS loop, not reproduced in
-// a second form of the same loop).  Results do not depend on it.
-#ifndef GC_FAIR
-#define GC_FAIR 0
-#endif
-// GC_PIPE=1 (experiment, default 0; same bits): PIPELINED K-step boundary.  A K step ends with a barrier and the next one
-// starts with fragment reads nothing covers: the matrix pipe drains once per step (tools/probe/glds_probe.hip measured the
-// same pattern on the direct-to-LDS loop: 112.6 -> 125.5 TFLOP/s when it is removed in one form of that loop, no gain in
-// another — to be measured with interleaved repeats).  Here the MFMAs of a step's LAST
-// fragment group are deferred: its fragments are in registers before the barrier, the MFMAs run right behind the next
-// step's first fragment reads.  Per output the k order is unchanged.
-#ifndef GC_PIPE
-#define GC_PIPE 0
-#endif
+// PIPELINED K-step boundary (adopted in round 5: C3 model step 428 -> 417 us, cost matrix 266 -> 260 us on this engine,
+// profiles/r5_experiments.txt; same bits).  A K step ends with a barrier and the next one would start with fragment reads
+// nothing covers — the matrix pipe drains once per step.  The MFMAs of a step's LAST fragment group are therefore
+// deferred: its fragments are in registers before the barrier, the MFMAs run right behind the next step's first fragment
+// reads.  Per output the k order is unchanged.  (Tried and removed: alternating s_setprio of the two workgroups of a CU
+// — 266 -> 275 us on the cost matrix; 128 x 64 layer tiles — model step 428 -> 501 us; earlier issue points of the
+// global loads — no difference.)
 typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gc_f32x2 __attribute__((ext_vector_type(2)));
 typedef float gc_f32x4 __attribute__((ext_vector_type(4)));
@@ -69,7 +48,7 @@ struct GcOperand {
     float4 v[VEC ? NV : 1];
     float s[VEC ? 1 : NS];
     unsigned okm;            // bit q: element q of this thread lies inside the operand (applied when the registers are
-                             // consumed — stash / sub_k — so that nothing waits for a load right after issuing it)
+                             // consumed — stash — so that nothing waits for a load right after issuing it)
 
     // Loads are unconditional from a clamped (always valid) address and zeroed afterwards: no branches in the main
     // loop.  VEC preconditions (the launchers check them): K-contiguous: ld % 4 == 0, kend % 4 == 0, 16-byte aligned
@@ -77,7 +56,7 @@ struct GcOperand {
     // Per-thread base pointers of the stage at k0 = 0 and the in-range mask of their rows, formed ONCE (bind): a stage
     // whose K range lies inside the operand then costs one 64-bit add of a uniform offset per 16-byte load.  Round 3
     // re-derived every address per stage — two v_mad_u64_u32, selects and compares per load, ~60 VALU instructions
-    // per K step — and the probes of round 4 (GC_DBG) priced the global loads at 13 % of the asymptotic rate.
+    // per K step — and the timing probes of round 4 priced the global loads at 13 % of the asymptotic rate.
     const float* base[VEC ? NV : 1];
     unsigned rowm = 0u;
     bool bound = false;
@@ -136,34 +115,12 @@ struct GcOperand {
         }
     }
 
-    // optional per-k offset (cost_gemm subtracts the common centre mu[k] on the way in): the offsets of the fetched
-    // k slice are loaded here and applied at stash time
-    // (out-of-range offsets need no zeroing of their own: they come from a clamped, valid address and the element they
-    //  are subtracted from is zeroed by okm when it is consumed.  A select right behind the load made the wave wait
-    //  for it — one L2 round trip per K step with no MFMA issued: round 4, tools/isa_report.py)
-    float4 off4; float off1; bool has_off = false, off_in = true;
-    __device__ __forceinline__ void sub_k(const float* __restrict__ mu, int k0, int kend) {
-        const int tid = threadIdx.x;
-        has_off = true;
-        if (VEC) {
-            static_assert(!KMAJOR, "sub_k: K-contiguous operands only");
-            const int gk = k0 + 4 * (tid % (BK / 4));
-            off_in = gk < kend;                          // kend % 4 == 0 (VEC precondition)
-            off4 = *reinterpret_cast<const float4*>(mu + (off_in ? gk : 0));
-        } else {
-            const int gk = k0 + tid % BK;
-            off_in = gk < kend;
-            off1 = mu[off_in ? gk : 0];
-        }
-    }
-
     __device__ __forceinline__ void stash(float* __restrict__ T) const {      // T: [BK][LD]
         const int tid = threadIdx.x;
         if (VEC) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 float4 x = v[q];
-                if (has_off) { x.x -= off4.x; x.y -= off4.y; x.z -= off4.z; x.w -= off4.w; }      // (k >= kend: zeroed by okm below)
                 if (!((okm >> q) & 1u)) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!KMAJOR) {
                     const int k = 4 * (tid % (BK / 4)), r = tid / (BK / 4) + q * (1024 / BK);
@@ -181,7 +138,6 @@ struct GcOperand {
                 if (!KMAJOR) { k = tid % BK; r = tid / BK + q * (256 / BK); }
                 else { r = tid % ROWS; k = tid / ROWS + q * (256 / ROWS); }
                 float x = s[q];
-                if (has_off) x -= off1;
                 T[k * LD + r] = ((okm >> q) & 1u) ? x : 0.f;
             }
         }
@@ -207,7 +163,7 @@ struct GemmCore {
 
     gc_f32x16 acc[M16 ? 1 : MT][M16 ? 1 : NT];
     gc_f32x4 acc16[2][2];
-    float pend_a[2][2], pend_b[2][2];       // GC_PIPE: fragments of the deferred group (two k-pairs / k-quads x two blocks)
+    float pend_a[2][2], pend_b[2][2];       // fragments of the deferred group (two k-pairs / k-quads x two blocks)
 
     __device__ __forceinline__ void zero() {
         if (M16) {
@@ -278,11 +234,10 @@ struct GemmCore {
             for (int g = 0; g < NG; ++g) {
                 const bool defer = PEND_OUT && g == NG - 1;
                 if (!defer) mm(2 * g);
-                if (NEXT && g == 0) { oa.stash(An); if (GC_FETCH_MODE == 2) fetch_a(); }
+                if (NEXT && g == 0) oa.stash(An);
                 if (NEXT && g == 1) ob.stash(Bn);
                 if (NEXT && NG == 1 && g == 0) ob.stash(Bn);
-                if (NEXT && GC_FETCH_MODE == 2 && g == (NG > 1 ? 1 : 0)) fetch_b();
-                if (NEXT && GC_FETCH_MODE != 2 && g == (GC_FETCH_MODE == 1 ? (NG > 1 ? 1 : 0) : (NG > 2 ? 2 : NG - 1))) { fetch_a(); fetch_b(); }
+                if (NEXT && g == (NG > 2 ? 2 : NG - 1)) { fetch_a(); fetch_b(); }       // the stage after next: behind the third group
                 if (!defer) mm(2 * g + 1);
                 else {
 #pragma unroll
@@ -329,58 +284,54 @@ struct GemmCore {
             if (PEND_OUT && g == NG - 1) {       // deferred: the fragments wait in registers for the next step (nothing else is scheduled in the last group when NG >= 4)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) { pend_a[h][0] = a[2 * g + h][0]; pend_a[h][1] = a[2 * g + h][1]; pend_b[h][0] = b[2 * g + h][0]; pend_b[h][1] = b[2 * g + h][1]; }
-                if (NEXT && !(GC_DBG & 2) && g == 0) { oa.stash(An); if (GC_FETCH_MODE == 2) fetch_a(); }
-                if (NEXT && !(GC_DBG & 2) && g == 1) ob.stash(Bn);
-                if (NEXT && !(GC_DBG & 2) && NG == 1 && g == 0) ob.stash(Bn);
-                if (NEXT && !(GC_DBG & 1) && GC_FETCH_MODE == 2 && g == (NG > 1 ? 1 : 0)) fetch_b();
-                if (NEXT && !(GC_DBG & 1) && GC_FETCH_MODE != 2 && g == (GC_FETCH_MODE == 1 ? (NG > 1 ? 1 : 0) : (NG > 2 ? 2 : NG - 1))) { fetch_a(); fetch_b(); }
+                if (NEXT && g == 0) oa.stash(An);
+                if (NEXT && g == 1) ob.stash(Bn);
+                if (NEXT && NG == 1 && g == 0) ob.stash(Bn);
+                if (NEXT && g == (NG > 2 ? 2 : NG - 1)) { fetch_a(); fetch_b(); }
                 __builtin_amdgcn_sched_barrier(0);
                 continue;
             }
-            mm((GC_DBG & 4) ? 0 : 2 * g);
-            if (NEXT && !(GC_DBG & 2) && g == 0) { oa.stash(An); if (GC_FETCH_MODE == 2) fetch_a(); }
-            if (NEXT && !(GC_DBG & 2) && g == 1) ob.stash(Bn);
-            if (NEXT && !(GC_DBG & 2) && NG == 1 && g == 0) ob.stash(Bn);
-            if (NEXT && !(GC_DBG & 1) && GC_FETCH_MODE == 2 && g == (NG > 1 ? 1 : 0)) fetch_b();
-            if (NEXT && !(GC_DBG & 1) && GC_FETCH_MODE != 2 && g == (GC_FETCH_MODE == 1 ? (NG > 1 ? 1 : 0) : (NG > 2 ? 2 : NG - 1))) { fetch_a(); fetch_b(); }
-            mm((GC_DBG & 4) ? 1 : 2 * g + 1);
-            if (!(GC_DBG & 4) && g + 2 < NG) { rd(2 * g + 4); rd(2 * g + 5); }
+            mm(2 * g);
+            if (NEXT && g == 0) oa.stash(An);
+            if (NEXT && g == 1) ob.stash(Bn);
+            if (NEXT && NG == 1 && g == 0) ob.stash(Bn);
+            if (NEXT && g == (NG > 2 ? 2 : NG - 1)) { fetch_a(); fetch_b(); }           // the stage after next: behind the third group
+            mm(2 * g + 1);
+            if (g + 2 < NG) { rd(2 * g + 4); rd(2 * g + 5); }
             __builtin_amdgcn_sched_barrier(0);       // the reads of group g + 2 stay in front of the MFMAs of group g + 1
         }
     }
 
-    // Main loop over [k_begin, k_end).  pre.a(opA, k0) / pre.b(opB, k0): hooks applied to freshly fetched registers (cost_gemm's
-    // centring); post(As_stage, k0): hook run once per stage after its barrier, before the MFMAs (wgrad's bias sums).
-    template <typename Pre, typename Post>
+    // Main loop over [k_begin, k_end).  post(As_stage, k0): hook run once per stage after its barrier, before the MFMAs
+    // (wgrad's bias sums).
+    template <typename Post>
     __device__ __forceinline__ void run(float* __restrict__ lds, const float* __restrict__ A, int lda, int row0, int M,
                                         const float* __restrict__ B, int ldb, int col0, int N, int k_begin, int k_end,
-                                        Pre pre, Post post) {
+                                        Post post) {
         GcOperand<BM, BK, A_KMAJOR, VEC_A> oa;
         GcOperand<BN, BK, B_KMAJOR, VEC_B> ob;
         float* As = lds; float* Bs = lds + 2 * STAGE_A;
         if (k_begin >= k_end) return;
         oa.bind(A, lda, row0, M); ob.bind(B, ldb, col0, N);
         oa.fetch(A, lda, row0, M, k_begin, k_end); ob.fetch(B, ldb, col0, N, k_begin, k_end);
-        pre.a(oa, k_begin); pre.b(ob, k_begin);
         oa.stash(As); ob.stash(Bs);
         __syncthreads();
         int st = 0;
-        if (k_begin + BK < k_end) { oa.fetch(A, lda, row0, M, k_begin + BK, k_end); ob.fetch(B, ldb, col0, N, k_begin + BK, k_end); pre.a(oa, k_begin + BK); pre.b(ob, k_begin + BK); }
+        if (k_begin + BK < k_end) { oa.fetch(A, lda, row0, M, k_begin + BK, k_end); ob.fetch(B, ldb, col0, N, k_begin + BK, k_end); }
         // ONE body in the loop, the last K step peeled behind it: with both step<> forms inside the loop (round 3) the
         // accumulators were loop-carried through a phi the register allocator resolved with a full copy of the
         // accumulator file on entry AND exit of every K step (64 + 64 v_accvgpr moves per step at 128 x 128:
         // tools/isa_report.py), a quarter of the step's issue slots with the matrix pipe idle behind them.
         int k0 = k_begin;
-        // GC_PIPE: the deferred group needs a fragment group to itself (NG >= 2 groups per step: every tile shape in use)
-        constexpr bool PIPE_BODY = GC_PIPE && ((M16 ? BK / 8 : BK / 4) >= 2);
-#if GC_PIPE
+        // the deferred group needs a fragment group to itself (NG >= 2 groups per step: every tile shape in use)
+        constexpr bool PIPE_BODY = ((M16 ? BK / 8 : BK / 4) >= 2);
         if (PIPE_BODY) {
             if (k0 + BK < k_end) {                   // the first step: nothing deferred comes in, its last group goes out
                 float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
                 post(Ac, k0);
                 step<true, false, true>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob,
-                           [&]() { if (k0 + 2 * BK < k_end) { oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); pre.a(oa, k0 + 2 * BK); } },
-                           [&]() { if (k0 + 2 * BK < k_end) { ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end); pre.b(ob, k0 + 2 * BK); } });
+                           [&]() { if (k0 + 2 * BK < k_end) { oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); } },
+                           [&]() { if (k0 + 2 * BK < k_end) { ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end); } });
                 __syncthreads();
                 st ^= 1; k0 += BK;
             } else {                                 // a single step: the deferred group that comes in is all zeros (adds + 0 to + 0)
@@ -388,25 +339,18 @@ struct GemmCore {
                 for (int h = 0; h < 2; ++h) { pend_a[h][0] = pend_a[h][1] = 0.f; pend_b[h][0] = pend_b[h][1] = 0.f; }
             }
         }
-#endif
         for (; k0 + BK < k_end; k0 += BK) {
             float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
             post(Ac, k0);
-#if GC_FAIR
-            if (((blockIdx.x >> 8) ^ (unsigned)((k0 - k_begin) / BK)) & 1u) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0");
-#endif
             step<true, PIPE_BODY, PIPE_BODY>(Ac, Bc, As + (st ^ 1) * STAGE_A, Bs + (st ^ 1) * STAGE_B, oa, ob,
-                       [&]() { if (k0 + 2 * BK < k_end) { oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); pre.a(oa, k0 + 2 * BK); } },
-                       [&]() { if (k0 + 2 * BK < k_end) { ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end); pre.b(ob, k0 + 2 * BK); } });
-            if (!(GC_DBG & 8)) __syncthreads();
+                       [&]() { if (k0 + 2 * BK < k_end) { oa.fetch(A, lda, row0, M, k0 + 2 * BK, k_end); } },
+                       [&]() { if (k0 + 2 * BK < k_end) { ob.fetch(B, ldb, col0, N, k0 + 2 * BK, k_end); } });
+            __syncthreads();
             st ^= 1;
         }
         {
             float* Ac = As + st * STAGE_A; float* Bc = Bs + st * STAGE_B;
             post(Ac, k0);
-#if GC_FAIR
-            asm volatile("s_setprio 0");
-#endif
             step<false, PIPE_BODY, false>(Ac, Bc, nullptr, nullptr, oa, ob, []() {}, []() {});
         }
     }
@@ -428,8 +372,4 @@ struct GemmCore {
     }
 };
 
-struct GcNoPre {
-    template <typename OA> __device__ __forceinline__ void a(OA&, int) const {}
-    template <typename OB> __device__ __forceinline__ void b(OB&, int) const {}
-};
 struct GcNoPost { __device__ __forceinline__ void operator()(const float*, int) const {} };

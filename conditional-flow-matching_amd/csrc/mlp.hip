@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, in
     const int row0 = tm * BM, col0 = tn * BN;
     Core g;
     g.zero();
-    g.run(lds, X, lda, row0, B, W, ldw, col0, N, 0, K, GcNoPre(), GcNoPost());
+    g.run(lds, X, lda, row0, B, W, ldw, col0, N, 0, K, GcNoPost());
     // epilogue: bias + time column + (pre-activation) + SELU; a lane owns EU adjacent columns
     constexpr int EU = Core::EU, EM = Core::EM, ER = Core::ER;
     const float tsc = (tcol >= 0 && !t_per_row) ? (tptr ? tptr[0] : tval) : 0.f;
@@ -89,18 +89,15 @@ extern "C" size_t cfm_mlp_ws_bytes_internal(int B, int width) {
     return 2 * sizeof(float) * (size_t)B * (size_t)width + 256;
 }
 
-// Tile choice of the dense products (shared with mlp_train.hip): 0 = 128 x 128 x 16, 1 = 128 x 64 x 32,
-// 2 = 64 x 64 x 32 — the largest tile that still gives the chip about one workgroup per CU.
-// CFM_GEMM_TILE=0|1|2 forces one (measurement switch: same bits whatever the tile).
+// Tile choice of the dense products (shared with mlp_train.hip): 0 = 128 x 128 x 16, 2 = 64 x 64 x 32 — the largest
+// tile that still gives the chip about two workgroups per CU (same bits whatever the tile).
+// Measured at the C3 layer shapes: 128 x 128 needs >= 2 workgroups per CU to pay (1024 tiles at 4096 x 4096); below
+// that the 64 x 64 tile (four 16x16x4 accumulators per wave, 2+ workgroups per CU) wins.  128 x 64 at one workgroup
+// per CU was measured twice (round 3; round 5 with the pipelined K-step boundary: C3 model step 501 vs 428 us,
+// profiles/r5_experiments.txt) and removed.
 int cfm_gemm_pick_tile(long M, long N, long splits) {
-    static const int forced = [] { const char* e = getenv("CFM_GEMM_TILE"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
-    if (forced >= 0) return forced;
-    // measured at the C3 layer shapes (tools/gemm_bench.py): 128 x 128 needs >= 2 workgroups per CU to pay
-    // (cost matrix: 1024 tiles); below that the 64 x 64 tile (four 16x16x4 accumulators per wave, 2+ workgroups
-    // per CU) beats 128 x 64 at one workgroup per CU
     const long t0 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
-    if (t0 >= 512) return 0;
-    return 2;
+    return t0 >= 512 ? 0 : 2;
 }
 
 template <bool ACT, bool VECA, bool VECB>
@@ -110,9 +107,6 @@ static void launch_layer_t(int tile, const float* X, int lda, const float* W, in
     if (tile == 0) {
         const int tm = (B + 127) / 128, tn = (N + 127) / 128;
         hipLaunchKernelGGL((mlp_layer<128, 128, 16, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
-    } else if (tile == 1) {
-        const int tm = (B + 127) / 128, tn = (N + 63) / 64;
-        hipLaunchKernelGGL((mlp_layer<128, 64, 32, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
     } else {
         const int tm = (B + 63) / 64, tn = (N + 63) / 64;
         hipLaunchKernelGGL((mlp_layer<64, 64, 32, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
     };
     Core g;
     g.zero();
-    g.run(lds, A, lda, row0, M, Bm, ldb, col0, N, k_begin, k_end, GcNoPre(), post);
+    g.run(lds, A, lda, row0, M, Bm, ldb, col0, N, k_begin, k_end, post);
     if (A_KMAJOR && do_colsum && row0 + tid < M) {
         colsum[(size_t)blockIdx.y * M + row0 + tid] = csum;
         if (do_tsum) tsum[(size_t)blockIdx.y * M + row0 + tid] = wsum;
@@ -158,10 +158,6 @@ static void launch_gemm_t(int tile, const float* A, int lda, const float* Bm, in
     if (tile == 0) {
         const int tm = (M + 127) / 128, tn = (N + 127) / 128;
         hipLaunchKernelGGL((gemm_f32_mfma<128, 128, 16, AK, BK_, EPI, VA, VB>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
-                           split_stride, H, M, N, Kc, k_chunk, tn, colsum, tvec, tsum);
-    } else if (tile == 1) {
-        const int tm = (M + 127) / 128, tn = (N + 63) / 64;
-        hipLaunchKernelGGL((gemm_f32_mfma<128, 64, 32, AK, BK_, EPI, VA, VB>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
                            split_stride, H, M, N, Kc, k_chunk, tn, colsum, tvec, tsum);
     } else {
         const int tm = (M + 63) / 64, tn = (N + 63) / 64;

@@ -353,9 +353,7 @@ extern "C" int cfm_ode_dopri5_mlp_f32(const float* const* W, const float* const*
 // =====================================================================================
 #define SM_W 64
 #define SM_LD 68     // row stride = 4 (mod 64): fragment reads (row = lane & 15, k = lane >> 4) hit 64 distinct banks
-#ifndef SM_MB
 #define SM_MB 1      // 16-row blocks per tile = independent MFMA accumulator chains per wave
-#endif
 #define SM_ROWS (16 * SM_MB)
 #define SM_V (4 * SM_MB)   // tile floats per lane: element i -> row sm_row(i, lane), column 16 * wave + (lane & 15)
 
@@ -575,12 +573,6 @@ __global__ __launch_bounds__(256) void ode_small_dopri(SmArgs A, int B, int d, S
     int attempt = 0, err = 0;
     for (; !st.done; ++attempt) {
         if (attempt >= max_attempts) { err = 1; break; }
-#ifdef SM_PROF
-        unsigned long long* prof = lines + 16;
-        const int pslot = (blockIdx.x == 0) ? 0 : (blockIdx.x == gridDim.x - 1 ? 1 : (blockIdx.x == 100 ? 2 : -1));
-        const bool pon = tid == 0 && pslot >= 0 && attempt >= 20 && attempt < 38;
-        if (pon) prof[(pslot * 18 + attempt - 20) * 4 + 0] = wall_clock64();
-#endif
         if (tid == 0)                                 // re-arm this workgroup's slot of the next attempt
             __hip_atomic_store(&partial[(size_t)((attempt + 1) % 3) * SM_MAXGRID + blockIdx.x], __longlong_as_double(-1ll),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -644,14 +636,8 @@ __global__ __launch_bounds__(256) void ode_small_dopri(SmArgs A, int B, int d, S
         esum = wave_sum_d(esum);
         if (lane == 0) redw[wv] = esum;
         if (RESIDENT) sm_lds_barrier(); else __syncthreads();   // (the streamed path re-reads its rows below)
-#ifdef SM_PROF
-        if (pon) prof[(pslot * 18 + attempt - 20) * 4 + 1] = wall_clock64();
-#endif
         if (!sm_grid_allsum(partial + (size_t)(attempt % 3) * SM_MAXGRID, redw[0] + redw[1] + redw[2] + redw[3], tid, lane,
                             wv, &sh_total, &sh_ok)) { err = 2; break; }
-#ifdef SM_PROF
-        if (pon) prof[(pslot * 18 + attempt - 20) * 4 + 2] = wall_clock64();
-#endif
         // accept / reject, next step size (identical in every workgroup and lane)
         const float ratio = (float)sqrt(sh_total / (double)n);
         const bool accept = ratio <= 1.f;

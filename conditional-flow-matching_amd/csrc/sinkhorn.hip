@@ -342,15 +342,9 @@ __device__ __forceinline__ void sk_row_trip(const float4 (&c)[U], int j0, double
 }
 
 #define SK_ROW_PRE 16   // float4 per lane in flight per 4096-column segment
-#ifndef SK_ROW_WAVES
 #define SK_ROW_WAVES 4   // waves per workgroup of the fast row pass
-#endif
-#ifndef SK_RPW
 #define SK_RPW 4         // rows per workgroup of the fast row pass (a multiple of SK_ROW_WAVES)
-#endif
-#ifndef SK_ROW_OCC
 #define SK_ROW_OCC 3     // waves per SIMD the fast row pass is compiled for
-#endif
 #define SK_ROW_THREADS (64 * SK_ROW_WAVES)
 
 // One wave per row; the row's first segment was loaded BEFORE v was staged into LDS (the two
@@ -498,15 +492,9 @@ __global__ __launch_bounds__(FAST ? SK_ROW_THREADS : 256, FAST ? SK_ROW_OCC : 4)
 // flight while the previous one is reduced.  Measured on the 64 MiB matrix (scratch/probe): a
 // one-shot "request the row, stage v, reduce" workgroup shape takes 18 us where the bare reads take
 // 10.7 us — all of the exp/LDS work lands behind the last load — a streaming shape 11.7 us.
-#ifndef SK_STREAM_WAVES
 #define SK_STREAM_WAVES 8
-#endif
-#ifndef SK_STREAM_UNIT
 #define SK_STREAM_UNIT 4         // float4 per lane and unit at most (256 columns each); 8, 16: 2 % and 9 % slower
-#endif
-#ifndef SK_STREAM_OCC
 #define SK_STREAM_OCC 2          // waves per SIMD the streaming row pass is compiled for
-#endif
 #define SK_STREAM_THREADS (64 * SK_STREAM_WAVES)
 
 // One 256*NF4-column unit: reduce the registers trip by trip; with NEXT, each trip's registers are

@@ -31,14 +31,10 @@ struct SkState {
 };
 extern "C" size_t cfm_sk_ws_bytes_internal(int B0, int B1);
 
-#ifndef PTS_T
 #define PTS_T 1024
-#endif
 #define PTS_NW (PTS_T / 64)
 #define PTS_OWN 16           // own points per workgroup
-#ifndef PTS_U
 #define PTS_U 8              // other points per trip and lane
-#endif
 #define PTS_STRIDE (PTS_NW * 4)   // lane-groups (wave, sub) interleave the other side's points
 // other points per trip and lane, by dimension: a trip keeps U x D coordinates + 2 U doubles in registers, and the
 // 1024-thread workgroup leaves 128 per lane — at U = 8, d = 6 / 7 / 8 spilled 48 / 100 / 248 bytes per lane (round 3);
@@ -116,9 +112,6 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane >> 4, ol = lane & 15;
     const int o = blockIdx.x * PTS_OWN + ol;
-#ifdef PTS_PROF
-    long long tp0 = clock64(), tp1 = 0, tp2 = 0;
-#endif
     // A launch starts cold: everything the first chunk needs — the own point, this thread's share of the
     // other cloud and of its potentials — is requested before the state block is looked at.
     float own[D];
@@ -185,28 +178,16 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
             }
         }
         __syncthreads();
-#ifdef PTS_PROF
-        tp1 = clock64();
-#endif
         const int first = wv * 4 + sub;          // lane-group (wave, sub) takes points first, first + PTS_STRIDE, ...
         if (precise) pts_accumulate<D, true>(own, pts_lds, pot_lds, first, n_stage, inv_reg, m, s_acc);
         else         pts_accumulate<D, false>(own, pts_lds, pot_lds, first, n_stage, inv_reg, m, s_acc);
     }
-#ifdef PTS_PROF
-    tp2 = clock64();
-#endif
     // merge the 4 sub-groups of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48) ...
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1)
         pts_merge(m, s_acc, __shfl_xor(m, off, 64), __shfl_xor(s_acc, off, 64), precise != 0);
     if (sub == 0) { sm[wv][ol] = m; ss[wv][ol] = s_acc; }
-#ifdef PTS_PROF
-    long long tp3 = clock64();
-#endif
     __syncthreads();
-#ifdef PTS_PROF
-    long long tp4 = clock64();
-#endif
     // ... then the 16 waves: lane (sub, ol) of wave 0 folds waves 4 sub .. 4 sub + 3, two more lane exchanges
     if (wv == 0) {
         m = sm[sub * (PTS_NW / 4)][ol]; s_acc = ss[sub * (PTS_NW / 4)][ol];
@@ -229,12 +210,6 @@ __global__ __launch_bounds__(PTS_T) void sk_pts_pass(const float* __restrict__ o
             if (lane == 0) atomicAdd(&st->err2[slot], e2);
         }
     }
-#ifdef PTS_PROF
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
-        long long* dbg = reinterpret_cast<long long*>(st) + 8 + (blockIdx.x ? 4 : 0);     // bytes 64.. of the 256-byte state block
-        dbg[0] = tp1 - tp0; dbg[1] = tp2 - tp1; dbg[2] = ((tp3 - tp2) << 32) | (tp4 - tp3); dbg[3] = clock64() - tp4;
-    }
-#endif
 }
 
 // (kernels of sinkhorn.hip, reused through their C entry points would need a header; the three small ones

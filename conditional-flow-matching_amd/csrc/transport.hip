@@ -27,7 +27,7 @@
 // (~100 cycles, four per pass over the columns) — 255 x 256 0.66 s, 200 x 333 (d = 16) 0.30 s; the first version
 // (whole-list passes instead of the column chains, shuffle reductions: 155 ms / 1.3 s / 0.59 s) took 2.7 s (d = 64) to
 // 10.9 s (d = 2) at 512 x 500 and 25 s at 1000 x 1024.  Nearly equal sizes cascade partial flows down long chains
-// (tools/proto/proto20.py has the counts, proto24.py the same finding for an auction), so this is the EXACT path for the
+// (round-3 host prototypes counted them; the same finding held for an auction), so this is the EXACT path for the
 // sizes of the reference's tutorials and tests — the Python side sends B0 + B1 <= 512 here — not a fast one, and not
 // for 4096 vs 4000.  (POT's network simplex on the host: about a millisecond at 127 x 128.)
 #include "cfm_common.h"

@@ -23,9 +23,6 @@
 #include "cfm_common.h"
 
 #define UB_NCHUNK_MAX 64
-#ifndef UB_FUSED
-#define UB_FUSED 1               // 0: the launch-per-step loops of round 3 (A/B switch; same results)
-#endif
 
 struct UbState {
     int done, iters, status, final_idx;   // status: 0 ok, 1 numerical error (previous iterate returned)
@@ -120,36 +117,6 @@ __global__ void ub_state_init(UbState* st) {
     }
 }
 
-// ---------------------------------------------------------------- streaming passes
-// y_i = scale_i * sum_j K_ij x_j  (scale may be null).  One wave per row.
-__global__ __launch_bounds__(256) void ub_rowdot(const double* __restrict__ K, int B0, int B1,
-                                                 const UbState* __restrict__ st,
-                                                 const double* __restrict__ x,
-                                                 double* __restrict__ y) {
-    if (st->done) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wv;
-    if (r >= B0) return;
-    const double* row = K + (size_t)r * B1;
-    double acc = 0.0;
-    if ((B1 & 1) == 0) {
-        for (int j = lane * 2; j < B1; j += 128 * 4) {
-            double2 k2[4], x2[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int jj = j + 128 * q;
-                k2[q] = (jj < B1) ? *reinterpret_cast<const double2*>(row + jj) : make_double2(0.0, 0.0);
-                x2[q] = (jj < B1) ? *reinterpret_cast<const double2*>(x + jj) : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc += k2[q].x * x2[q].x + k2[q].y * x2[q].y;
-        }
-    } else {
-        for (int j = lane; j < B1; j += 64) acc += row[j] * x[j];
-    }
-    acc = wave_sum_d(acc);
-    if (lane == 0) y[r] = acc;
-}
 
 // partial column sums over a strip of rows: part[chunk][j] = sum_{i in strip} w_i K_ij
 __global__ __launch_bounds__(256) void ub_coldot(const double* __restrict__ K, int B0, int B1,
@@ -180,62 +147,8 @@ __device__ __forceinline__ void ub_atomic_max_abs(unsigned long long* slot, doub
     atomicMax(slot, (unsigned long long)__double_as_longlong(fabs(v)));
 }
 
-// ---------------------------------------------------------------- unbalanced
-// u_new = (a / Kv)^fi  from rowacc = K v
-__global__ void ub_u_update(int B0, double a, double fi, UbState* st, const double* __restrict__ Kv,
-                            const double* __restrict__ uprev, double* __restrict__ unew, int check) {
-    if (st->done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B0) return;
-    const double u = pow(a / Kv[i], fi);
-    unew[i] = u;
-    if (isnan(u) || isinf(u)) atomicOr(&st->flag_bad, 1);
-    if (check) {
-        const double up = uprev[i];
-        ub_atomic_max_abs(&st->mx[0], u - up); ub_atomic_max_abs(&st->mx[1], u); ub_atomic_max_abs(&st->mx[2], up);
-    }
-}
 
-// Ktu_j = sum of strips; v_new = (b / Ktu)^fi
-__global__ void ub_v_update(int B1, int nchunk, double b, double fi, UbState* st,
-                            const double* __restrict__ part, const double* __restrict__ vprev,
-                            double* __restrict__ vnew, int check) {
-    if (st->done) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= B1) return;
-    double ktu = 0.0;
-    for (int c = 0; c < nchunk; ++c) ktu += part[(size_t)c * B1 + j];
-    const double v = pow(b / ktu, fi);
-    vnew[j] = v;
-    if (ktu == 0.0 || isnan(v) || isinf(v)) atomicOr(&st->flag_bad, 1);
-    if (check) {
-        const double vp = vprev[j];
-        ub_atomic_max_abs(&st->mx[3], v - vp); ub_atomic_max_abs(&st->mx[4], v); ub_atomic_max_abs(&st->mx[5], vp);
-    }
-}
 
-// loop control of iteration `cpt` (runner/...:150-186): numerical error -> previous iterate;
-// every 10th iteration the error; `while err > stopThr and cpt < numItermax`.
-__global__ void ub_decide(UbState* st, int cpt, int max_iter, double stop_thr, int check) {
-    if (st->done) return;
-    if (st->flag_bad) {                      // u, v = uprev, vprev; break
-        st->status = 1; st->final_idx = cpt & 1; st->iters = cpt; st->done = 1;
-        return;
-    }
-    if (check) {
-        const double du = __longlong_as_double((long long)st->mx[0]), mu = __longlong_as_double((long long)st->mx[1]),
-                     mup = __longlong_as_double((long long)st->mx[2]);
-        const double dv = __longlong_as_double((long long)st->mx[3]), mv = __longlong_as_double((long long)st->mx[4]),
-                     mvp = __longlong_as_double((long long)st->mx[5]);
-        const double err_u = du / fmax(fmax(mu, mup), 1.0);
-        const double err_v = dv / fmax(fmax(mv, mvp), 1.0);
-        st->err = 0.5 * (err_u + err_v);
-        for (int k = 0; k < 6; ++k) st->mx[k] = 0ull;
-    }
-    const int next = cpt + 1;
-    st->iters = next; st->final_idx = next & 1;
-    if (!(st->err > stop_thr) || next >= max_iter) st->done = 1;
-}
 
 // plan = u_i K_ij v_j  (in place)
 __global__ __launch_bounds__(256) void ub_plan(double* __restrict__ K, int B0, int B1,
@@ -390,8 +303,10 @@ __global__ __launch_bounds__(UB_COLW) void ub_col_fused(int B1, int nchunk, UbSt
     // arrival: the last workgroup (one wave) takes the control decision of the iteration.  What it needs from the other
     // workgroups of THIS launch travels through device-scope atomics (total, flags, column maxima); the row side it
     // reads from the arrays the row kernel wrote one launch earlier.
+    // (the ticket is an acquire-release operation at device scope: the atomics above are ordered before it and the
+    //  deciding wave's reads behind it by the memory model, not by the fields happening to share one 256-byte block)
     unsigned tt = 0u;
-    if (threadIdx.x == 0) tt = atomicAdd(&st->tiles_done, 1u);
+    if (threadIdx.x == 0) tt = __hip_atomic_fetch_add(&st->tiles_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     tt = (unsigned)__shfl((int)tt, 0, 64);
     if (tt != gridDim.x - 1u) return;
     const int lane = threadIdx.x;
@@ -480,7 +395,6 @@ extern "C" int cfm_unbalanced_sinkhorn_f64(const float* M, int B0, int B1, doubl
     for (int cpt = 0; cpt < max_iter; ++cpt) {
         const int check = (cpt % 10 == 0) ? 1 : 0;
         const int p = cpt & 1, q = p ^ 1;
-#if UB_FUSED
         hipLaunchKernelGGL(ub_row_fused<0>, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], a, fi,
                            w.U[p], w.U[q], (double*)nullptr, check, p);
         hipLaunchKernelGGL(ub_coldot, dim3((B1 + 255) / 256, nchunk), dim3(256), 0, s, plan, B0, B1, w.st,
@@ -488,16 +402,6 @@ extern "C" int cfm_unbalanced_sinkhorn_f64(const float* M, int B0, int B1, doubl
         hipLaunchKernelGGL(ub_col_fused<0>, dim3((B1 + UB_COLW - 1) / UB_COLW), dim3(UB_COLW), 0, s, B1, nchunk, w.st, w.part, b, fi,
                            w.V[p], w.V[q], (double*)nullptr, check, cpt, max_iter, stop_thr, 0.0, 0, (const double*)nullptr,
                            B0, (const double*)w.U[p], (const double*)w.U[q]);
-#else
-        hipLaunchKernelGGL(ub_rowdot, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], w.rowacc);
-        hipLaunchKernelGGL(ub_u_update, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, a, fi, w.st, w.rowacc,
-                           w.U[p], w.U[q], check);
-        hipLaunchKernelGGL(ub_coldot, dim3((B1 + 255) / 256, nchunk), dim3(256), 0, s, plan, B0, B1, w.st,
-                           w.U[q], w.part, rows_per_chunk);
-        hipLaunchKernelGGL(ub_v_update, dim3((B1 + 255) / 256), dim3(256), 0, s, B1, nchunk, b, fi, w.st,
-                           w.part, w.V[p], w.V[q], check);
-        hipLaunchKernelGGL(ub_decide, dim3(1), dim3(1), 0, s, w.st, cpt, max_iter, stop_thr, check);
-#endif
     }
     hipLaunchKernelGGL(ub_plan, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[0], w.U[1], w.V[0], w.V[1], 0);
     hipLaunchKernelGGL(ub_info, dim3(1), dim3(64), 0, s, w.st, info);
@@ -511,44 +415,7 @@ __global__ __launch_bounds__(256) void pt_scale(double* __restrict__ K, size_t n
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) K[k] *= f;
 }
 
-// rows: alpha1 = alpha * rho; rowsum = alpha1 * (K0 beta); r = min(a / rowsum, 1);
-//       alpha2 = r * alpha1; rho <- rho * alpha / alpha2
-__global__ void pt_row_update(int B0, double a, const UbState* st, const double* __restrict__ Kb,
-                              const double* __restrict__ alpha, double* __restrict__ rho,
-                              double* __restrict__ alpha2) {
-    if (st->done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B0) return;
-    const double al = alpha[i], a1 = al * rho[i];
-    const double rowsum = a1 * Kb[i];
-    const double r = fmin(a / rowsum, 1.0);
-    const double a2 = r * a1;
-    alpha2[i] = a2;
-    rho[i] = rho[i] * al / a2;
-}
 
-// cols: beta1 = beta * kappa; colsum = beta1 * (K0^T alpha2); c = min(b / colsum, 1);
-//       beta2 = c * beta1; kappa <- kappa * beta / beta2; total += beta2 * (K0^T alpha2)
-__global__ void pt_col_update(int B1, int nchunk, double b, UbState* st, const double* __restrict__ part,
-                              const double* __restrict__ beta, double* __restrict__ kappa,
-                              double* __restrict__ beta2) {
-    if (st->done) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double contrib = 0.0;
-    if (j < B1) {
-        double kta = 0.0;
-        for (int c = 0; c < nchunk; ++c) kta += part[(size_t)c * B1 + j];
-        const double be = beta[j], b1 = be * kappa[j];
-        const double colsum = b1 * kta;
-        const double cc = fmin(b / colsum, 1.0);
-        const double b2 = cc * b1;
-        beta2[j] = b2;
-        kappa[j] = kappa[j] * be / b2;
-        contrib = b2 * kta;
-    }
-    contrib = wave_sum_d(contrib);
-    if ((threadIdx.x & 63) == 0 && contrib != 0.0) atomicAdd(&st->total, contrib);
-}
 
 // || diag(alpha) K0 diag(beta) - diag(alpha2) K0 diag(beta2) ||_F^2 (alpha2 already carries sigma * s)
 __global__ __launch_bounds__(256) void pt_err(const double* __restrict__ K, int B0, int B1, UbState* st,
@@ -573,16 +440,6 @@ __global__ __launch_bounds__(256) void pt_err(const double* __restrict__ K, int 
     if (threadIdx.x == 0) atomicAdd(&st->err2, sd[0] + sd[1] + sd[2] + sd[3]);
 }
 
-// scalar step: K = K2 * q3 * (m / sum(K2 * q3)); q3 <- q3 * K2prev / K = 1 / s; folds the factor
-// sigma * s into alpha2 (kernel pt_fold) — here only the scalars.
-__global__ void pt_scalar(UbState* st, double m) {
-    if (st->done) return;
-    const double S = st->sigma * st->total;      // sum(K2 * q3)
-    const double s = m / S;
-    st->fold[0] = st->sigma * s;                 // the scalar factor of this iteration, folded into alpha2 (launch-per-step loop)
-    st->sigma = 1.0 / s;
-    st->total = 0.0;
-}
 
 __global__ void pt_fold(int B0, const UbState* st, double* __restrict__ alpha2) {
     if (st->done) return;
@@ -592,15 +449,6 @@ __global__ void pt_fold(int B0, const UbState* st, double* __restrict__ alpha2) 
     }
 }
 
-__global__ void pt_flags(int B0, int B1, UbState* st, const double* __restrict__ alpha2,
-                         const double* __restrict__ beta2) {
-    if (st->done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int bad = 0;
-    if (i < B0 && !isfinite(alpha2[i])) bad = 1;
-    if (i < B1 && !isfinite(beta2[i])) bad = 1;
-    if (bad) atomicOr(&st->flag_bad, 1);
-}
 
 // loop control (POT entropic_partial_wasserstein): nan / inf in K -> warning, break (K kept);
 // cpt % 10 == 0: err = ||Kprev - K||_F; `while err > stopThr and cpt < numItermax`.
@@ -640,7 +488,6 @@ extern "C" int cfm_partial_entropic_f64(const float* M, int B0, int B1, double r
     for (int cpt = 0; cpt < max_iter; ++cpt) {
         const int check = (cpt % 10 == 0) ? 1 : 0;
         const int p = cpt & 1, q = p ^ 1;    // (alpha, beta) = (U[p], V[p]) -> (U[q], V[q])
-#if UB_FUSED
         hipLaunchKernelGGL(ub_row_fused<1>, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], a, 0.0,
                            w.U[p], w.U[q], w.rho, 0, p);
         hipLaunchKernelGGL(ub_coldot, dim3((B1 + 255) / 256, nchunk), dim3(256), 0, s, plan, B0, B1, w.st,
@@ -652,25 +499,8 @@ extern "C" int cfm_partial_entropic_f64(const float* M, int B0, int B1, double r
             hipLaunchKernelGGL(pt_err, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[p], w.V[p], w.U[q], w.V[q], p);
             hipLaunchKernelGGL(pt_decide, dim3(1), dim3(1), 0, s, w.st, cpt, max_iter, stop_thr, check, w.colacc);
         }
-#else
-        hipLaunchKernelGGL(ub_rowdot, dim3((B0 + 3) / 4), dim3(256), 0, s, plan, B0, B1, w.st, w.V[p], w.rowacc);
-        hipLaunchKernelGGL(pt_row_update, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, a, w.st, w.rowacc,
-                           w.U[p], w.rho, w.U[q]);
-        hipLaunchKernelGGL(ub_coldot, dim3((B1 + 255) / 256, nchunk), dim3(256), 0, s, plan, B0, B1, w.st,
-                           w.U[q], w.part, rows_per_chunk);
-        hipLaunchKernelGGL(pt_col_update, dim3((B1 + 255) / 256), dim3(256), 0, s, B1, nchunk, b, w.st, w.part,
-                           w.V[p], w.kappa, w.V[q]);
-        hipLaunchKernelGGL(pt_scalar, dim3(1), dim3(1), 0, s, w.st, m);
-        hipLaunchKernelGGL(pt_fold, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, w.st, w.U[q]);
-        hipLaunchKernelGGL(pt_flags, dim3((nmax + 255) / 256), dim3(256), 0, s, B0, B1, w.st, w.U[q], w.V[q]);
-        if (check)
-            hipLaunchKernelGGL(pt_err, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[p], w.V[p], w.U[q], w.V[q], -1);
-        hipLaunchKernelGGL(pt_decide, dim3(1), dim3(1), 0, s, w.st, cpt, max_iter, stop_thr, check, w.colacc);
-#endif
     }
-#if UB_FUSED
     hipLaunchKernelGGL(pt_fold_final, dim3((B0 + 255) / 256), dim3(256), 0, s, B0, w.st, w.U[0], w.U[1]);
-#endif
     // POT keeps the NaN matrix when K had zeros (0 / 0 in the q updates poisons every entry within
     // two iterations): reproduce it so the caller's diagnostics (optimal_transport.py:88-92) fire
     hipLaunchKernelGGL(ub_plan, dim3(2048), dim3(256), 0, s, plan, B0, B1, w.st, w.U[0], w.U[1], w.V[0], w.V[1], 1);

@@ -414,6 +414,15 @@ class OTPlanSampler:
     # ---- device-resident solve (no host plan) ----
     def _prepare(self, x0, x1):
         dev = _lib.require_gpu()
+        # The reference computes torch.cdist in the INPUT dtype (ref:84) and hands POT that matrix; the device
+        # solvers take an fp32 cost matrix (fp64 duals / potentials on top of it).  float64 clouds are therefore
+        # coupled on the fp32 rounding of their coordinates — said once per sampler, never silently (the matchers'
+        # x_t / u_t arithmetic does honour float64: it takes the composed eager path).
+        if self.warn and not getattr(self, "_warned_f64", False) and \
+                (getattr(x0, "dtype", None) == torch.float64 or getattr(x1, "dtype", None) == torch.float64):
+            self._warned_f64 = True
+            warnings.warn("OTPlanSampler: float64 inputs are coupled on a float32 cost matrix (the device solvers' input "
+                          "precision); the reference would solve on the float64 matrix.", UserWarning, stacklevel=3)
         a = _lib.to_dev_f32(_flatten2(x0), dev)
         b = _lib.to_dev_f32(_flatten2(x1), dev)
         M = cost_matrix(a, b, squared=True, normalize=self.normalize_cost)
@@ -666,7 +675,35 @@ class OTPlanSampler:
         # slice, in row order (np.random.choice draws one double per call, ref:244).
         rows = torch.arange(n, dtype=torch.int64, device=dev)
         chain = [rows]
-        for kind, sol, M in sols:
+        for t, (kind, sol, M) in enumerate(sols):
+            # get_map's diagnostics per slice (ref:88-96, called at ref:233): a non-finite plan is reported and
+            # np.random.choice raises on it (ref:244); a plan without mass reverts to the uniform plan.  One small
+            # device reduction + read-back per entropic slice (exact slices have neither case).
+            uniform = False
+            if kind == "plan":
+                finite = bool(torch.isfinite(sol).all())
+                total = float(sol.sum()) if finite else float("nan")
+                if not finite:
+                    print("ERROR: p is not finite")
+                    print(sol)
+                    print("Cost mean, max", M.mean(), M.max())
+                    print(X[:, t], X[:, t + 1])
+                    raise ValueError("probabilities contain NaN")
+                uniform = abs(total) < 1e-8
+            elif kind == "dense":
+                if not bool(torch.isfinite(sol.f).all() and torch.isfinite(sol.g).all()):
+                    print("ERROR: p is not finite")
+                    print("Cost mean, max", M.mean(), M.max())
+                    print(X[:, t], X[:, t + 1])
+                    raise ValueError("probabilities contain NaN")
+            if uniform:
+                if self.warn:
+                    warnings.warn("Numerical errors in OT plan, reverting to uniform plan.")
+                sol = torch.full(tuple(M.shape), 1.0 / M.numel(), dtype=torch.float64, device=dev)   # ref:96
+            elif kind == "plan":
+                # a visited row without mass: pi[i] / pi[i].sum() is NaN and np.random.choice raises (ref:244)
+                if bool((sol.sum(1)[rows] <= 0).any()):
+                    raise ValueError("probabilities contain NaN")
             u = _u01_to_device(np.random.random_sample(n), dev)
             if kind == "perm":
                 # a permutation plan: row i has the single nonzero pi[i, perm[i]] (the draw is consumed)

@@ -43,6 +43,12 @@ class ChipPartition:
     def __init__(self, device=None, solver_cus_per_xcd=4, dense_all=False, solver_all=False):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        # The mask layout (bit i = XCD i % 8, CU i // 8 of it) is the SPX mode of an 8-XCD part (MI355X: 256 CUs).  A
+        # CPX / NPS-partitioned device or another part exposes a different CU count per agent: refuse instead of building
+        # masks whose two halves are no longer complementary per XCD.
+        if ncu % N_XCD != 0 or ncu < 2 * N_XCD:
+            raise RuntimeError(f"ChipPartition assumes {N_XCD} XCDs in SPX mode; this device reports {ncu} CUs "
+                               "(compute-partitioned mode?): run without a partition")
         per = ncu // N_XCD
         k = int(solver_cus_per_xcd)
         if not 1 <= k < per:

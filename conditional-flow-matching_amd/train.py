@@ -37,6 +37,8 @@ class RegressionStep:
         if not isinstance(net, MLP):
             raise TypeError("RegressionStep drives a cfm_amd.MLP vector field")
         self.net, self.opt = net, optimizer
+        from .optim import FusedAdam
+        self._fused_opt = isinstance(optimizer, FusedAdam)           # its step() takes the 1 / world of the mean (grad_scale)
         self.lins = net._linears()
         self.n = len(self.lins)
         dev = self.lins[0].weight.device
@@ -136,5 +138,9 @@ class RegressionStep:
                 works.append(dist.all_reduce(self._buckets[l], async_op=True))
         for w in works:
             w.wait()                                                 # the compute stream waits for the buckets
-        self.opt.step(grad_scale=1.0 / world)                        # sum -> mean inside the Adam launch
+        if self._fused_opt:
+            self.opt.step(grad_scale=1.0 / world)                    # sum -> mean inside the Adam launch
+        else:                                                        # any other optimizer: scale the buckets, then its own step
+            self.flat_grad.mul_(1.0 / world)
+            self.opt.step()
         return loss

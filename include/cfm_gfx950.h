@@ -34,6 +34,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: only what this header (and cfm_gfx950_tuning.h) declares leaves it. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define CFM_ABI_VERSION 2
 
@@ -382,6 +386,9 @@ int cfm_ode_dopri5_mlp_f32(const float* const* W, const float* const* b, const i
                            int n_t, float atol, float rtol, float* traj, int* n_steps,
                            int* nfe, void* ws, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* exact assignment (cfm_assign_exact_f32): epsilon schedule (theta, first / last epsilon as fractions of the cost
  * range, phase cut), round caps, launches per polled chunk.  Arguments <= 0 (stop_frac, arr_cap: < 0) keep the value. */
@@ -33,6 +36,9 @@ void cfm_assign_debug_small(int* out16);                           /* status blo
 void cfm_assign_debug_fallback(int* out2);                         /* {solves of this thread redone by the dense machine, last device error} */
 int cfm_plan_zero_entries_f64(double* pi, const int64_t* flat, int n, void* stream);   /* pi.flat[flat[q]] = 0 (sample_map(replace=False) bookkeeping of the mirror) */
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

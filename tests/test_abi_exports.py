@@ -29,6 +29,19 @@ def test_library_exports_every_declared_symbol(lib_built):
         assert hasattr(lib, name), f"{name} declared in include/cfm_gfx950.h but not exported"
 
 
+def test_library_exports_nothing_undeclared(lib_built):
+    """-fvisibility=hidden (csrc/build.sh) + the visibility pragmas of the two headers: the dynamic symbol table's cfm_*
+    functions are EXACTLY the declared ones (no *_internal helper, no stray setter leaves the library)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_built.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if " T " in ln})
+    src = open(os.path.join(ROOT, "include", "cfm_gfx950_tuning.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    tuning = set(re.findall(r"\b(cfm_[a-z0-9_]+)\s*\(", src))
+    assert exported == sorted(set(_declared()) | tuning), sorted(set(exported) ^ (set(_declared()) | tuning))
+    assert "-fvisibility=hidden" in open(os.path.join(ROOT, "conditional-flow-matching_amd", "csrc", "build.sh")).read()
+
+
 def test_python_binding_covers_header(lib_built):
     assert sorted(lib_built.SIGNATURES) == _declared()
     assert sorted(lib_built.exported_symbols()) == _declared()
@@ -43,8 +56,10 @@ def test_workspace_sizes(lib_built):
     assert lib.cfm_workspace_bytes(99, 4, 4, 4) == 0
     # Sinkhorn scratch is O(B) potentials + strip partials, far below the B^2 matrix
     assert lib.cfm_workspace_bytes(1, 4096, 4096, 0) < 16 * 2**20
-    # cost scratch (matrix-core form): the centre (d floats) and one norm per point
-    assert 4 * (784 + 8192) <= lib.cfm_workspace_bytes(7, 4096, 4096, 784) < 64 * 2**10
+    # cost scratch (matrix-core form): the centre (d floats), one norm per point and the centred clouds in the padded
+    # layout of the direct-to-LDS engine ([(B0 + 1) + (B1 + 1)][d rounded up to 32] floats)
+    need = 4 * (784 + 8192 + (4097 + 4097) * 800)
+    assert need <= lib.cfm_workspace_bytes(7, 4096, 4096, 784) < need + 64 * 2**10
     assert lib.cfm_workspace_bytes(7, 4096, 4096, 0) == 0
     # assignment scratch: O(B) state + 64 candidate (column, cost) pairs per row
     assert lib.cfm_workspace_bytes(2, 4096, 4096, 0) < 4 * 2**20
@@ -70,19 +85,18 @@ def test_tuning_header_lists_every_extra_export(lib_built):
     assert not set(names) & set(_declared())
 
 
-def test_experiment_switches_are_off_in_the_product_build():
-    """Every compile-time experiment of the kernels (prepared, not yet measured) defaults to 0 — the product
-    library is built without any -D flag (csrc/build.sh) — except the two that only select WHICH experimental loop a
-    COST_GLDS_V2 build takes."""
+def test_no_compile_time_experiments_left_in_the_kernels():
+    """Round 5 adopted or deleted every compile-time experiment of the kernels (profiles/r5_experiments.txt): what is
+    left of the preprocessor in csrc/ is the instrumented build of the list solver (SP_PROFILE, tools/probe/build_prof.sh);
+    the product library is built without any -D flag."""
+    import glob
     csrc = os.path.join(ROOT, "conditional-flow-matching_amd", "csrc")
-    want = {"gemm_core.h": {"GC_FAIR": "0", "GC_PIPE": "0", "GC_DBG": "0", "GC_FETCH_MODE": "0"},
-            "cost.hip": {"COST_GLDS_V2": "0"}, "assign.hip": {"ASG_PREFETCH_CTL": "0"}, "gemm_glds.h": {"GL_DBG": "0"}}
-    for fname, macros in want.items():
-        src = open(os.path.join(csrc, fname)).read()
-        for name, val in macros.items():
-            m = re.search(r"#ifndef %s\s*\n#define %s (\S+)" % (name, name), src)
-            assert m and m.group(1) == val, (fname, name, m and m.group(1))
+    conds = []
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        for ln in open(f):
+            if re.match(r"#\s*(if|ifdef|ifndef)\b", ln):
+                conds.append((os.path.basename(f), ln.strip()))
+    assert all(c[1] == "#ifdef SP_PROFILE" for c in conds), conds
+    assert len(conds) <= 8
     build = open(os.path.join(csrc, "build.sh")).read()
     assert "-D" not in build.replace("$CFM_EXTRA_FLAGS", "")
-    r = __import__("subprocess").run(["bash", "-n", os.path.join(ROOT, "tools", "probe", "try_glds_v2.sh")], capture_output=True)
-    assert r.returncode == 0, r.stderr

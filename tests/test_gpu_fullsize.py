@@ -134,3 +134,62 @@ def test_c5_shapes_run():
     traj = node.trajectory(x0, torch.linspace(0, 1, 100))
     assert traj.shape == (100, 8192, 50) and torch.isfinite(traj).all()
     print("C5 dopri5 steps", node.n_steps, "nfe", node.nfe)
+
+
+def test_c2_same_matrix_b4096_all_indices():
+    """Solver-level bit-exactness at the FULL C2 size (VERDICT r4 Next #7a): ONE fp32 matrix — the reference's own
+    torch.cdist(x0, x1) ** 2 on CPU (optimal_transport.py:84) — goes to both cfm_assign_exact_f32 and SciPy's LSAP
+    (the reference's solver at :179; float64 on the same fp32 values): all 4096 indices must agree.  (End to end the
+    d = 2 optimum is decided below fp32 cost rounding — SURVEY 0.5 — which is why the matrix is shared here.)"""
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    x0, x1 = oracle.config_inputs("C2")
+    Mref = oracle.ref_cost_f32(x0, x1)
+    assert Mref.shape == (4096, 4096) and Mref.dtype == np.float32
+    perm, info = ot.assign_exact(torch.from_numpy(Mref).to(dev), return_info=True)
+    p = perm.cpu().numpy()
+    assert info["certified"] and sorted(p.tolist()) == list(range(4096))
+    t0 = time.perf_counter()
+    ref = oracle.exact_perm(Mref)
+    print(f"C2 same-matrix: SciPy LSAP {time.perf_counter() - t0:.1f} s")
+    ndiff = int((p != ref).sum())
+    if ndiff:       # a tie between two optima is the only legitimate difference: say so precisely
+        ar = np.arange(4096); M64 = Mref.astype(np.float64)
+        print("cost gap", float(M64[ar, p].sum() - M64[ar, ref].sum()))
+    assert ndiff == 0, ndiff
+
+
+def test_c5_sample_dense_b8192_vs_oracle():
+    """C5 full size (B = 8192, d = 50, eps = 0.1): the plan SAMPLER at full size (VERDICT r4 Next #7b).
+    (i) oracle.sample_map_given_u on the device solver's own float64 plan == the device draws, all 8192;
+    (ii) against the plan built from the C ORACLE's potentials (oracle/sinkhorn_oracle.c, 50 iterations of POT's
+    loop on the same fp32 matrix): the potentials agree to 1e-5, so a draw can only differ where u falls within
+    that of a cdf step — at most a handful, and then by a neighbouring support entry."""
+    import cfm_amd.optimal_transport as ot
+    import sinkhorn_c
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    x0, x1 = oracle.config_inputs("C5")
+    B = 8192
+    M = ot.cost_matrix(x0.to(dev), x1.to(dev))
+    r = ot.sinkhorn_log(M, 0.1, max_iter=50, stop_thr=0.0)
+    np.random.seed(5)
+    uu = np.random.random_sample(B)
+    i, j = ot.sample_dense(r, torch.from_numpy(uu).to(dev))
+    i, j = i.cpu().numpy(), j.cpu().numpy()
+    P = ot.sinkhorn_plan(r).cpu().numpy()
+    io, jo = oracle.sample_map_given_u(P, uu)
+    assert np.array_equal(i, io) and np.array_equal(j, jo)
+    del P
+    Mh = M.cpu().numpy()
+    uo, vo, _, _ = sinkhorn_c.sinkhorn_log(Mh, 0.1, numItermax=50, stopThr=0.0)
+    Po = np.exp(uo[:, None] + vo[None, :] - Mh.astype(np.float64) / 0.1)
+    ic, jc = oracle.sample_map_given_u(Po, uu)
+    same = (i == ic) & (j == jc)
+    print(f"C5 sampler vs C-oracle plan: {int(same.sum())} of {B} draws identical")
+    assert same.mean() >= 0.995
+    bad = np.where(~same)[0]
+    # a differing draw sits on a cdf boundary: both candidates carry mass in BOTH plans' neighbourhoods
+    for q in bad:
+        assert Po[i[q], j[q]] > 0 and abs(int(i[q]) - int(ic[q])) <= 1

@@ -1,6 +1,6 @@
 """Time + check the fp32-MFMA dense products of the path (gemm_core.h) at the C3 shapes:
   forward layers (mlp_layer), backward (gemm_f32_mfma dgrad / wgrad), cost_gemm, and the whole model step.
-    CFM_GEMM_TILE=0|1|2 python tools/gemm_bench.py      (tile forced; unset = the library's choice)
+    python tools/gemm_bench.py
 Checks every result against float64 torch on the host (max relative error vs sum |a||b|).  Measurement
 infrastructure; not part of the product path."""
 import os, sys, time
@@ -31,7 +31,6 @@ def timeit(fn, reps=20):
 import ctypes
 lib = _lib.load()
 from cfm_amd._lib import ptr, stream_ptr, check
-print("tile:", os.environ.get("CFM_GEMM_TILE", "auto"))
 
 
 def c_args(ws_list):

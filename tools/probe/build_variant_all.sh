@@ -9,7 +9,7 @@ FILES="${*:-cost mlp mlp_train ode}"
 objs=""
 for f in abi cost sinkhorn sinkhorn_pts assign transport sample elem mlp mlp_train ode unbalanced; do
   if [[ " $FILES " == *" $f "* ]]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $FL -c "$C/$f.hip" -o /tmp/${f}_$NAME.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-result $FL -c "$C/$f.hip" -o /tmp/${f}_$NAME.o &
     objs="$objs /tmp/${f}_$NAME.o"
   else
     objs="$objs $C/obj/$f.o"
