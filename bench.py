@@ -666,6 +666,10 @@ def main():
                          "streams may use every CU")
     ap.add_argument("--priority", type=int, default=int(os.environ.get("CFM_BENCH_PRIORITY", "0")),
                     help="HIP priority of the coupling workers' streams when no partition is used (-1: high)")
+    ap.add_argument("--solver-async", default="",
+                    help="A/B switch (not used by the default run): 'on,blocks,last_div' for cfm_assign_set_async — on = 0: the exact "
+                         "solver's epsilon > 0 phases as synchronous rounds; blocks: workgroups per problem of the one-launch "
+                         "asynchronous auction in the batch entry; last_div: its last phase is cut at stop_frac / last_div")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the C1 / C2 / C5 / roofline legs")
     ap.add_argument("--cpu-standin", action="store_true",
@@ -686,6 +690,9 @@ def main():
     import cfm_amd.optimal_transport as ot
 
     lib_ = _lib.load()
+    if args.solver_async:
+        on, blocks, div = (int(x) for x in args.solver_async.split(","))
+        lib_.cfm_assign_set_async(on, blocks, div)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the HIP path: it needs an MI355X (no CPU fallback exists)")
     rank, local, world = D.init_from_env()

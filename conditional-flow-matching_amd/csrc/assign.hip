@@ -102,12 +102,18 @@ struct AsgParams {
     int bulk;              // asg_step launches enqueued before the first poll (n >= bulk_min_n)
     int bulk_min_n;
     int small;             // 1: problems of 2 <= n <= 256 take the one-workgroup solver (assign_small.h)
+    int async_auction;     // 1: the epsilon > 0 phases run in ONE launch without global rounds (asg_auction; 1024 <= n <= 8192)
+    int async_blocks;      // ... on this many workgroups per problem in the batch entry (0: the grid of the other kernels)
+    int async_last_div;    // ... the last phase is cut at stop_frac / this
 };
 
 // Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
 // called from another thread never tear a running solve.
 static std::mutex g_params_mu;
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
+// async_blocks / async_last_div: measured in the C3 pipelined loop, three interleaved passes of nine regions each on one box
+// (profiles/r5_async_sweep.txt): synchronous rounds 1.18 - 1.21 ms per step; asynchronous on 16 workgroups per problem
+// 1.10 - 1.12, with the last phase cut at a quarter of the usual 2 % 1.07 - 1.11; 24 / 32 workgroups 1.09 - 1.13; cut / 8: 1.10 - 1.11.
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 1, 16, 4};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
@@ -130,6 +136,12 @@ extern "C" void cfm_assign_set_handoff(int handoff) {      // at most 64 free ro
     if (handoff >= 0) g_params.handoff = handoff > 64 ? 64 : handoff;
 }
 extern "C" void cfm_assign_set_stop_early(double f) { std::lock_guard<std::mutex> lk(g_params_mu); if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
+extern "C" void cfm_assign_set_async(int on, int blocks, int last_div) {
+    std::lock_guard<std::mutex> lk(g_params_mu);
+    g_params.async_auction = on ? 1 : 0;
+    if (blocks >= 0) g_params.async_blocks = blocks;
+    if (last_div > 0) g_params.async_last_div = last_div;
+}
 extern "C" void cfm_assign_set_small(int on) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.small = on > 0 ? on : 0; }
 extern "C" void cfm_assign_set_bulk(int bulk, int min_n) {
     std::lock_guard<std::mutex> lk(g_params_mu);
@@ -197,7 +209,14 @@ struct AucCtl {
     int auction_rounds, arr_rounds, row_scans;
     int pad[2];
 };
-struct AsgAuc { AucCtl ctl[2]; alignas(128) int bidcnt[4]; };
+struct AsgAuc {
+    AucCtl ctl[2];
+    alignas(128) int bidcnt[4];
+    // asynchronous phase A (asg_auction): the phase word every workgroup polls (low 16 bits: index of the current epsilon
+    // phase, bit 31: the phases are over), the hand-over flag, and the bid totals the workgroups add when they leave
+    alignas(128) int async_word;
+    int async_done, async_scans, async_list;
+};
 static_assert(sizeof(AsgAuc) <= 512, "AsgAuc has 512 bytes of the workspace");
 
 // SAP scan list entry arrays (two copies: current / next)
@@ -226,7 +245,7 @@ struct AsgWs {
     int* listFC;      // free columns
     int* pred;
     int* tcol;        // per tree: accepted free column of the phase (or MS_NONE)
-    int* grp_ticket;  // [n/64] arrival counters of a split relax round (one per column group)
+    int* grp_ticket;  // [n] asg_auction: per workgroup, (phase + 1) << 16 | unmatched rows at its last look
     double* part_d;   // [MS_YMAX][n] partial minima of a split relax round
     int* part_i;      // [MS_YMAX][n] their rows
     int* part_r;      // [MS_YMAX][n] their trees
@@ -658,7 +677,8 @@ __device__ __forceinline__ int wide_bid_queue(gfp M, const AsgWs& w, const doubl
                                               int my_bc, bool stage_p, int n, double eps, int tag, int rb, int rnd) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool lists = ASG_BL_ON && (w.cl != nullptr);
-    const int i_chk = blockIdx.x + gridDim.x * threadIdx.x;             // row t of this workgroup
+    int tq = threadIdx.x; asm volatile("" : "+v"(tq));                  // (opaque: formed per call, never carried — and spilled — across the persistent loop of asg_auction)
+    const int i_chk = blockIdx.x + gridDim.x * tq;                      // row t of this workgroup
     if (i_chk < n && threadIdx.x < ASG_BQ && !bid_matched(w, r_lds, stage_p, my_bc, tag, i_chk, rb))
         bq[atomicAdd(bq_cnt, 1)] = i_chk;
     __syncthreads();
@@ -681,7 +701,7 @@ __device__ __forceinline__ int wide_bid_queue(gfp M, const AsgWs& w, const doubl
 __device__ __forceinline__ void wide_umin0(gfp M, const AsgWs& w, AsgState* st,
                                            int wave_gid, int n_waves, int n, float* sh) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int j = blockIdx.x * WT + threadIdx.x; j < n; j += gridDim.x * WT) { w.key[j] = 0ull; w.bidcol[j] = -1; }
+    for (int j = blockIdx.x * WT + threadIdx.x; j < n; j += gridDim.x * WT) { w.key[j] = 0ull; w.bidcol[j] = -1; w.grp_ticket[j] = 0; }
     float lo = INFINITY, hi = -INFINITY;
     const bool vec = ((n & 3) == 0);
     for (int i = wave_gid; i < n; i += n_waves) {
@@ -1311,6 +1331,7 @@ __device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode
         C.r = 0; C.auction_rounds = 0; C.arr_rounds = 0; C.row_scans = 0; C.pad[0] = C.pad[1] = 0;
         w.auc->ctl[par ^ 1] = C;
         for (int q = 0; q < 4; ++q) asg_st(&w.auc->bidcnt[q], 0);
+        asg_st(&w.auc->async_word, 0); w.auc->async_done = 0; w.auc->async_scans = 0; w.auc->async_list = 0;
         st->mode = MODE_AUCTION;
     } else if (mode == MODE_CONVERT || mode == MODE_MS_FINISH) {
         st->mode = asg_ld(&st->next_mode);
@@ -1420,7 +1441,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
                 // the rounds are over: their results go back into the state block, this launch is the CONVERT step
                 st->tag = C.tag; st->eps = C.eps; st->phase = C.phase; st->round = C.round; st->arr_round = C.arr_round;
                 st->st_auction_rounds = C.auction_rounds; st->st_arr_rounds = C.arr_rounds;
-                st->st_total_row_scans += C.row_scans; st->st_list_bids = C.pad[0];
+                st->st_total_row_scans += C.row_scans + w.auc->async_scans; st->st_list_bids = C.pad[0] + w.auc->async_list;
             } else {
                 AucCtl N2 = C; N2.r = C.r + 1;
                 w.auc->ctl[(par & 1) ^ 1] = N2;
@@ -1492,6 +1513,146 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
     }
     const bool wait = (mode == MODE_SAP || mode == MODE_UMIN0 || mode == MODE_CERT || mode == MODE_CONVERT || mode == MODE_MS_FINISH);
     if (asg_arrive_last(st, w.arrive_sub, &sh[30], payload, wait)) step_ctrl(w, st, mode, n, sh[31], par & 1);
+}
+
+// ------------------------------------------------------- asynchronous phase A ------
+// The epsilon > 0 phases WITHOUT a global round.  One launch: every workgroup loops on its own rows at its own pace —
+//   refresh: all keys, read past the L1 (device-scope loads), become the workgroup's price / owner snapshot in LDS;
+//   bid:     its unmatched rows bid on that snapshot exactly as in a synchronous round (wide_bid_queue / wide_bid: bid
+//            lists, row scans, one atomicMax per bid);
+//   report:  the number of rows it found unmatched goes to its slot of cnt[] (tagged with the phase);
+// and workgroup 0 adds up the slots after each of its own iterations and moves the phase word on (cut at <= 2 % unmatched
+// like the synchronous rounds).  No kernel boundary and no grid barrier between "rounds": a workgroup's iteration is two
+// dependent round trips (refresh, row or list) + an atomic, 2.5 - 3.5 us against 8.6 us for a round as a launch — and
+// nobody waits for the slowest workgroup of the chip.
+// Why this is allowed: (i) an auction with OUTDATED prices is still an auction — prices only rise (atomicMax), a bid
+// computed from older (lower) prices p' <= p leaves c_ij + b = w' + eps <= min_k (c_ik + p_k) + eps if it is accepted
+// (Bertsekas' asynchronous auction), and a bid below the object's current price is simply not accepted: the row finds
+// itself unmatched at its next look; (ii) the bid lists stay valid for the same reason they do across rounds (their
+// bound only needs prices that never fall); (iii) NOTHING downstream trusts phase A: the epsilon = 0 rounds start
+// from the prices alone ("every row is unassigned again, the prices stay"), and phases B - D are exact on any prices.
+// The only products of this kernel are the keys (prices), the bid lists and a few counters.
+// Residency: a workgroup never waits for another one to START (a late workgroup's slot reads "all rows unmatched"),
+// so a grid larger than what the chip can hold at the moment only delays the end of a phase.  Every loop is capped.
+#define ASG_ASYNC_ITER_CAP 60000
+// wave-uniform values that came out of vector loads: into scalar registers (the loop carries a dozen of them)
+__device__ __forceinline__ double asg_uni_d(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int asg_uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t stride) {
+    extern __shared__ __attribute__((aligned(16))) char auc_lds[];
+    const AsgWs w = asg_shift(w0, stride * blockIdx.y);
+    __shared__ int sh[12];
+    __shared__ int bq[ASG_BQ];
+    AsgState* st = w.st;
+    const int n = n_host;
+    const AsgHead H = *reinterpret_cast<const AsgHead*>(st);
+    if (H.mode != MODE_AUCTION || H.error || w.auc->async_done) return;
+    gfp M = ASG_GLOBAL(H.Mptr);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int G = (int)gridDim.x;
+    const int rb = asg_uni_i(H.rb), mb = rb + ASG_RND_BITS;
+    const double theta = asg_uni_d(H.theta), eps_last = asg_uni_d(H.eps_last);
+    const double stop_frac = H.stop_frac, stop_early = st->stop_early;
+    const int round_cap = asg_uni_i(H.round_cap);
+    int* cnt = w.grp_ticket;
+    double* p_lds = reinterpret_cast<double*>(auc_lds);
+    int* r_lds = reinterpret_cast<int*>(auc_lds + (size_t)((n + 1) & ~1) * sizeof(double));
+    constexpr int KP = WIDE_PLDS_MAX / (2 * WT);
+    // local view of the schedule: phase index, its epsilon (the controller divides the same way) and tag
+    int phase = 0; double eps = asg_uni_d(H.eps);
+    int scans_tot = 0, lists_tot = 0;
+    // controller state (workgroup 0, thread 0)
+    int c_rounds = 0, c_total_rounds = 0;
+    const int last_div = asg_uni_i(st->pad0) > 0 ? asg_uni_i(st->pad0) : 1;
+    const int stop_mid = asg_uni_i((int)(fmax(stop_frac, stop_early) * n)), stop_last = asg_uni_i((int)(stop_frac / last_div * n));
+    bool c_last = (eps / theta) < eps_last;
+    int c_stop = c_last ? stop_last : stop_mid;
+    bool idle = false;
+    for (int it = 0; it < ASG_ASYNC_ITER_CAP; ++it) {
+        if (idle) __builtin_amdgcn_s_sleep(20);                      // nothing to bid for at the last look: poll a little slower
+        // ---- refresh (past the L1: the keys are raised by other CUs' atomics, the phase word by workgroup 0) ----
+        const int word0 = asg_ld(&w.auc->async_word);
+        unsigned long long kk[2 * KP];
+#pragma unroll
+        for (int q = 0; q < KP; ++q) {
+            const int j = threadIdx.x * 2 + 2 * WT * q;
+            const int jj = j < n ? j : 0;
+            kk[2 * q] = asg_ld(&w.key[jj]); kk[2 * q + 1] = asg_ld(&w.key[jj + 1 < n ? jj + 1 : jj]);
+        }
+        // (always the queue form of the round: thread t looks at row t of this workgroup — rows b, b + G, ... —, the
+        //  unmatched ones go to the LDS queue and the waves take them from there)
+        int my_bc = -1;
+        if (threadIdx.x < ASG_BQ && (int)(blockIdx.x + G * threadIdx.x) < n) my_bc = asg_ld(&w.bidcol[blockIdx.x + G * threadIdx.x]);
+        // (the waves of a workgroup may have read different words: thread 0's copy decides for all of them, behind the
+        //  barrier; the counters of this iteration live in the slots of its parity — a slow wave may still be reading
+        //  the previous iteration's)
+        int* shc = sh + 4 * (it & 1);
+        if (threadIdx.x == 0) { shc[0] = 0; shc[1] = 0; sh[2] = word0; }
+#pragma unroll
+        for (int q = 0; q < KP; ++q) {
+            const int j = threadIdx.x * 2 + 2 * WT * q;
+            if (j < n) { *reinterpret_cast<double2*>(p_lds + j) = make_double2(asg_price(kk[2 * q], mb), asg_price(kk[2 * q + 1], mb));
+                         *reinterpret_cast<int2*>(r_lds + j) = make_int2(asg_key_row(kk[2 * q], rb), asg_key_row(kk[2 * q + 1], rb)); }
+        }
+        __syncthreads();
+        const int word = asg_uni_i(sh[2]);
+        if (word < 0) break;                                         // (uniform) the phases are over
+        const int wphase = word & 0xffff;
+        while (phase < wphase) { eps = eps / theta; ++phase; }       // a new phase: every row is unassigned again (new tag)
+        const int tag = (phase % 254) + 1;
+        // ---- bid: the synchronous round's body on this snapshot ----
+        const int nb = wide_bid_queue(M, w, p_lds, r_lds, bq, &shc[1], my_bc, true, n, eps, tag, rb, 0);
+        if (lane == 0 && nb) atomicAdd(&shc[0], nb);
+        __syncthreads();
+        const int mine = asg_uni_i(shc[0]);                               // bids of this iteration = rows found unmatched (+ list-served ones above bit 16)
+        idle = ((mine & 0xffff) == 0);
+        scans_tot += mine & 0xffff; lists_tot += mine >> 16;
+        // ---- report; workgroup 0 decides ----
+        if (threadIdx.x == 0) asg_st(&cnt[blockIdx.x], ((phase + 1) << 16) | (mine & 0xffff));
+        if (blockIdx.x == 0 && wv == 0) {
+            // (the controller's own slot may not have landed yet: it uses `mine` for itself)
+            int tot = 0;
+            for (int g = lane; g < G; g += 64) {
+                const int c = (g == 0) ? (((phase + 1) << 16) | (mine & 0xffff)) : asg_ld(&cnt[g]);
+                const int rg = (n - g + G - 1) / G;
+                tot += ((c >> 16) == phase + 1) ? (c & 0xffff) : rg;  // a slot of another phase (or never written): all of its rows
+            }
+            tot = wave_sum_i(tot);
+            if (lane == 0) {
+                ++c_rounds; ++c_total_rounds;
+                int nw = 0;                                          // 0: go on; > 0: new word
+                if (tot <= c_stop || c_rounds >= round_cap || it + 8 >= ASG_ASYNC_ITER_CAP) {
+                    const double e2 = eps / theta;
+                    if (e2 < eps_last || it + 8 >= ASG_ASYNC_ITER_CAP) nw = (int)0x80000000u | (phase + 1);
+                    else {
+                        nw = phase + 1; c_rounds = 0;
+                        c_last = (e2 / theta) < eps_last;
+                        c_stop = c_last ? stop_last : stop_mid;
+                    }
+                }
+                if (nw) asg_st(&w.auc->async_word, nw);
+            }
+        }
+    }
+    // ---- leave: the bid totals; workgroup 0 hands the state machine over to the epsilon = 0 rounds ----
+    if (threadIdx.x == 0) {
+        if (scans_tot) atomicAdd(&w.auc->async_scans, scans_tot);
+        if (lists_tot) atomicAdd(&w.auc->async_list, lists_tot);
+        if (blockIdx.x == 0) {
+            const int word = asg_ld(&w.auc->async_word);
+            if (word >= 0) asg_st(&w.auc->async_word, (int)0x80000000u | (word & 0xffff));   // (left by the cap)
+            const int nph = (word & 0xffff);
+            AucCtl C;
+            C.eps = 0.0; C.mode = MODE_ARR; C.tag = (nph % 254) + 1; C.round = 0; C.phase = nph; C.stop = 0; C.arr_round = 0;
+            C.r = 0; C.auction_rounds = c_total_rounds; C.arr_rounds = 0; C.row_scans = 0; C.pad[0] = C.pad[1] = 0;
+            w.auc->ctl[0] = C; w.auc->ctl[1] = C;                    // whichever parity the next asg_step launch has
+            for (int q = 0; q < 4; ++q) asg_st(&w.auc->bidcnt[q], 0);
+            w.auc->async_done = 1;
+            asg_book(st, MODE_AUCTION);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- build ------
@@ -1583,6 +1744,7 @@ static int asg_raise_lds() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     std::call_once(once[dev], [dev] {
         hipError_t e1 = hipFuncSetAttribute((const void*)asg_step, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void*)asg_auction, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
         hipError_t e2 = hipFuncSetAttribute((const void*)asg_build, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
         hipError_t e3 = hipFuncSetAttribute((const void*)asg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ok[dev] = (e1 == hipSuccess ? 1 : 0) | (e2 == hipSuccess && e3 == hipSuccess ? 2 : 0);
@@ -1601,13 +1763,20 @@ extern "C" void cfm_assign_debug_small(int* out16) { for (int q = 0; q < 16; ++q
 
 struct AsgLaunch {
     AsgWs w; int n, blocks, blocks_build, nb; size_t stride; size_t lds_step, lds_build, lds_solve; int sparse; hipStream_t s;
+    int async_auction = 0, blocks_auction = 0;
     // every program holds an EVEN number of asg_step launches and starts on an even launch count, so the parity
     // argument (which control record a bid round reads, see AucCtl) is the position inside the program.
     // grid.y = the problems of a batch (one carving each, `stride` bytes apart)
     void step(int par) const { hipLaunchKernelGGL(asg_step, dim3(blocks, nb), dim3(WT), lds_step, s, w, n, par & 1, stride); }
     void program(int prg, int chunk, int bulk) const {
         int k = 0;
-        if (prg == PRG_BULK) { for (int c = 0; c < bulk; ++c) step(k++); return; }
+        // asynchronous phase A: ONE launch behind the two init steps (a no-op in any other state, like every kernel here)
+        auto auction = [&]() { if (async_auction) hipLaunchKernelGGL(asg_auction, dim3(blocks_auction, nb), dim3(WT), lds_step, s, w, n, stride); };
+        if (prg == PRG_BULK) {
+            for (int c = 0; c < bulk; ++c) { if (c == 2) auction(); step(k++); }
+            return;
+        }
+        auction();
         for (int c = 0; c < chunk; ++c) step(k++);
         if (sparse) {
             hipLaunchKernelGGL(asg_build, dim3(blocks_build, nb), dim3(SP_BUILD_WAVES * 64), lds_build, s, w, n, stride);
@@ -1615,7 +1784,7 @@ struct AsgLaunch {
             step(k++); step(k++);      // certificate + whatever the guess missed
         }
     }
-    int count(int prg, int chunk, int bulk) const { return prg == PRG_BULK ? bulk : chunk + (sparse ? 4 : 0); }
+    int count(int prg, int chunk, int bulk) const { return (prg == PRG_BULK ? bulk : chunk + (sparse ? 4 : 0)) + ((async_auction && (prg != PRG_BULK || bulk > 2)) ? 1 : 0); }
 };
 
 // the first 64 bytes of every problem's state block, gathered for ONE copy to the host
@@ -1691,7 +1860,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
         h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
         h.fr_min = ~0ull; h.fr_max = 0ull;
         h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early;
-        h.tag = 1;
+        h.tag = 1; h.pad0 = P.async_last_div;
         { int rb = 1; while ((1 << rb) <= n) ++rb; h.rb = rb; }     // row ids 0 .. n-1 and the all-ones "none"
         hipLaunchKernelGGL(asg_init, dim3(1), dim3(64), 0, s, asg_carve((char*)ws + (size_t)b * L.stride, n), h);
     }
@@ -1704,11 +1873,26 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     // build vary by ~+-6 between problems: 24 instead of 10 steps in front of the pair (a no-op step costs 3-5 us).
 #define ASG_BATCH_CHUNK 24
     if (nb > 1 && chunk < ASG_BATCH_CHUNK) chunk = ASG_BATCH_CHUNK;
-    const int bulk = ((n >= P.bulk_min_n) ? P.bulk : 0) & ~1;
+    // asynchronous phase A: the keys must fit the LDS snapshot and the grid must give every workgroup at most ASG_BQ rows
+    L.blocks_auction = wide_blocks;
+    if (nb > 1 && P.async_blocks > 0 && P.async_blocks < wide_blocks) L.blocks_auction = P.async_blocks;
+    if ((long)L.blocks_auction * ASG_BQ < n) L.blocks_auction = (n + ASG_BQ - 1) / ASG_BQ;      // (a workgroup takes at most ASG_BQ rows)
+    {   // its workgroups (16 waves, the whole register file of a CU each) must be able to be resident TOGETHER: a phase ends
+        // when the whole grid has reported, and a workgroup that has not started counts as "all rows unmatched"
+        static int cus[CFM_MAX_DEVICES];
+        int& c = cus[cfm_device_index()];
+        if (c <= 0 && (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, cfm_device_index()) != hipSuccess || c <= 0)) c = 256;
+        if ((long)L.blocks_auction * nb > c) L.blocks_auction = c / nb > 0 ? c / nb : 1;
+    }
+    L.async_auction = (P.async_auction && n >= 1024 && n <= WIDE_PLDS_MAX && (raised & 1) && (long)L.blocks_auction * ASG_BQ >= n) ? 1 : 0;
+    // ... the unpolled head then is: 2 init steps, the auction launch, ~10 epsilon = 0 rounds + convert / row minima / column
+    // reduction (the synchronous rounds needed ~96 launches here)
+    int bulk = ((n >= P.bulk_min_n) ? P.bulk : 0) & ~1;
+    if (L.async_auction && bulk > 16) bulk = 16;
     AsgGraph& G = asg_graph_slot(ws, n, nb, s);
     bool use_graph = asg_graph_enabled() && !g_graph_off && n >= 256;
     if (use_graph && !(G.exec[0] && G.ws == ws && G.n == n && G.nb == nb && G.chunk == chunk && G.bulk == bulk &&
-                       G.blocks == wide_blocks && G.sparse == L.sparse && G.stream == s)) {
+                       G.blocks == wide_blocks + 1024 * L.blocks_auction && G.sparse == L.sparse + 2 * L.async_auction && G.stream == s)) {
         for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
         hipError_t e = hipSuccess;
         for (int prg = 0; prg < PRG_COUNT && e == hipSuccess; ++prg) {
@@ -1728,8 +1912,8 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
             for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
             g_graph_off = 1; use_graph = false;     // e.g. the legacy default stream
         } else {
-            G.ws = ws; G.n = n; G.nb = nb; G.chunk = chunk; G.bulk = bulk; G.blocks = wide_blocks;
-            G.sparse = L.sparse; G.stream = s;
+            G.ws = ws; G.n = n; G.nb = nb; G.chunk = chunk; G.bulk = bulk; G.blocks = wide_blocks + 1024 * L.blocks_auction;
+            G.sparse = L.sparse + 2 * L.async_auction; G.stream = s;
         }
     }
     if (!use_graph) for (int q = 0; q < 2; ++q)

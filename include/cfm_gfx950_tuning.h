@@ -26,6 +26,7 @@ void cfm_assign_set_handoff(int handoff);        /* free rows at which phase C m
 void cfm_assign_set_stop_early(double f);        /* phase cut of every epsilon phase but the last */
 void cfm_assign_set_wide_blocks(int cap);        /* upper bound on the grid of the chip-wide step kernel (0: none) */
 void cfm_assign_set_bulk(int bulk, int min_n);   /* launches enqueued before the first poll, for n >= min_n */
+void cfm_assign_set_async(int on, int blocks, int last_div);   /* on = 0: the epsilon > 0 phases as synchronous rounds (one launch each) instead of the one-launch asynchronous auction; blocks >= 0: its workgroups per problem in the batch entry (0: as the other kernels); last_div > 0: its last phase is cut at stop_frac / last_div */
 void cfm_assign_set_small(int on);               /* 0: problems of n <= 256 take the chip-wide machine too */
 void cfm_ode_set_fused(int on);                  /* 0: layer-per-kernel ODE stages instead of the fused small-field drivers */
 

@@ -132,3 +132,46 @@ def test_sizes_beyond_the_lds_price_snapshot(B, check_scipy):
     if check_scipy:
         ref = oracle.exact_perm(Mh)
         assert oracle.assignment_cost(Mh, p) == pytest.approx(oracle.assignment_cost(Mh, ref), rel=1e-12)
+
+
+@pytest.mark.parametrize("n,kind", [(1024, "geo"), (1500, "geo"), (2048, "uniform"), (4096, "ties"), (4096, "geo784"), (8192, "geo")])
+def test_async_auction_gives_the_synchronous_rounds_permutation(n, kind):
+    """The one-launch asynchronous phase A (asg_auction, default for 1024 <= n <= 8192) against the synchronous bid
+    rounds (cfm_assign_set_async(0, ...)): nothing downstream trusts phase A, so both must end in the SAME certified
+    optimum — identical permutations on generic costs, identical optimal cost on heavily tied ones — for single solves
+    and for the batch entry (which runs the auction on its own, smaller grid)."""
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + len(kind))
+    if kind == "uniform":
+        Ms = [torch.rand(n, n, generator=g).to(dev) for _ in range(3)]
+    elif kind == "ties":
+        Ms = [torch.randint(0, 8, (n, n), generator=g).float().to(dev) for _ in range(3)]
+    else:
+        d = 784 if kind == "geo784" else 3
+        Ms = []
+        for _ in range(3):
+            a = torch.randn(n, d, generator=g).to(dev); b = (torch.randn(n, d, generator=g) * 0.7 + 0.3).to(dev)
+            Ms.append(ot.cost_matrix(a, b))
+    try:
+        res = {}
+        for on in (0, 1):
+            lib.cfm_assign_set_async(on, -1, -1)
+            singles = [ot.assign_exact(M, return_info=True) for M in Ms]
+            batch = ot.assign_exact_batch(Ms)
+            for (p, info), pb in zip(singles, batch):
+                assert info["certified"] and sorted(p.cpu().tolist()) == list(range(n))
+                if kind != "ties":
+                    assert torch.equal(p, pb)
+            res[on] = singles
+        for (p0, i0), (p1, i1), M in zip(res[0], res[1], Ms):
+            if kind == "ties":
+                assert i0["total_cost"] == i1["total_cost"]
+            else:
+                assert torch.equal(p0, p1)
+        # the asynchronous path really ran: ~20 launches per solve instead of ~100
+        assert res[1][0][1]["stats"][6] < res[0][0][1]["stats"][6]
+    finally:
+        lib.cfm_assign_set_async(1, -1, -1)

@@ -45,7 +45,7 @@ def test_glds_cost_matrix_vs_f64_oracle(B0, B1, d):
 
 
 def test_glds_cost_matrix_is_deterministic_and_workspace_is_private():
-    """Two calls give the same bits; an unaligned view of the clouds (row pitch != d would be a copy in the mirror) too."""
+    """Two calls give the same bits; so does a cloud whose base pointer is not 16-byte aligned (the padded copies take any alignment)."""
     import cfm_amd.optimal_transport as ot
     from cfm_amd import _lib
     dev = _lib.require_gpu()
@@ -54,6 +54,8 @@ def test_glds_cost_matrix_is_deterministic_and_workspace_is_private():
     M1 = ot.cost_matrix(a, b).clone()
     M2 = ot.cost_matrix(a, b)
     assert torch.equal(M1, M2)
-    big = torch.randn(701, 131, generator=g).to(dev)
-    big[:700, :130] = a
-    assert torch.equal(ot.cost_matrix(big[:700, :130], b), M1)
+    flat = torch.zeros(700 * 130 + 1, device=dev)             # a base pointer off the 16-byte grid (4-byte aligned only)
+    a2 = flat[1:].view(700, 130)
+    a2.copy_(a)
+    assert a2.data_ptr() % 16 != 0 and a2.is_contiguous()
+    assert torch.equal(ot.cost_matrix(a2, b), M1)

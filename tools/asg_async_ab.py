@@ -1,0 +1,52 @@
+"""A/B of the asynchronous phase A (asg_auction) against the synchronous bid rounds at C3 size: per solve / per batch
+time, launches, row evaluations, time booked per mode, and that the permutations are identical.
+    python tools/asg_async_ab.py [nb ...]
+Measurement infrastructure."""
+import ctypes, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import torch
+import cfm_amd.optimal_transport as ot
+import cfm_oracle as oracle
+from cfm_amd import _lib
+
+lib = _lib.load(); dev = torch.device("cuda", 0)
+sizes = [int(a) for a in sys.argv[1:]] or [1, 4]
+Ms = []
+for k in range(8):
+    x0, x1 = oracle.config_inputs("C3", rank=k)
+    Ms.append(ot.cost_matrix(x0.to(dev), x1.to(dev)))
+B = Ms[0].shape[0]
+MODES = ["umin0", "initred", "auction", "arr", "convert", "umin", "colred", "rootmin", "sap", "ms_finish", "cert", "build", "solver"]
+perms = {}
+with torch.cuda.stream(torch.cuda.Stream()):
+    ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)      # (the cached workspace of THIS stream: the one assign_exact uses)
+    for asy in [tuple(int(y) for y in x.split(',')) for x in os.environ.get('ASYNC_LIST', '0,0,1;1,0,1;0,0,1;1,0,1').split(';')]:
+        lib.cfm_assign_set_async(*asy)
+        for M in Ms[:2]:
+            ot.assign_exact(M)
+        ts, acc, st = [], np.zeros(16), []
+        for q, M in enumerate(Ms):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            perm, info = ot.assign_exact(M, return_info=True); torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+            buf = (ctypes.c_double * 32)(); lib.cfm_assign_debug_times(_lib.ptr(ws), buf)
+            acc += np.array(list(buf))[:16]; st.append(info["stats"])
+            perms.setdefault(q, perm.cpu()); assert torch.equal(perms[q], perm.cpu()), (asy, q)
+        st = np.array(st, dtype=float).mean(0)
+        print(f"async={asy}  lone solve: median {1e3 * np.median(ts):.3f} ms  (min {1e3 * min(ts):.3f})  launches {st[6]:.1f}  row evaluations {st[5]:.0f}  "
+              f"auction rounds {st[0]:.1f}  eps=0 rounds {st[1]:.1f}  free rows after {st[2]:.1f}")
+        print("      us per mode: " + "  ".join(f"{m} {acc[i] / len(Ms):.0f}" for i, m in enumerate(MODES) if acc[i] > 0))
+        for nb in sizes:
+            if nb < 2:
+                continue
+            out = ot.assign_exact_batch(Ms[:nb]); torch.cuda.synchronize()
+            for q in range(nb):
+                assert torch.equal(out[q].cpu(), perms[q]), ("batch", asy, q)
+            tb = []
+            for _ in range(8):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                ot.assign_exact_batch(Ms[:nb]); torch.cuda.synchronize(); tb.append(time.perf_counter() - t0)
+            print(f"      batch of {nb}: median {1e3 * np.median(tb):.3f} ms = {1e3 * np.median(tb) / nb:.3f} ms per problem")
+print("permutations identical in every configuration")
