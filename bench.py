@@ -504,25 +504,31 @@ def parity_leg(dev, ot, budget_s=60.0):
     return out
 
 
-def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
-    """Dominant kernel of the step: asg_step (every chip-wide step of the exact-assignment state machine).
-    Un-overlapped solves on one stream.  Algorithmic bytes per SURVEY §8d: 4 B per row scan (the fp32 cost
-    row) + 8 B prices per sweep (= per launch).  Launch durations: the device books the time of every
-    step on its own 100 MHz clock (cfm_assign_debug_times); HIP events bracket each solve on its stream."""
+def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8, nbatch=4):
+    """Dominant kernel family of the coupling: the chip-wide kernels of the exact-assignment state machine — asg_auction
+    (the epsilon > 0 phases, one launch) and asg_step (every other chip-wide step).  Un-overlapped solves on one stream.
+    Algorithmic bytes per SURVEY §8d: 4 B x n per row evaluation (the fp32 cost row) + 8 B x n prices per launch.
+    Launch durations: the device books the time of every step on its own 100 MHz clock (cfm_assign_debug_times); HIP
+    events bracket each solve on its stream.  `batch`: the same figure for the form the headline schedule runs —
+    cfm_assign_exact_batch_f32 with `nbatch` problems in one chain of launches (the auction on 16 workgroups per
+    problem): nbatch x the algorithmic bytes / the booked time of the chain's chip-wide launches."""
     Ms = [ot.cost_matrix(x0, x1) for (x0, x1) in pool[:nsolves]]
     ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
     for M in Ms[:2]:
         ot.assign_exact(M)
-    ev_ms, step_us, steps, scans, solver_us, listed = [], [], [], [], [], []
+
+    def booked(wsbuf):
+        buf = (ctypes.c_double * 32)()
+        _lib.check(lib.cfm_assign_debug_times(_lib.ptr(wsbuf), buf), "cfm_assign_debug_times")
+        return np.array(list(buf))
+    ev_ms, step_us, steps, scans, solver_us, listed, auction_us = [], [], [], [], [], [], []
     for M in Ms:
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); perm, info = ot.assign_exact(M, return_info=True); e1.record(); torch.cuda.synchronize()
-        buf = (ctypes.c_double * 32)()
-        _lib.check(lib.cfm_assign_debug_times(_lib.ptr(ws), buf), "cfm_assign_debug_times")
-        t = np.array(list(buf))
+        t = booked(ws)
         ev_ms.append(e0.elapsed_time(e1)); step_us.append(float(t[:11].sum())); solver_us.append(float(t[11:13].sum()))
-        steps.append(info["stats"][6]); scans.append(info["stats"][5]); listed.append(float(t[16]))
+        steps.append(info["stats"][6]); scans.append(info["stats"][5]); listed.append(float(t[16])); auction_us.append(float(t[2]))
     steps_m, scans_m, listed_m = float(np.mean(steps)), float(np.mean(scans)), float(np.mean(listed))
     bytes_solve = scans_m * 4.0 * B + steps_m * 8.0 * B
     t_step = float(np.mean(step_us)) * 1e-6
@@ -531,23 +537,49 @@ def assign_roofline(dev, pool, lib, _lib, ot, B, nsolves=8):
     pmc = newest_profile("asg_pmc_summary.json")
     if pmc and os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("asg_step_hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get("asg_chip_wide_hbm_bytes_per_solve")      # (rounds 1-4 committed a per-launch figure: None then)
         except Exception:  # noqa: BLE001
             traffic = None
+    # the batch form (what the pipelined schedule runs)
+    batch = None
+    try:
+        nbq = min(nbatch, len(Ms))
+        wsb = _lib.workspace(_lib.OP_ASSIGN, B, B, nbq, dev)
+        ot.assign_exact_batch(Ms[:nbq]); torch.cuda.synchronize()
+        b_ms, b_step_us, b_scans, b_steps = [], [], [], []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); _, infos = ot.assign_exact_batch(Ms[:nbq], return_info=True); e1.record(); torch.cuda.synchronize()
+            tb = booked(wsb)                                   # (problem 0's books: the chain's launches carry all problems)
+            b_ms.append(e0.elapsed_time(e1)); b_step_us.append(float(tb[:11].sum()))
+            b_scans.append(sum(i["stats"][5] for i in infos)); b_steps.append(infos[0]["stats"][6])
+        b_bytes = float(np.mean(b_scans)) * 4.0 * B + float(np.mean(b_steps)) * 8.0 * B * nbq
+        b_gbs = b_bytes / (float(np.median(b_step_us)) * 1e-6) / 1e9
+        batch = {"problems": nbq, "achieved": b_gbs, "frac": b_gbs / HBM_PEAK_GBS, "unit": "GB/s",
+                 "chip_wide_launch_ms": float(np.median(b_step_us)) * 1e-3, "batch_ms": float(np.median(b_ms)),
+                 "ms_per_problem": float(np.median(b_ms)) / nbq, "row_evaluations": float(np.mean(b_scans)),
+                 "note": "cfm_assign_exact_batch_f32: the form the headline schedule runs; achieved = algorithmic bytes of all "
+                         "problems / booked time of the chain's chip-wide launches (asg_auction on 16 workgroups per problem + "
+                         "asg_step); the one-workgroup list solvers run beside the next launches and are not in this time"}
+    except Exception as exc:  # noqa: BLE001 — a side figure must not take the line down
+        batch = {"error": repr(exc)[:200]}
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "asg_step (cfm_assign_exact_f32)",
+            "traffic": traffic, "kernel": "asg_auction + asg_step (cfm_assign_exact_f32)",
             "launches_per_solve": steps_m, "avg_launch_us": float(np.mean(step_us)) / steps_m,
-            "algorithmic_bytes_per_launch": bytes_solve / steps_m, "row_scans_per_solve": scans_m,
+            "auction_launch_us": float(np.mean(auction_us)),
+            "algorithmic_bytes_per_solve": bytes_solve, "algorithmic_bytes_per_launch": bytes_solve / steps_m, "row_scans_per_solve": scans_m,
             "row_scans_served_from_bid_lists": listed_m,
-            "bytes_read_per_launch_by_construction": ((scans_m - listed_m) * 4.0 * B + listed_m * 1024.0 + steps_m * 8.0 * B) / steps_m,
+            "bytes_read_per_solve_by_construction": (scans_m - listed_m) * 4.0 * B + listed_m * 1024.0 + steps_m * 8.0 * B,
             "solve_ms": float(np.mean(ev_ms)), "list_solver_ms": float(np.mean(solver_us)) * 1e-3,
-            "note": "latency-bound chain of ~200 dependent launches per solve (each >= 1.6 us of launch boundary): "
-                    "the figure of merit is solve_ms; achieved = (4B per row scan + 8B prices per launch) / summed "
-                    "asg_step time of an un-overlapped solve (SURVEY 8d's algorithmic figure: a row scan = one row "
-                    "evaluation of the auction / the forest; row_scans_served_from_bid_lists of them read the row's "
-                    "64-entry bid list (512 B + 64 prices) instead of the 4 B x n row, so the bytes actually requested "
-                    "are bytes_read_per_launch_by_construction); traffic (if present) = HBM bytes per launch from the "
-                    "committed rocprofv3 --pmc passes (profiles/), FETCH x2 + WRITE"}
+            "chip_wide_ms": t_step * 1e3, "batch": batch,
+            "note": "latency-bound: the figure of merit is solve_ms; achieved = (4B x n per row evaluation + 8B x n prices "
+                    "per launch) / booked time of the chip-wide launches of an un-overlapped solve (SURVEY 8d's algorithmic "
+                    "figure: a row evaluation = one bid of the auction / one row of the forest; "
+                    "row_scans_served_from_bid_lists of them read the row's 64-entry bid list (512 B + 64 prices) instead of "
+                    "the 4 B x n row, so the bytes actually requested are bytes_read_per_solve_by_construction); since round 5 "
+                    "the epsilon > 0 phases are ONE launch (asg_auction, auction_launch_us) instead of ~90, so the unit of "
+                    "achieved / traffic is the SOLVE (its chip-wide launches together); traffic (if present) = HBM bytes per "
+                    "solve over asg_auction + asg_step from the committed rocprofv3 --pmc passes (profiles/), FETCH x2 + WRITE"}
 
 
 def self_launch(args, argv):
@@ -606,16 +638,45 @@ def cpu_standin_main(args):
     def couple_group(batches, drawn):
         return [couple(x0, x1, dr) for (x0, x1), dr in zip(batches, drawn)]
 
+    if args.host_cost:
+        # HOST-COST stand-in (VERDICT r4 Next #10): what the host side of a rank costs per step when the device work is
+        # replaced by waits of its measured duration with the GIL released (a coupling job of g minibatches: g x 0.9 ms
+        # of launch chain — the solver's host thread sits in hipEventSynchronize —, a model step: 0.45 ms in flight while
+        # the host runs ahead): the real loop (run_steps, the prefetch workers, the host RNG draws of the real batch
+        # size, the futures and hand-overs) with nothing but that left.  Reported: process CPU time per step (all
+        # threads) — below the GPU step means one host core per rank carries the loop.
+        Bh = args.batch
+        hb = [(torch.zeros(1), torch.zeros(1)) for _ in range(4)]
+
+        def draw():                                                   # noqa: F811  (the real draws: 8 B x B + 4 B x B per coupling)
+            return np.random.random_sample(Bh), torch.rand(Bh)
+
+        def couple(x0, x1, drawn):                                    # noqa: F811
+            time.sleep(0.9e-3)
+            return drawn[1], x0, x1
+
+        def couple_group(batches, drawn):                             # noqa: F811
+            time.sleep(0.9e-3 * len(batches))
+            return [(dr[1], x0, x1) for (x0, x1), dr in zip(batches, drawn)]
+
+        def model_step(t, xt, ut):                                    # noqa: F811
+            time.sleep(0.45e-3)
+        pool = hb
+
     pre = CouplingPrefetcher(None, torch.device("cpu"), workers=args.pipeline) if args.pipeline else None
     if pre is not None:
         pre.prime(lambda: None)
-    regions = []
+    regions, cpu_s = [], []
     for _ in range(max(1, args.repeats)):
+        c0 = time.process_time()
         el, gathered = timed_region(D, lambda: None, pool, args.warmup, args.steps, couple, model_step, draw, pre,
                                     args.pipeline, torch.device("cpu"), args.group, couple_group)
-        assert gathered.shape[0] == world * B
+        cpu_s.append(time.process_time() - c0)
+        assert args.host_cost or gathered.shape[0] == world * B
         regions.append(el)
     elapsed = float(np.median(regions))
+    # process CPU time (all threads) per step of the slowest rank, warm-up steps included in the denominator
+    host_cpu_ms = D.max_over_ranks(float(np.median(cpu_s)) / (args.steps + args.warmup) * 1e3, torch.device("cpu"))
     if pre is not None:
         pre.close()
     if rank == 0:
@@ -624,7 +685,9 @@ def cpu_standin_main(args):
                           "repeats": len(regions), "ms_per_step_all": [round(r / args.steps * 1e3, 4) for r in regions],
                           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "cpu-standin (launcher self-test, NOT a measurement)",
-                          "valid": False, "config": {"workload": "launcher self-test", "parallelism": f"dp{world}"}}))
+                          "valid": False, "host_cpu_ms_per_step": host_cpu_ms, "host_cost_standin": bool(args.host_cost),
+                          "host_cores": os.cpu_count(),
+                          "config": {"workload": "launcher self-test", "parallelism": f"dp{world}"}}))
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -672,6 +735,9 @@ def main():
                          "asynchronous auction in the batch entry; last_div: its last phase is cut at stop_frac / last_div")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the C1 / C2 / C5 / roofline legs")
+    ap.add_argument("--host-cost", action="store_true",
+                    help="with --cpu-standin: device work replaced by waits of its measured duration; the line carries the "
+                         "host CPU time per step (max over ranks)")
     ap.add_argument("--cpu-standin", action="store_true",
                     help="launcher self-test on CPU tensors over gloo (no measurement; see cpu_standin_main)")
     args = ap.parse_args()

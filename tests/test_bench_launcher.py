@@ -112,3 +112,23 @@ def test_two_ranks_sharing_the_gpu_run_the_real_loop():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["valid"] is False and d["value"] > 0
     assert d["config"]["parallelism"] == "dp2"
+
+
+def test_gpus_8_host_cost_fits_one_core_per_rank():
+    """8-GPU readiness without the node (VERDICT r4 Next #10): the host side of 8 ranks x (1 + 3) threads — run_steps, the
+    prefetch workers, futures, per-coupling RNG draws of the real batch size, the final all-gather and the max-over-ranks
+    plumbing — with the device work replaced by waits of its measured duration (GIL released).  The process CPU time per
+    step of the slowest rank must stay well below the ~1.06 ms GPU step, i.e. one host core per rank carries the loop
+    (here 8 ranks share this box's cores; the GPU node has 256).  What the stand-in cannot see is stated in DESIGN 7:
+    the HIP runtime's own threads and the solver's event waits."""
+    p = _run(["--gpus", "8", "--steps", "40", "--warmup", "8", "--pipeline", "3", "--group", "4", "--repeats", "3",
+              "--cpu-standin", "--host-cost"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["host_cost_standin"] is True and out["valid"] is False
+    print("host CPU ms per step (max over 8 ranks):", out["host_cpu_ms_per_step"], "wall ms per step:", out["ms_per_step"])
+    assert out["host_cpu_ms_per_step"] < 0.8                  # one core per rank: below the 1.06 ms device step with margin
+    # and the stand-in loop itself keeps the stubbed device busy: the wall step is close to the stubbed durations
+    # (0.9 ms of coupling chain per minibatch over 3 workers, 0.45 ms of model step), not host bound
+    if (os.cpu_count() or 1) >= 8:
+        assert out["ms_per_step"] < 1.6

@@ -57,23 +57,32 @@ def util(pmc_csv, out):
 def asgjson(fetch_csv, write_csv, out):
     import json
     def load(f, counter):
-        d = {}
+        d, calls = {}, {}
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 if r["counter"] == counter:
-                    d[r["kernel"]] = float(r["mean_per_call"])
-        return d
-    fe, wr = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+                    d[r["kernel"]] = float(r["mean_per_call"]); calls[r["kernel"]] = int(r["calls"])
+        return d, calls
+    (fe, fcalls), (wr, _) = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     res = {}
-    for k in ("asg_step", "asg_build", "asg_solve", "asg_small"):
+    for k in ("asg_auction", "asg_step", "asg_build", "asg_solve", "asg_small"):
         if k in fe:
             res[f"{k}_FETCH_SIZE_KiB_per_launch"] = round(fe[k], 3)
             res[f"{k}_WRITE_SIZE_KiB_per_launch"] = round(wr.get(k, 0.0), 3)
+            res[f"{k}_launches"] = fcalls[k]
     if "asg_step" in fe:
         res["asg_step_hbm_bytes_per_launch"] = round((2.0 * fe["asg_step"] + wr.get("asg_step", 0.0)) * 1024.0, 3)
+    # per SOLVE over the chip-wide kernels (asg_auction: the epsilon > 0 phases in one launch; asg_step: every other step):
+    # the figure bench.py's roofline sets next to algorithmic_bytes_per_solve
+    solves = fcalls.get("asg_init", 0)
+    if solves:
+        tot = sum((2.0 * fe[k] + wr.get(k, 0.0)) * 1024.0 * fcalls[k] for k in ("asg_auction", "asg_step") if k in fe)
+        res["solves"] = solves
+        res["asg_chip_wide_hbm_bytes_per_solve"] = round(tot / solves, 3)
     res["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/asg_trace.py (8 C3 solves); FETCH_SIZE x2 "
                    "(gfx950 reports half the bytes of wide coalesced reads: calibrated on cost_tiled, which writes its 64 MiB output = "
-                   "65536 KiB of WRITE_SIZE), WRITE_SIZE x1; means include no-op launches")
+                   "65536 KiB of WRITE_SIZE), WRITE_SIZE x1; means include no-op launches; per solve = sum over the launches of "
+                   "asg_auction and asg_step / number of asg_init launches")
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
 
