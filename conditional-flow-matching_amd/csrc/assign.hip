@@ -113,7 +113,7 @@ static std::mutex g_params_mu;
 // async_blocks / async_last_div: measured in the C3 pipelined loop, three interleaved passes of nine regions each on one box
 // (profiles/r5_async_sweep.txt): synchronous rounds 1.18 - 1.21 ms per step; asynchronous on 16 workgroups per problem
 // 1.10 - 1.12, with the last phase cut at a quarter of the usual 2 % 1.07 - 1.11; 24 / 32 workgroups 1.09 - 1.13; cut / 8: 1.10 - 1.11.
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 1, 16, 4};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 2, 16, 4};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
@@ -138,7 +138,7 @@ extern "C" void cfm_assign_set_handoff(int handoff) {      // at most 64 free ro
 extern "C" void cfm_assign_set_stop_early(double f) { std::lock_guard<std::mutex> lk(g_params_mu); if (f >= 0.0 && f < 1.0) g_params.stop_early = f; }
 extern "C" void cfm_assign_set_async(int on, int blocks, int last_div) {
     std::lock_guard<std::mutex> lk(g_params_mu);
-    g_params.async_auction = on ? 1 : 0;
+    g_params.async_auction = on < 0 ? 0 : (on > 2 ? 2 : on);        // 1: the epsilon > 0 phases; 2: the epsilon = 0 rounds too
     if (blocks >= 0) g_params.async_blocks = blocks;
     if (last_div > 0) g_params.async_last_div = last_div;
 }
@@ -1565,7 +1565,14 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
     int scans_tot = 0, lists_tot = 0;
     // controller state (workgroup 0, thread 0)
     int c_rounds = 0, c_total_rounds = 0;
-    const int last_div = asg_uni_i(st->pad0) > 0 ? asg_uni_i(st->pad0) : 1;
+    const int pad0 = asg_uni_i(st->pad0);
+    const int last_div = (pad0 & 0xff) > 0 ? (pad0 & 0xff) : 1;
+    const bool do_arr = ((pad0 >> 8) & 1) != 0;                      // the epsilon = 0 rounds run here too (below)
+    // (an epsilon = 0 iteration costs a workgroup ~5 us here, not a launch of the whole chip: 2 x the synchronous cap + 4.
+    //  Measured over 40 C3 instances, profiles/r5_async_sweep.txt: 10 / 16 / 24 iterations leave 36.5 / 32.3 / 28.4 free
+    //  rows to the list solver, lone solve 2.42 / 2.43 / 2.33 ms)
+    const int arr_cap = 2 * asg_uni_i(H.arr_cap) + 4;
+    int arr_it = 0, c_arr_rounds = 0;
     const int stop_mid = asg_uni_i((int)(fmax(stop_frac, stop_early) * n)), stop_last = asg_uni_i((int)(stop_frac / last_div * n));
     bool c_last = (eps / theta) < eps_last;
     int c_stop = c_last ? stop_last : stop_mid;
@@ -1601,36 +1608,52 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
         if (word < 0) break;                                         // (uniform) the phases are over
         const int wphase = word & 0xffff;
         while (phase < wphase) { eps = eps / theta; ++phase; }       // a new phase: every row is unassigned again (new tag)
-        const int tag = (phase % 254) + 1;
+        // The epsilon = 0 rounds (bit 30 of the word; phase = the number of epsilon phases run): the same loop with
+        // epsilon = 0 and a fresh tag.  A kept pair is exactly tight whatever the timing: the bid b = p'_j + (second' -
+        // best'), from a snapshot p' <= p, leaves c_ij + b = second' <= c_ik + p'_k <= c_ik + p_k for every other k if it
+        // is accepted, and prices only rise afterwards.  Equal-price bids are decided by the round field as in the
+        // synchronous rounds — here the bidder's own count of epsilon = 0 iterations: a later try beats an earlier one.
+        const bool arr = ((word >> 30) & 1) != 0;
+        const int tag = (phase % 254) + 1;                           // (the phases used tags 1 .. phase; this one is new)
+        const double eps_use = arr ? 0.0 : eps;
+        const int rnd = arr ? min(arr_it + 1, (1 << ASG_RND_BITS) - 1) : 0;
+        arr_it += arr ? 1 : 0;
+        const int slot_tag = (phase + 1) | (arr ? 0x4000 : 0);
         // ---- bid: the synchronous round's body on this snapshot ----
-        const int nb = wide_bid_queue(M, w, p_lds, r_lds, bq, &shc[1], my_bc, true, n, eps, tag, rb, 0);
+        const int nb = wide_bid_queue(M, w, p_lds, r_lds, bq, &shc[1], my_bc, true, n, eps_use, tag, rb, rnd);
         if (lane == 0 && nb) atomicAdd(&shc[0], nb);
         __syncthreads();
         const int mine = asg_uni_i(shc[0]);                               // bids of this iteration = rows found unmatched (+ list-served ones above bit 16)
         idle = ((mine & 0xffff) == 0);
         scans_tot += mine & 0xffff; lists_tot += mine >> 16;
         // ---- report; workgroup 0 decides ----
-        if (threadIdx.x == 0) asg_st(&cnt[blockIdx.x], ((phase + 1) << 16) | (mine & 0xffff));
+        if (threadIdx.x == 0) asg_st(&cnt[blockIdx.x], (slot_tag << 16) | (mine & 0xffff));
         if (blockIdx.x == 0 && wv == 0) {
             // (the controller's own slot may not have landed yet: it uses `mine` for itself)
             int tot = 0;
             for (int g = lane; g < G; g += 64) {
-                const int c = (g == 0) ? (((phase + 1) << 16) | (mine & 0xffff)) : asg_ld(&cnt[g]);
+                const int c = (g == 0) ? ((slot_tag << 16) | (mine & 0xffff)) : asg_ld(&cnt[g]);
                 const int rg = (n - g + G - 1) / G;
-                tot += ((c >> 16) == phase + 1) ? (c & 0xffff) : rg;  // a slot of another phase (or never written): all of its rows
+                tot += ((c >> 16) == slot_tag) ? (c & 0xffff) : rg;   // a slot of another phase (or never written): all of its rows
             }
             tot = wave_sum_i(tot);
             if (lane == 0) {
+                int nw = 0;                                          // 0: go on; != 0: new word
+                if (arr) {
+                    ++c_arr_rounds;
+                    if (tot == 0 || c_arr_rounds >= arr_cap || it + 8 >= ASG_ASYNC_ITER_CAP) nw = (int)0x80000000u | phase;
+                } else {
                 ++c_rounds; ++c_total_rounds;
-                int nw = 0;                                          // 0: go on; > 0: new word
                 if (tot <= c_stop || c_rounds >= round_cap || it + 8 >= ASG_ASYNC_ITER_CAP) {
                     const double e2 = eps / theta;
-                    if (e2 < eps_last || it + 8 >= ASG_ASYNC_ITER_CAP) nw = (int)0x80000000u | (phase + 1);
+                    if (e2 < eps_last || it + 8 >= ASG_ASYNC_ITER_CAP)
+                        nw = (do_arr && it + 8 < ASG_ASYNC_ITER_CAP) ? (0x40000000 | (phase + 1)) : ((int)0x80000000u | (phase + 1));
                     else {
                         nw = phase + 1; c_rounds = 0;
                         c_last = (e2 / theta) < eps_last;
                         c_stop = c_last ? stop_last : stop_mid;
                     }
+                }
                 }
                 if (nw) asg_st(&w.auc->async_word, nw);
             }
@@ -1644,9 +1667,12 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
             const int word = asg_ld(&w.auc->async_word);
             if (word >= 0) asg_st(&w.auc->async_word, (int)0x80000000u | (word & 0xffff));   // (left by the cap)
             const int nph = (word & 0xffff);
+            // the epsilon = 0 rounds ran here (c_arr_rounds > 0): the next asg_step launch is the CONVERT step; else it
+            // is their first round
             AucCtl C;
-            C.eps = 0.0; C.mode = MODE_ARR; C.tag = (nph % 254) + 1; C.round = 0; C.phase = nph; C.stop = 0; C.arr_round = 0;
-            C.r = 0; C.auction_rounds = c_total_rounds; C.arr_rounds = 0; C.row_scans = 0; C.pad[0] = C.pad[1] = 0;
+            C.eps = 0.0; C.mode = c_arr_rounds > 0 ? MODE_CONVERT : MODE_ARR; C.tag = (nph % 254) + 1; C.round = 0; C.phase = nph; C.stop = 0;
+            C.arr_round = c_arr_rounds;
+            C.r = 0; C.auction_rounds = c_total_rounds; C.arr_rounds = c_arr_rounds; C.row_scans = 0; C.pad[0] = C.pad[1] = 0;
             w.auc->ctl[0] = C; w.auc->ctl[1] = C;                    // whichever parity the next asg_step launch has
             for (int q = 0; q < 4; ++q) asg_st(&w.auc->bidcnt[q], 0);
             w.auc->async_done = 1;
@@ -1773,6 +1799,21 @@ struct AsgLaunch {
         // asynchronous phase A: ONE launch behind the two init steps (a no-op in any other state, like every kernel here)
         auto auction = [&]() { if (async_auction) hipLaunchKernelGGL(asg_auction, dim3(blocks_auction, nb), dim3(WT), lds_step, s, w, n, stride); };
         if (prg == PRG_BULK) {
+            if (async_auction >= 2 && sparse) {
+                // The WHOLE solve as the unpolled head when the bid rounds (epsilon > 0 and epsilon = 0) are the one auction
+                // launch and the list solver closes the search: 2 init steps, the auction, convert / row minima / column
+                // reduction (+ one spare step: an even count), list build, list solver, certificate (+ one spare).  A solve
+                // that takes this road — every C3 instance seen so far — is finished when the head is; the others are
+                // picked up by the polled chunks.  (Round 4's head was 96 steps, then chunks of 10 steps + the pair + 2: a
+                // lone solve paid ~35 no-op launches, 0.15 ms, around its list build and behind its last step.)
+                step(k++); step(k++);
+                auction();
+                step(k++); step(k++); step(k++); step(k++);
+                hipLaunchKernelGGL(asg_build, dim3(blocks_build, nb), dim3(SP_BUILD_WAVES * 64), lds_build, s, w, n, stride);
+                hipLaunchKernelGGL(asg_solve, dim3(1, nb), dim3(SP_T), lds_solve, s, w, n, stride);
+                step(k++); step(k++);
+                return;
+            }
             for (int c = 0; c < bulk; ++c) { if (c == 2) auction(); step(k++); }
             return;
         }
@@ -1784,7 +1825,10 @@ struct AsgLaunch {
             step(k++); step(k++);      // certificate + whatever the guess missed
         }
     }
-    int count(int prg, int chunk, int bulk) const { return (prg == PRG_BULK ? bulk : chunk + (sparse ? 4 : 0)) + ((async_auction && (prg != PRG_BULK || bulk > 2)) ? 1 : 0); }
+    int count(int prg, int chunk, int bulk) const {
+        if (prg == PRG_BULK && async_auction >= 2 && sparse) return bulk > 0 ? 11 : 0;
+        return (prg == PRG_BULK ? bulk : chunk + (sparse ? 4 : 0)) + ((async_auction && (prg != PRG_BULK || bulk > 2)) ? 1 : 0);
+    }
 };
 
 // the first 64 bytes of every problem's state block, gathered for ONE copy to the host
@@ -1860,7 +1904,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
         h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
         h.fr_min = ~0ull; h.fr_max = 0ull;
         h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early;
-        h.tag = 1; h.pad0 = P.async_last_div;
+        h.tag = 1; h.pad0 = P.async_last_div | ((P.async_auction >= 2 ? 1 : 0) << 8);
         { int rb = 1; while ((1 << rb) <= n) ++rb; h.rb = rb; }     // row ids 0 .. n-1 and the all-ones "none"
         hipLaunchKernelGGL(asg_init, dim3(1), dim3(64), 0, s, asg_carve((char*)ws + (size_t)b * L.stride, n), h);
     }
@@ -1884,7 +1928,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
         if (c <= 0 && (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, cfm_device_index()) != hipSuccess || c <= 0)) c = 256;
         if ((long)L.blocks_auction * nb > c) L.blocks_auction = c / nb > 0 ? c / nb : 1;
     }
-    L.async_auction = (P.async_auction && n >= 1024 && n <= WIDE_PLDS_MAX && (raised & 1) && (long)L.blocks_auction * ASG_BQ >= n) ? 1 : 0;
+    L.async_auction = (P.async_auction && n >= 1024 && n <= WIDE_PLDS_MAX && (raised & 1) && (long)L.blocks_auction * ASG_BQ >= n) ? P.async_auction : 0;
     // ... the unpolled head then is: 2 init steps, the auction launch, ~10 epsilon = 0 rounds + convert / row minima / column
     // reduction (the synchronous rounds needed ~96 launches here)
     int bulk = ((n >= P.bulk_min_n) ? P.bulk : 0) & ~1;
@@ -1935,8 +1979,8 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     rc = run(PRG_BULK); if (rc) return rc;
     int cur = 0;
     int* stage = reinterpret_cast<int*>((char*)ws + (size_t)nb * stride);      // batches: 2 x nb x 64 bytes behind the carvings
-    auto issue = [&](int slot) -> int {
-        int r2 = run(PRG_CHUNK); if (r2) return r2;
+    auto issue = [&](int slot, bool with_chunk = true) -> int {
+        int r2 = with_chunk ? run(PRG_CHUNK) : 0; if (r2) return r2;
         int* host = g_pinned + 16 * ASG_BATCH_MAX * slot;
         if (nb == 1) r2 = cfm_hip(hipMemcpyAsync(host, L.w.st, 64, hipMemcpyDeviceToHost, s));
         else {
@@ -1947,6 +1991,23 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
         if (r2) return r2;
         return cfm_hip(hipEventRecord(G.ev[slot], s));
     };
+    // the head holds the whole solve (see AsgLaunch::program): look at the state behind it BEFORE queueing anything else —
+    // a finished solve returns here, with no look-ahead chunk of no-ops to wait for
+    const bool head_is_whole = L.async_auction >= 2 && L.sparse && bulk > 0;
+    if (head_is_whole) {
+        rc = issue(0, false); if (rc) return rc;
+        rc = cfm_hip(hipEventSynchronize(G.ev[0])); if (rc) return rc;
+        const int* hs = g_pinned;
+        int open_ = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int mode = hs[16 * b + 0], err = hs[16 * b + 2];
+            if (err) err_out[b] = err;
+            else if (mode == MODE_DONE) cert_out[b] = hs[16 * b + 3];
+            else ++open_;
+        }
+        if (!open_) return 0;
+        for (int b = 0; b < nb; ++b) { err_out[b] = 0; cert_out[b] = 1; }      // (re-read by the chunk loop)
+    }
     rc = issue(0); if (rc) return rc;
     int result = 0;
     for (;;) {

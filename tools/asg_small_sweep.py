@@ -1,0 +1,43 @@
+"""Sweep the epsilon schedule of the one-workgroup solver (n <= 256) over a few instances: total time per instance set.
+    python tools/asg_small_sweep.py
+Measurement infrastructure."""
+import sys, time, ctypes, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+import cfm_amd
+from cfm_amd import _lib
+import cfm_amd.optimal_transport as ot
+import cfm_oracle as oracle
+lib = _lib.load(); dev = _lib.require_gpu()
+rng = np.random.RandomState(0)
+inst = []
+x0, x1 = oracle.config_inputs("C1")
+inst.append(("C1", ot.cost_matrix(x0.to(dev), x1.to(dev), matrix_cores=False)))
+for seed in range(3):
+    a, b = oracle.config_inputs("C1", rank=seed + 1)
+    inst.append((f"C1r{seed+1}", ot.cost_matrix(a.to(dev), b.to(dev), matrix_cores=False)))
+for n, d in ((256, 784), (128, 2), (128, 784), (64, 2)):
+    x = torch.from_numpy(rng.randn(n, d).astype(np.float32)).to(dev); y = torch.from_numpy((rng.randn(n, d) + 0.5).astype(np.float32)).to(dev)
+    inst.append((f"n{n}d{d}", ot.cost_matrix(x, y, matrix_cores=False)))
+inst.append(("uni256", torch.from_numpy((rng.rand(256, 256) * 10).astype(np.float32)).to(dev)))
+ref = {k: ot.assign_exact(M).cpu() for k, M in inst}
+
+
+def timeit(M):
+    for _ in range(2): ot.assign_exact(M)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): ot.assign_exact(M)
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / 10 * 1e6
+
+
+print("config: " + " ".join(k for k, _ in inst) + " | sum")
+for theta in (3.0, 5.0, 8.0, 12.0, 20.0):
+    for eps0 in (2e-3, 8e-3, 3e-2):
+        for cap in (1, 2):
+            lib.cfm_assign_set_params(theta, eps0, 0, -1, 0, -1, 0); lib.cfm_assign_set_small(cap + 1 if cap > 1 else 1)
+            ts = []
+            for k, M in inst:
+                ts.append(timeit(M))
+                assert torch.equal(ot.assign_exact(M).cpu(), ref[k]), (k, theta, eps0)
+            print(f"theta {theta:4.0f} eps0 {eps0:.0e} cap {cap}: " + " ".join(f"{t:5.0f}" for t in ts) + f" | {sum(ts):6.0f}")
