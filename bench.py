@@ -757,8 +757,10 @@ def main():
 
     lib_ = _lib.load()
     if args.solver_async:
-        on, blocks, div = (int(x) for x in args.solver_async.split(","))
+        on, blocks, div = (int(x) for x in args.solver_async.split(",")[:3])
         lib_.cfm_assign_set_async(on, blocks, div)
+        if len(args.solver_async.split(",")) > 3:      # 4th field: cap on the grid of the solver's other chip-wide kernels
+            lib_.cfm_assign_set_wide_blocks(int(args.solver_async.split(",")[3]))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the HIP path: it needs an MI355X (no CPU fallback exists)")
     rank, local, world = D.init_from_env()

@@ -14,6 +14,13 @@ python tools/prof_summary.py asgjson $O/asg_pmc_FETCH_SIZE.csv $O/asg_pmc_WRITE_
 rocprofv3 --kernel-trace --output-format csv -d $O/raw/asg_trace -- python tools/asg_trace.py run > /dev/null 2>&1
 python tools/asg_trace.py summary $O/raw/asg_trace > $O/asg_trace_summary.txt 2>&1
 python tools/prof_summary.py stats $O/raw/asg_trace $O/asg_kernel_stats.csv
+# the batch form of the solver (what the pipelined schedule runs): cfm_assign_exact_batch_f32 with 4 problems
+rocprofv3 --kernel-trace --output-format csv -d $O/raw/asg_batch -- python tools/asg_batch_bench.py 4 > $O/asg_batch_bench.txt 2>&1
+python tools/prof_summary.py stats $O/raw/asg_batch $O/asg_batch_kernel_stats.csv
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/raw/asg_batch_$C -- python tools/asg_batch_bench.py 4 > /dev/null 2>&1
+  python tools/prof_summary.py pmc $O/raw/asg_batch_$C $O/asg_batch_pmc_$C.csv
+done
 rocprofv3 --kernel-trace --output-format csv -d $O/raw/mfma_trace -- python tools/mfma_probe.py > /dev/null 2>&1
 python tools/prof_summary.py stats $O/raw/mfma_trace $O/mfma_kernel_stats.csv
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/raw/mfma_pmc -- python tools/mfma_probe.py > $O/mfma_pmc.log 2>&1
@@ -38,6 +45,9 @@ done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/raw/sk_C2_valu -- python tools/sk_probe.py C2 > /dev/null 2>&1
 python tools/prof_summary.py pmc $O/raw/sk_C2_valu $O/sk_C2_pmc_valu.csv
 python tools/prof_summary.py skjson $O $O/sk_pmc_summary.json
+# the C5 Sinkhorn leg window by window, with the solver's own state after each (iterations done, fp64-exp regime)
+python tools/sk_windows.py C5 > $O/sk_C5_windows.txt 2>&1
+python tools/sk_windows.py C2 >> $O/sk_C5_windows.txt 2>&1
 rocprofv3 -L 2>/dev/null | grep -i -E "mfma|FETCH_SIZE|WRITE_SIZE|MfmaUtil" | head -40 > $O/counters_available.txt
 rm -rf $O/raw
 ls -la $O
