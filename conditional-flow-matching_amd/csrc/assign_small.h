@@ -79,21 +79,33 @@ __device__ __forceinline__ double sma_c(float c, double mcs, double S) {
     return fma((double)c, S, mcs);
 }
 
-// top-2 of the lane-local (best, second) pairs over the wave in ONE DPP reduction (row_shr 1, 2, 4, 8 inside the
-// 16-lane rows, then row_bcast 15 / 31); uniform results
-__device__ __forceinline__ void sma_wave_top2(double b1, double b2, double& w1, double& w2) {
-#define SMA_STAGE(CTRL, MASK)                                                              \
-    {                                                                                      \
-        const double o1 = asg_dpp_d<CTRL, MASK>(INFINITY, b1), o2 = asg_dpp_d<CTRL, MASK>(INFINITY, b2); \
-        b2 = fmin(fmax(b1, o1), fmin(b2, o2));                                             \
-        b1 = fmin(b1, o1);                                                                 \
-    }
-    SMA_STAGE(0x111, 0xf) SMA_STAGE(0x112, 0xf) SMA_STAGE(0x114, 0xf) SMA_STAGE(0x118, 0xf)
-    SMA_STAGE(0x142, 0xa) SMA_STAGE(0x143, 0xc)
-#undef SMA_STAGE
-    w1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b1), 63), __builtin_amdgcn_readlane(__double2loint(b1), 63));
-    w2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b2), 63), __builtin_amdgcn_readlane(__double2loint(b2), 63));
+// Wave minimum of NON-NEGATIVE doubles (every value this solver reduces: scaled costs + prices, search labels, +inf
+// for padding) on their bit patterns: for x >= 0 the IEEE-754 bits order like the values, so the minimum is the
+// lexicographic minimum of (high word, low word) — two 32-bit reductions.  A 32-bit min takes its DPP operand INSIDE
+// the instruction (v_min_u32_dpp x, x, x: a lane whose source lies outside its row is left alone, which is the
+// identity here), so a reduction is 6 instructions + 1 v_readlane; the fp64 form needs two v_mov_b32_dpp and two seed
+// moves per stage around every v_min_f64 (round 4: ~100 of the ~190 instructions of a bid were this reduction, and the
+// one-workgroup solver is issue bound: 16 waves on 4 SIMDs).  (s_nop 1: the two wait states between a VALU write and a
+// DPP read of the same register, which the compiler cannot insert inside an asm block.)
+__device__ __forceinline__ unsigned sma_wave_min_u32(unsigned x) {
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(x));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
+struct SmaMin { unsigned hi, lo; };
+__device__ __forceinline__ SmaMin sma_wave_min_pos(double v) {          // v >= 0 in every lane; uniform result
+    const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+    SmaMin m;
+    m.hi = sma_wave_min_u32(hi);
+    m.lo = sma_wave_min_u32(hi == m.hi ? lo : 0xffffffffu);
+    return m;
+}
+__device__ __forceinline__ double sma_min_value(SmaMin m) { return __hiloint2double((int)m.hi, (int)m.lo); }
 
 // the 4 entries of row slot r (0..15) of this wave: r is wave uniform, the registers are selected with
 // constant indices (a dynamically indexed register array would go to scratch)
@@ -119,9 +131,13 @@ __device__ __forceinline__ SmaTop sma_top2(const float4& c, const double (&p)[4]
     b2 = fmin(b2, fmax(b1, v2)); k1 = v2 < b1 ? 2 : k1; b1 = fmin(b1, v2);
     b2 = fmin(b2, fmax(b1, v3)); k1 = v3 < b1 ? 3 : k1; b1 = fmin(b1, v3);
     SmaTop t;
-    sma_wave_top2(b1, b2, t.w1, t.w2);
-    const unsigned long long ball = __ballot(b1 == t.w1);
+    // the wave's best, the lane that holds it (the first one), then the best of everything else: that lane's second, the
+    // other lanes' best — the same pair the (best, second) pair reduction of round 4 produced
+    const SmaMin m1 = sma_wave_min_pos(b1);
+    t.w1 = sma_min_value(m1);
+    const unsigned long long ball = __ballot((unsigned)__double2hiint(b1) == m1.hi && (unsigned)__double2loint(b1) == m1.lo);
     const int win = __builtin_amdgcn_readfirstlane(__ffsll((long long)ball) - 1);
+    t.w2 = sma_min_value(sma_wave_min_pos(lane == win ? b2 : b1));
     t.j1 = __builtin_amdgcn_readlane(4 * lane + k1, win);
     const double ps = k1 == 0 ? p[0] : k1 == 1 ? p[1] : k1 == 2 ? p[2] : p[3];
     t.pold = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ps), win),
@@ -169,7 +185,7 @@ __device__ __forceinline__ void sma_scan(SmaShared& sh, const float4& c, int row
         if (open && nd[k] < d[k]) { d[k] = nd[k]; sh.dist[4 * lane + k] = nd[k]; sh.pred[4 * lane + k] = (short)row; }
         if (open && d[k] < b1) { b1 = d[k]; k1 = k; }
     }
-    const double w1 = asg_wave_min_d(b1);
+    const double w1 = sma_min_value(sma_wave_min_pos(b1));           // (labels are >= 0 or +inf)
     const unsigned long long ball = __ballot(b1 == w1);
     const int win = __builtin_amdgcn_readfirstlane(__ffsll((long long)ball) - 1);
     const int js = __builtin_amdgcn_readlane(4 * lane + k1, win);
