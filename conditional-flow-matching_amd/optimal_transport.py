@@ -413,7 +413,6 @@ class OTPlanSampler:
 
     # ---- device-resident solve (no host plan) ----
     def _prepare(self, x0, x1):
-        dev = _lib.require_gpu()
         # The reference computes torch.cdist in the INPUT dtype (ref:84) and hands POT that matrix; the device
         # solvers take an fp32 cost matrix (fp64 duals / potentials on top of it).  float64 clouds are therefore
         # coupled on the fp32 rounding of their coordinates — said once per sampler, never silently (the matchers'
@@ -423,6 +422,7 @@ class OTPlanSampler:
             self._warned_f64 = True
             warnings.warn("OTPlanSampler: float64 inputs are coupled on a float32 cost matrix (the device solvers' input "
                           "precision); the reference would solve on the float64 matrix.", UserWarning, stacklevel=3)
+        dev = _lib.require_gpu()
         a = _lib.to_dev_f32(_flatten2(x0), dev)
         b = _lib.to_dev_f32(_flatten2(x1), dev)
         M = cost_matrix(a, b, squared=True, normalize=self.normalize_cost)

@@ -66,3 +66,49 @@ def test_trajectory_of_unbalanced_plans_matches_the_host_chain(dev):
         idx.append(np.array([np.random.choice(96, p=pi[i] / pi[i].sum()) for i in idx[-1]]))
     ref = np.stack([X[:, t].numpy()[idx[t]] for t in range(4)], axis=1)
     assert np.array_equal(out, ref)
+
+
+def test_trajectory_diagnostics_of_a_plan_without_mass_or_with_nans(dev, monkeypatch):
+    """sample_trajectory goes through get_map's diagnostics per slice like the reference (ref:88-96 via :233): a plan
+    without mass reverts to the uniform plan (with the warning), a non-finite one is reported and raises what
+    np.random.choice raises, a visited row without mass raises too — never silent last-column indices."""
+    import warnings
+    from cfm_amd.optimal_transport import OTPlanSampler
+    g = torch.Generator().manual_seed(8)
+    X = torch.randn(64, 3, 2, generator=g)
+    s = OTPlanSampler(method="unbalanced", reg=1.0, reg_m=2.0)
+    real = s._solve_many
+
+    def patched(kind):
+        def solve_many(pairs, workers=3):
+            sols = real(pairs, workers)
+            k, plan, M = sols[1]
+            plan = plan.clone()
+            if kind == "zero":
+                plan.zero_()
+            elif kind == "nan":
+                plan[3, 5] = float("nan")
+            else:                                    # half of the rows without mass, the plan as a whole fine
+                plan[:] = 1.0 / plan.numel(); plan[:32] = 0.0
+            sols[1] = (k, plan, M)
+            return sols
+        return solve_many
+
+    monkeypatch.setattr(s, "_solve_many", patched("zero"))
+    np.random.seed(0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = s.sample_trajectory(X)
+    assert out.shape == (64, 3, 2) and any("reverting to uniform plan" in str(x.message) for x in w)
+    # the uniform slice draws searchsorted(cumsum(1 / B), u): column floor(u * B) up to rounding — spread over the columns
+    monkeypatch.setattr(s, "_solve_many", patched("nan"))
+    with pytest.raises(ValueError, match="probabilities contain NaN"):
+        s.sample_trajectory(X)
+    monkeypatch.setattr(s, "_solve_many", patched("row"))
+    np.random.seed(1)
+    try:
+        s.sample_trajectory(X)           # raises iff a massless row of slice 1 is visited by the chain (64 draws over 64 columns, half of them massless rows: certain)
+        visited = False
+    except ValueError as e:
+        visited = "probabilities contain NaN" in str(e)
+    assert visited
