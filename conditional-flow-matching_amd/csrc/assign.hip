@@ -1532,8 +1532,9 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
 // bound only needs prices that never fall); (iii) NOTHING downstream trusts phase A: the epsilon = 0 rounds start
 // from the prices alone ("every row is unassigned again, the prices stay"), and phases B - D are exact on any prices.
 // The only products of this kernel are the keys (prices), the bid lists and a few counters.
-// Residency: a workgroup never waits for another one to START (a late workgroup's slot reads "all rows unmatched"),
-// so a grid larger than what the chip can hold at the moment only delays the end of a phase.  Every loop is capped.
+// Residency: a workgroup never waits for another one to START — a slot never written counts as "all rows unmatched" for
+// the controller's first 64 looks only, so two auction grids from different streams that each hold a part of the chip
+// cannot stall each other; the grid is capped at the CU count (asg_run).  Every loop is capped.
 #define ASG_ASYNC_ITER_CAP 60000
 // wave-uniform values that came out of vector loads: into scalar registers (the loop carries a dozen of them)
 __device__ __forceinline__ double asg_uni_d(double v) {
@@ -1634,7 +1635,12 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
             for (int g = lane; g < G; g += 64) {
                 const int c = (g == 0) ? ((slot_tag << 16) | (mine & 0xffff)) : asg_ld(&cnt[g]);
                 const int rg = (n - g + G - 1) / G;
-                tot += ((c >> 16) == slot_tag) ? (c & 0xffff) : rg;   // a slot of another phase (or never written): all of its rows
+                // a slot of another phase: all of its rows (its workgroup is about to report).  A slot NEVER written (0
+                // since the init step): its workgroup has not started — all of its rows for the first 64 looks (every
+                // workgroup of a grid that fits the chip starts within microseconds), nothing afterwards: when two such
+                // grids from different streams each hold a part of the chip, neither may wait for workgroups that
+                // cannot start before the other one has finished (they join whatever phase is on when they do start)
+                tot += ((c >> 16) == slot_tag) ? (c & 0xffff) : ((c != 0 || it < 64) ? rg : 0);
             }
             tot = wave_sum_i(tot);
             if (lane == 0) {
