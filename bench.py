@@ -733,6 +733,8 @@ def main():
                     help="A/B switch (not used by the default run): 'on,blocks,last_div' for cfm_assign_set_async — on = 0: the exact "
                          "solver's epsilon > 0 phases as synchronous rounds; blocks: workgroups per problem of the one-launch "
                          "asynchronous auction in the batch entry; last_div: its last phase is cut at stop_frac / last_div")
+    ap.add_argument("--solver-sched", default="",
+                    help="A/B switch (not used by the default run): 'theta,eps0,eps_last,stop_frac' for cfm_assign_set_params (0 / -1 keep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the C1 / C2 / C5 / roofline legs")
     ap.add_argument("--host-cost", action="store_true",
@@ -761,6 +763,9 @@ def main():
         lib_.cfm_assign_set_async(on, blocks, div)
         if len(args.solver_async.split(",")) > 3:      # 4th field: cap on the grid of the solver's other chip-wide kernels
             lib_.cfm_assign_set_wide_blocks(int(args.solver_async.split(",")[3]))
+    if args.solver_sched:
+        th, e0, el, sf = (float(x) for x in args.solver_sched.split(","))
+        lib_.cfm_assign_set_params(th, e0, el, sf, 0, -1, 0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the HIP path: it needs an MI355X (no CPU fallback exists)")
     rank, local, world = D.init_from_env()

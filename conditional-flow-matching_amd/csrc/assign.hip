@@ -105,6 +105,7 @@ struct AsgParams {
     int async_auction;     // 1: the epsilon > 0 phases run in ONE launch without global rounds (asg_auction; 1024 <= n <= 8192)
     int async_blocks;      // ... on this many workgroups per problem in the batch entry (0: the grid of the other kernels)
     int async_last_div;    // ... the last phase is cut at stop_frac / this
+    double async_theta;    // ... its epsilon reduction factor (a phase costs it microseconds, not ~15 launches: gentler scaling pays)
 };
 
 // Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
@@ -113,13 +114,16 @@ static std::mutex g_params_mu;
 // async_blocks / async_last_div: measured in the C3 pipelined loop, three interleaved passes of nine regions each on one box
 // (profiles/r5_async_sweep.txt): synchronous rounds 1.18 - 1.21 ms per step; asynchronous on 16 workgroups per problem
 // 1.10 - 1.12, with the last phase cut at a quarter of the usual 2 % 1.07 - 1.11; 24 / 32 workgroups 1.09 - 1.13; cut / 8: 1.10 - 1.11.
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 2, 16, 4};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
+// async_theta: 40 C3 instances (profiles/r5_async_sweep.txt): theta 5 / 4 / 3 / 2.5 / 2: lone solve 2.33 / 2.28 / 2.08 / 1.92 / 1.93 ms — gentler
+// scaling leaves the list solver 15 free rows instead of 27 and shorter searches (1.04 vs 1.56 ms) for 0.1 ms more auction; the
+// sequential step 2.96 -> 2.56 ms (2.47 at theta 2), the pipelined step 1.07 -> 1.01-1.04 on the same box (1.04-1.05 at theta 2).
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 2, 16, 4, 2.5};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
                                       double stop_frac, int round_cap, int arr_cap, int chunk) {
     std::lock_guard<std::mutex> lk(g_params_mu);
-    if (theta > 1.0) g_params.theta = theta;
+    if (theta > 1.0) { g_params.theta = theta; g_params.async_theta = theta; }      // (an explicit factor applies to both forms of the auction)
     if (eps0_frac > 0) g_params.eps0_frac = eps0_frac;
     if (eps_last_frac > 0) g_params.eps_last_frac = eps_last_frac;
     if (stop_frac >= 0) g_params.stop_frac = stop_frac;
@@ -1899,13 +1903,25 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     L.sparse = (use_sparse && n <= SP_NMAX && (raised & 2)) ? 1 : 0;
     L.lds_build = sp_build_lds_bytes(n); L.lds_solve = sp_solver_lds_bytes(n);
 
+    // asynchronous phase A: the keys must fit the LDS snapshot and the grid must give every workgroup at most ASG_BQ rows
+    L.blocks_auction = wide_blocks;
+    if (nb > 1 && P.async_blocks > 0 && P.async_blocks < wide_blocks) L.blocks_auction = P.async_blocks;
+    if ((long)L.blocks_auction * ASG_BQ < n) L.blocks_auction = (n + ASG_BQ - 1) / ASG_BQ;      // (a workgroup takes at most ASG_BQ rows)
+    {   // its workgroups (16 waves, the whole register file of a CU each) must be able to be resident TOGETHER: a phase ends
+        // when the whole grid has reported, and a workgroup that has not started counts as "all rows unmatched"
+        static int cus[CFM_MAX_DEVICES];
+        int& c = cus[cfm_device_index()];
+        if (c <= 0 && (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, cfm_device_index()) != hipSuccess || c <= 0)) c = 256;
+        if ((long)L.blocks_auction * nb > c) L.blocks_auction = c / nb > 0 ? c / nb : 1;
+    }
+    L.async_auction = (P.async_auction && n >= 1024 && n <= WIDE_PLDS_MAX && (raised & 1) && (long)L.blocks_auction * ASG_BQ >= n) ? P.async_auction : 0;
     for (int b = 0; b < nb; ++b) {
         AsgState h;
         memset(&h, 0, sizeof(h));
         h.wide_blocks = wide_blocks;
         h.mode = MODE_UMIN0; h.n = n; h.Mptr = pr[b].M;
         h.out_perm = pr[b].perm; h.out_cert = pr[b].certified; h.out_cost = pr[b].total_cost; h.out_stats = pr[b].stats;
-        h.eps = P.eps0_frac; h.eps_last = P.eps_last_frac; h.theta = P.theta;
+        h.eps = P.eps0_frac; h.eps_last = P.eps_last_frac; h.theta = L.async_auction ? P.async_theta : P.theta;
         h.stop_frac = P.stop_frac; h.round_cap = P.round_cap; h.arr_cap = P.arr_cap;
         h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
         h.fr_min = ~0ull; h.fr_max = 0ull;
@@ -1923,18 +1939,6 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     // build vary by ~+-6 between problems: 24 instead of 10 steps in front of the pair (a no-op step costs 3-5 us).
 #define ASG_BATCH_CHUNK 24
     if (nb > 1 && chunk < ASG_BATCH_CHUNK) chunk = ASG_BATCH_CHUNK;
-    // asynchronous phase A: the keys must fit the LDS snapshot and the grid must give every workgroup at most ASG_BQ rows
-    L.blocks_auction = wide_blocks;
-    if (nb > 1 && P.async_blocks > 0 && P.async_blocks < wide_blocks) L.blocks_auction = P.async_blocks;
-    if ((long)L.blocks_auction * ASG_BQ < n) L.blocks_auction = (n + ASG_BQ - 1) / ASG_BQ;      // (a workgroup takes at most ASG_BQ rows)
-    {   // its workgroups (16 waves, the whole register file of a CU each) must be able to be resident TOGETHER: a phase ends
-        // when the whole grid has reported, and a workgroup that has not started counts as "all rows unmatched"
-        static int cus[CFM_MAX_DEVICES];
-        int& c = cus[cfm_device_index()];
-        if (c <= 0 && (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, cfm_device_index()) != hipSuccess || c <= 0)) c = 256;
-        if ((long)L.blocks_auction * nb > c) L.blocks_auction = c / nb > 0 ? c / nb : 1;
-    }
-    L.async_auction = (P.async_auction && n >= 1024 && n <= WIDE_PLDS_MAX && (raised & 1) && (long)L.blocks_auction * ASG_BQ >= n) ? P.async_auction : 0;
     // ... the unpolled head then is: 2 init steps, the auction launch, ~10 epsilon = 0 rounds + convert / row minima / column
     // reduction (the synchronous rounds needed ~96 launches here)
     int bulk = ((n >= P.bulk_min_n) ? P.bulk : 0) & ~1;

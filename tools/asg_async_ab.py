@@ -32,6 +32,10 @@ with torch.cuda.stream(torch.cuda.Stream()):
         lib.cfm_assign_set_async(*asy[:3])
         if len(asy) > 3:                                       # 4th field: number of epsilon = 0 rounds
             lib.cfm_assign_set_params(0, 0, 0, -1, 0, asy[3], 0)
+        sched = os.environ.get("SCHED")                        # "theta,eps0,eps_last,stop_frac" (0 / -1 keep the default)
+        if sched:
+            th, e0, el, sf = (float(x) for x in sched.split(","))
+            lib.cfm_assign_set_params(th, e0, el, sf, 0, -1, 0)
         for M in Ms[:2]:
             ot.assign_exact(M)
         ts, acc, st = [], np.zeros(16), []

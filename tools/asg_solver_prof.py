@@ -15,17 +15,20 @@ B = 4096
 names = ["phase init (labels, roots)", "fast batches", "collect", "a-posteriori", "phase finish (accept, duals, augment)", "dense batches", "#fast", "#batches", "#phases",
          "fb: entries+lists issue", "fb: gathers+lower", "fb: barrier1", "fb: phase W", "fb: barrier2", "fb: radius (last wave)", "pending seen"]
 with torch.cuda.stream(torch.cuda.Stream()):
-    Ms = [ot.cost_matrix(x0, x1) for (x0, x1) in bench.synth_batches(B, 784, 8, 1000, dev)]
+    Ms = [ot.cost_matrix(x0, x1) for (x0, x1) in bench.synth_batches(B, 784, 8, 1000, dev) + bench.synth_batches(B, 784, 8, 2000, dev)]
     ws = _lib.workspace(_lib.OP_ASSIGN, B, B, 0, dev)
-    acc = np.zeros(16)
-    for M in Ms:
-        ot.assign_exact(M); torch.cuda.synchronize()
-        buf = (ctypes.c_longlong * 16)()
-        _lib.check(lib.cfm_assign_debug_solver(_lib.ptr(ws), B, buf), "dbg")
-        acc += np.array(list(buf), dtype=np.float64)
-    acc /= len(Ms)
-    clk = 100e6   # wall_clock64 ticks? the solver uses clock64 (shader clock); print raw and per-batch
-    print("mean per solve (cycles of clock64; per-batch in parentheses):")
-    nb = max(acc[7], 1)
-    for q, nm in enumerate(names):
-        print(f"  {nm:26s} {acc[q]:12.0f}   ({acc[q]/nb:9.1f})")
+    for asy in [int(x) for x in os.environ.get("ASYNC_LIST", "0,2").split(",")]:
+        lib.cfm_assign_set_async(asy, -1, -1)
+        print(f"== cfm_assign_set_async({asy}): {'synchronous bid rounds' if asy == 0 else 'one-launch asynchronous auction'}")
+        acc = np.zeros(16); free = []
+        for M in Ms:
+            _, info = ot.assign_exact(M, return_info=True); torch.cuda.synchronize()
+            free.append(info["stats"][2])
+            buf = (ctypes.c_longlong * 16)()
+            _lib.check(lib.cfm_assign_debug_solver(_lib.ptr(ws), B, buf), "dbg")
+            acc += np.array(list(buf), dtype=np.float64)
+        acc /= len(Ms)
+        print(f"mean per solve over {len(Ms)} instances, free rows handed to the solver {np.mean(free):.1f} (cycles of clock64; per batch in parentheses):")
+        nb = max(acc[7], 1)
+        for q, nm in enumerate(names):
+            print(f"  {nm:26s} {acc[q]:12.0f}   ({acc[q]/nb:9.1f})")
