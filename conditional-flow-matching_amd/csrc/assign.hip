@@ -16,9 +16,13 @@
 // min / max words), so no release / acquire fence is paid; everything else is read by
 // the NEXT launch, where the kernel boundary is the fence.  A kernel whose family does
 // not own the current mode exits at once, so the host may replay a guessed program:
-// correctness never depends on the guess.  Three kernels, one per register / LDS
-// profile (no scratch, no oversized LDS reservation):
+// correctness never depends on the guess.  Four kernels, one per register / LDS
+// profile (no oversized LDS reservation):
 //
+//   asg_auction  (round 5; 1024 <= n <= 8192) every bid of the solve — the epsilon > 0 phases and the epsilon = 0
+//              stage — in ONE launch without global rounds: see "asynchronous phase A" below.  The synchronous
+//              rounds of asg_step (phases A / B as described here) remain the path of the other sizes, the
+//              fallback of a failed list certificate, and the A/B reference (cfm_assign_set_async(0, ...)).
 //   asg_step   every chip-wide step   UMIN0, INITRED, AUCTION, ARR, CONVERT, UMIN, COLRED, ROOTMIN,
 //                                     SAP, MS_FINISH, CERT       (125 VGPRs, <= 48 KiB LDS at n = 4096)
 //   asg_build  candidate lists        BUILD            (n <= 4096; 8 waves, 128 KiB of row strips)
