@@ -21,9 +21,12 @@ the OT path), the model is data parallel (gradient all-reduce over RCCL), and th
 timed region is all-gathered once (the north star's "all-gather of the final samples"), inside
 the timed region; weak scaling.  Rank 0 prints ONE JSON line.
 
-Also in the line (rank 0, N = 1): `roofline` of the dominant kernel (asg_step, per solve, from an
-un-overlapped leg), `c2` / `c5` (BASELINE configs[1] / configs[4]: Sinkhorn iterations/s and, for
-C5, the dopri5 sampling time), `c1_solve_ms` (exact-OT latency at B = 256) and `cpu_baseline`.
+Also in the line (rank 0, N = 1): `roofline` of the coupling's dominant kernel family (the exact solver's chip-wide
+kernels asg_auction + asg_step, per solve from an un-overlapped leg, and for the batch-of-4 form the schedule runs),
+`value_public_api` (the sequential and the pipelined loop through FM.sample_location_and_conditional_flow[_group],
+asserted bit-equal to the composition timed above), `c2` / `c5` (BASELINE configs[1] / configs[4]: Sinkhorn
+iterations/s as the median of 7 windows with the solver's state after each, and, for C5, the dopri5 sampling time),
+`c1` (exact-OT latency at B = 256 next to its CPU figure), `aux`, `parity` and `cpu_baseline`.
 """
 import argparse
 import collections
