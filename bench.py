@@ -785,7 +785,7 @@ def main():
     torch.cuda.set_device(dev)
     B, d = args.batch, args.dim
 
-    pool = synth_batches(B, d, min(8, args.steps + args.warmup), D.shard_seed(1000, rank), dev)
+    pool = synth_batches(B, d, min(16, args.steps + args.warmup), D.shard_seed(1000, rank), dev)      # 16 distinct minibatches, cycled (solver time is instance dependent)
     fm = ExactOptimalTransportConditionalFlowMatcher(sigma=args.sigma)
     torch.manual_seed(0)
     model = cfm_amd.MLP(dim=d, time_varying=True, w=args.width).to(dev)

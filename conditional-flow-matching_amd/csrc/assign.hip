@@ -148,7 +148,7 @@ extern "C" void cfm_assign_set_async(int on, int blocks, int last_div) {
     std::lock_guard<std::mutex> lk(g_params_mu);
     g_params.async_auction = on < 0 ? 0 : (on > 2 ? 2 : on);        // 1: the epsilon > 0 phases; 2: the epsilon = 0 rounds too
     if (blocks >= 0) g_params.async_blocks = blocks;
-    if (last_div > 0) g_params.async_last_div = last_div;
+    if (last_div > 0) g_params.async_last_div = last_div;      // (bits 8+: see asg_run)
 }
 extern "C" void cfm_assign_set_small(int on) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.small = on > 0 ? on : 0; }
 extern "C" void cfm_assign_set_bulk(int bulk, int min_n) {
@@ -1540,10 +1540,19 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
 // bound only needs prices that never fall); (iii) NOTHING downstream trusts phase A: the epsilon = 0 rounds start
 // from the prices alone ("every row is unassigned again, the prices stay"), and phases B - D are exact on any prices.
 // The only products of this kernel are the keys (prices), the bid lists and a few counters.
-// Residency: a workgroup never waits for another one to START — a slot never written counts as "all rows unmatched" for
-// the controller's first 64 looks only, so two auction grids from different streams that each hold a part of the chip
-// cannot stall each other; the grid is capped at the CU count (asg_run).  Every loop is capped.
+// Residency: the phases wait for workgroups that have not started yet (a slot never written counts as "all rows
+// unmatched") — but only for ASG_ASYNC_GRACE looks of the controller, so two auction grids from different streams that
+// each hold a part of the chip cannot stall each other for long; the grid is capped at the CU count (asg_run).  Every
+// loop is capped.
 #define ASG_ASYNC_ITER_CAP 60000
+// Looks of the controller during which a workgroup that has not started counts as "all rows unmatched".  Its only purpose
+// is to break the mutual wait of two chip-sized auction grids that each hold a part of the chip (a 40 ms stall instead of
+// the loop caps' 0.3 s) — NOT to run ahead of late workgroups: beside the dense products of a training loop an auction
+// workgroup (16 waves, the whole register file of a CU) often waits hundreds of microseconds for an EMPTY CU, and
+// phases that went on without those rows left the list solver more than 64 free rows now and then — the dense
+// fallback, 10-20 ms.  Measured (profiles/r5_async_sweep.txt): 64 looks: one region in three at 1.3-2.05 ms per step;
+// 8192 looks: none above 1.1 in 33 regions but one (1.32).
+#define ASG_ASYNC_GRACE 8192
 // wave-uniform values that came out of vector loads: into scalar registers (the loop carries a dozen of them)
 __device__ __forceinline__ double asg_uni_d(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -1577,6 +1586,7 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
     const int pad0 = asg_uni_i(st->pad0);
     const int last_div = (pad0 & 0xff) > 0 ? (pad0 & 0xff) : 1;
     const bool do_arr = ((pad0 >> 8) & 1) != 0;                      // the epsilon = 0 rounds run here too (below)
+    const int grace = (pad0 >> 16) > 0 ? (pad0 >> 16) * 64 : ASG_ASYNC_GRACE;
     // (an epsilon = 0 iteration costs a workgroup ~5 us here, not a launch of the whole chip: 2 x the synchronous cap + 4.
     //  Measured over 40 C3 instances, profiles/r5_async_sweep.txt: 10 / 16 / 24 iterations leave 36.5 / 32.3 / 28.4 free
     //  rows to the list solver, lone solve 2.42 / 2.43 / 2.33 ms)
@@ -1644,11 +1654,11 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
                 const int c = (g == 0) ? ((slot_tag << 16) | (mine & 0xffff)) : asg_ld(&cnt[g]);
                 const int rg = (n - g + G - 1) / G;
                 // a slot of another phase: all of its rows (its workgroup is about to report).  A slot NEVER written (0
-                // since the init step): its workgroup has not started — all of its rows for the first 64 looks (every
-                // workgroup of a grid that fits the chip starts within microseconds), nothing afterwards: when two such
-                // grids from different streams each hold a part of the chip, neither may wait for workgroups that
-                // cannot start before the other one has finished (they join whatever phase is on when they do start)
-                tot += ((c >> 16) == slot_tag) ? (c & 0xffff) : ((c != 0 || it < 64) ? rg : 0);
+                // since the init step): its workgroup has not started — all of its rows for the first ASG_ASYNC_GRACE
+                // looks, nothing afterwards: when two chip-sized grids from different streams each hold a part of the
+                // chip, neither may wait for ever for workgroups that cannot start before the other one has finished
+                // (they join whatever phase is on when they do start)
+                tot += ((c >> 16) == slot_tag) ? (c & 0xffff) : ((c != 0 || it < grace) ? rg : 0);
             }
             tot = wave_sum_i(tot);
             if (lane == 0) {
@@ -1930,7 +1940,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
         h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
         h.fr_min = ~0ull; h.fr_max = 0ull;
         h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early;
-        h.tag = 1; h.pad0 = P.async_last_div | ((P.async_auction >= 2 ? 1 : 0) << 8);
+        h.tag = 1; h.pad0 = (P.async_last_div & 0xff) | ((P.async_auction >= 2 ? 1 : 0) << 8) | ((P.async_last_div >> 8) << 16);   // (bits 16+: experiment — grace of unstarted workgroups / 64)
         { int rb = 1; while ((1 << rb) <= n) ++rb; h.rb = rb; }     // row ids 0 .. n-1 and the all-ones "none"
         hipLaunchKernelGGL(asg_init, dim3(1), dim3(64), 0, s, asg_carve((char*)ws + (size_t)b * L.stride, n), h);
     }

@@ -182,7 +182,7 @@ def test_async_auction_gives_the_synchronous_rounds_permutation(n, kind):
 def test_concurrent_lone_solves_on_many_streams_do_not_stall_each_other():
     """Six host threads, six streams, lone solves at the same time: every solve launches an auction grid as large as the
     chip, so their workgroups can only be resident in part — none may wait for workgroups that cannot start before another
-    grid has finished (asg_auction: a slot never written stops counting after the controller's first 64 looks).  Same
+    grid has finished for long (asg_auction: a slot never written stops counting after ASG_ASYNC_GRACE looks of the controller, ~40 ms).  Same
     permutations as one after the other, and no solve anywhere near the loop caps (0.3 s)."""
     import concurrent.futures as cf
     import time
