@@ -168,7 +168,14 @@ def _sk_windows(fn, iters, nwin):
     """nwin timed windows of `iters` iterations each (HIP events on the current stream), after a first-touch pass; every
     window with the solver's state after it — a slow window can then be told from a regime switch (the kernels move to
     fp64 exp once the marginal violation nears the fp32 noise floor) or an early stop."""
+    # warm-up: first touch of every buffer, then at least 150 ms of the same work — the leg starts behind host-side input
+    # generation during which the chip idles, and the first tens of milliseconds after an idle stretch run at a fraction
+    # of the rate (power state): the driver's round-4 figure of 4.7 k it/s at C5 was ONE 200-iteration window right
+    # there, and a first window at 2.4 k it/s next to six at 10.3 k was seen again in round 5 before this warm-up existed
     fn(20); torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.15:
+        fn(iters); torch.cuda.synchronize()
     out = []
     for _ in range(nwin):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
