@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round-5 A/B of the exact solver (run through gpurun): tools/asg_async_ab.py over 40 instances, the solver tests, then bench.py
+# regions for two settings of cfm_assign_set_async, interleaved.  Output: gpurun_out/r5_async_ab*.txt (kept in profiles/r5_async_sweep.txt).
 cd /root/repo
 NINST=16 BENCH_POOL=1 ASYNC_LIST="1,16,4;2,16,4;0,16,4;2,16,4" timeout 400 python tools/asg_async_ab.py 1 4 2>&1 | grep -v amdgpu.ids > gpurun_out/r5_async_ab8.txt
 timeout 900 python -m pytest tests/test_gpu_assign_batch.py tests/test_gpu_kernels.py tests/test_gpu_fullsize.py tests/test_gpu_prefetch.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -3 >> gpurun_out/r5_async_ab8.txt

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round-5 A/B of bench.py settings (run through gpurun): the epsilon reduction factor of the asynchronous auction in the pipelined
+# loop, three interleaved passes.  Output kept in profiles/r5_async_sweep.txt.
 cd /root/repo
 rm -f gpurun_out/r5_theta.txt
 run() { timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs --repeats 9 "$@" 2>/dev/null | tail -1 | python -c "
