@@ -74,6 +74,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <atomic>
 
 enum { MODE_UMIN0 = 0,     // u_i = min_j c_ij, cost range, key / bid state reset          (f1)
        MODE_INITRED = 1,   // initial prices: p_j = max_i (u_i - c_ij), straight into the keys (f1)
@@ -149,6 +150,10 @@ extern "C" void cfm_assign_set_async(int on, int blocks, int last_div) {
     g_params.async_auction = on < 0 ? 0 : (on > 2 ? 2 : on);        // 1: the epsilon > 0 phases; 2: the epsilon = 0 rounds too
     if (blocks >= 0) g_params.async_blocks = blocks;
     if (last_div > 0) g_params.async_last_div = last_div;      // (bits 8+: see asg_run)
+}
+extern "C" void cfm_assign_get_async(int* out3) {
+    std::lock_guard<std::mutex> lk(g_params_mu);
+    out3[0] = g_params.async_auction; out3[1] = g_params.async_blocks; out3[2] = g_params.async_last_div;
 }
 extern "C" void cfm_assign_set_small(int on) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.small = on > 0 ? on : 0; }
 extern "C" void cfm_assign_set_bulk(int bulk, int min_n) {
@@ -1760,6 +1765,7 @@ struct AsgGraph {
     hipGraphExec_t exec[PRG_COUNT] = {nullptr, nullptr};
     hipStream_t stream = nullptr; int disabled = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    int ev_blocking = -1;          // how ev[] were created (this thread's g_blocking_sync at the time)
 };
 // A host thread keeps the programs of its last few (workspace, size, batch, stream) combinations: a training loop
 // alternates between a few of them (groups of couplings and a shorter last group, single solves), and capturing +
@@ -1769,6 +1775,24 @@ static thread_local AsgGraph g_graphs[ASG_GRAPH_SLOTS];
 static thread_local unsigned g_graph_use[ASG_GRAPH_SLOTS];
 static thread_local unsigned g_graph_clock = 0;
 static thread_local int g_graph_off = 0;      // this thread's streams cannot be captured: plain launches from now on
+// The host wait of a solve (ONE hipEventSynchronize per solve since round 5): with HIP's default an event wait SPINS on
+// a host core; a coupling worker of a training loop (cfm_amd.prefetch: 3 per rank, 8 ranks per node) would burn a core
+// each for the whole solve.  cfm_set_blocking_sync(1) makes this THREAD's solver events hipEventBlockingSync: the wait
+// sleeps in the kernel driver and is woken by the completion interrupt (tens of microseconds later than a spin would
+// notice — once per job of several couplings, not per step).  Thread-local: a latency-critical lone solve on the
+// caller's own thread keeps the spin.
+static thread_local int g_blocking_sync = 0;
+extern "C" void cfm_set_blocking_sync(int on) { g_blocking_sync = on ? 1 : 0; }
+static hipError_t asg_events(AsgGraph& G) {
+    if (G.ev_blocking != g_blocking_sync) {
+        for (int q = 0; q < 2; ++q) if (G.ev[q]) { (void)hipEventDestroy(G.ev[q]); G.ev[q] = nullptr; }
+        G.ev_blocking = g_blocking_sync;
+    }
+    const unsigned flags = hipEventDisableTiming | (g_blocking_sync ? hipEventBlockingSync : 0u);
+    for (int q = 0; q < 2; ++q)
+        if (!G.ev[q]) { hipError_t e = hipEventCreateWithFlags(&G.ev[q], flags); if (e != hipSuccess) return e; }
+    return hipSuccess;
+}
 static AsgGraph& asg_graph_slot(void* ws, int n, int nb, hipStream_t s) {
     int hit = -1, lru = 0;
     for (int q = 0; q < ASG_GRAPH_SLOTS; ++q) {
@@ -1807,9 +1831,40 @@ static int asg_raise_lds() {
 // must not share it
 static thread_local int* g_pinned = nullptr;
 static thread_local int g_small_last[16];      // status block of this thread's last one-workgroup solve (phase times)
-static thread_local int g_fallback[2];         // tuning aid: {solves of this thread that the dense state machine had to redo, last device error code}
-extern "C" void cfm_assign_debug_fallback(int* out2) { out2[0] = g_fallback[0]; out2[1] = g_fallback[1]; }
+// tuning aid: {solves of this PROCESS that the dense state machine had to redo, last device error code} — process-wide
+// since round 6: the couplings of a training loop run on prefetch worker threads, and the bench line reports the count
+struct AsgFallback {
+    std::atomic<int> v[2];
+    struct Ref { std::atomic<int>& a; Ref& operator=(int x) { a.store(x, std::memory_order_relaxed); return *this; }
+                 Ref& operator++() { a.fetch_add(1, std::memory_order_relaxed); return *this; } };
+    Ref operator[](int q) { return Ref{v[q]}; }
+};
+static AsgFallback g_fallback;
+extern "C" void cfm_assign_debug_fallback(int* out2) { out2[0] = g_fallback.v[0].load(); out2[1] = g_fallback.v[1].load(); }
 extern "C" void cfm_assign_debug_small(int* out16) { for (int q = 0; q < 16; ++q) out16[q] = g_small_last[q]; }
+
+// CUs the stream may use: the device's count, or the population of its CU mask (hipExtStreamCreateWithCUMask streams).
+// Cached per host thread for its last few streams (the query is a host-side lookup, but it sits on every solve's path).
+static int asg_stream_cus(hipStream_t s) {
+    static int cus[CFM_MAX_DEVICES];
+    const int di = cfm_device_index();
+    int& c = cus[di];
+    if (c <= 0 && (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, di) != hipSuccess || c <= 0)) c = 256;
+    if (!s) return c;
+    static thread_local struct { hipStream_t s; int dev, n; } cache[4];
+    static thread_local unsigned clock_ = 0;
+    for (auto& e : cache) if (e.s == s && e.dev == di && e.n > 0) return e.n;
+    uint32_t mask[16] = {0};
+    int n = c;
+    if (hipExtStreamGetCUMask(s, 16, mask) == hipSuccess) {
+        int pop = 0;
+        for (int q = 0; q < 16; ++q) pop += __builtin_popcount(mask[q]);
+        if (pop > 0 && pop < n) n = pop;
+    } else (void)hipGetLastError();
+    auto& e = cache[clock_++ & 3];
+    e.s = s; e.dev = di; e.n = n;
+    return n;
+}
 
 struct AsgLaunch {
     AsgWs w; int n, blocks, blocks_build, nb; size_t stride; size_t lds_step, lds_build, lds_solve; int sparse; hipStream_t s;
@@ -1923,9 +1978,10 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     if ((long)L.blocks_auction * ASG_BQ < n) L.blocks_auction = (n + ASG_BQ - 1) / ASG_BQ;      // (a workgroup takes at most ASG_BQ rows)
     {   // its workgroups (16 waves, the whole register file of a CU each) must be able to be resident TOGETHER: a phase ends
         // when the whole grid has reported, and a workgroup that has not started counts as "all rows unmatched"
-        static int cus[CFM_MAX_DEVICES];
-        int& c = cus[cfm_device_index()];
-        if (c <= 0 && (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, cfm_device_index()) != hipSuccess || c <= 0)) c = 256;
+        // — on the CUs THIS STREAM may use: a CU-masked stream (cfm_stream_create_cu_mask, ChipPartition) gives the grid
+        // fewer than the device has, and workgroups that cannot start before others exit would be counted as "all rows
+        // unmatched" for the whole grace (~40 ms) and then left out: > 64 free rows, the dense fallback
+        int c = asg_stream_cus(s);
         if ((long)L.blocks_auction * nb > c) L.blocks_auction = c / nb > 0 ? c / nb : 1;
     }
     L.async_auction = (P.async_auction && n >= 1024 && n <= WIDE_PLDS_MAX && (raised & 1) && (long)L.blocks_auction * ASG_BQ >= n) ? P.async_auction : 0;
@@ -1973,8 +2029,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
             if (e == hipSuccess && graph) e = hipGraphInstantiate(&G.exec[prg], graph, nullptr, nullptr, 0);
             if (graph) (void)hipGraphDestroy(graph);
         }
-        for (int q = 0; q < 2 && e == hipSuccess; ++q)
-            if (!G.ev[q]) e = hipEventCreateWithFlags(&G.ev[q], hipEventDisableTiming);
+        if (e == hipSuccess) e = asg_events(G);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
@@ -1984,8 +2039,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
             G.sparse = L.sparse + 2 * L.async_auction; G.stream = s;
         }
     }
-    if (!use_graph) for (int q = 0; q < 2; ++q)
-        if (!G.ev[q]) { rc = cfm_hip(hipEventCreateWithFlags(&G.ev[q], hipEventDisableTiming)); if (rc) return rc; }
+    rc = cfm_hip(asg_events(G)); if (rc) return rc;      // (also: the thread's blocking-sync choice changed since they were made)
 
     long launched = 0;
     auto run = [&](int prg) -> int {

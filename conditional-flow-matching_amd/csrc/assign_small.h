@@ -176,8 +176,11 @@ __device__ __forceinline__ void sma_scan(SmaShared& sh, const float4& c, int row
     const unsigned dn = *reinterpret_cast<const unsigned*>(&sh.done[4 * lane]);
     const short4 cr = *reinterpret_cast<const short4*>(&sh.colrow[4 * lane]);      // (not behind the reduction: one LDS round trip less)
     double d[4] = {da.x, da.y, db.x, db.y};
-    const double nd[4] = {base + ((sma_c(c.x, mcs, S) + pa.x) - ur), base + ((sma_c(c.y, mcs, S) + pa.y) - ur),
-                          base + ((sma_c(c.z, mcs, S) + pb.x) - ur), base + ((sma_c(c.w, mcs, S) + pb.y) - ur)};
+    // (reduced costs are >= 0 up to rounding: after a dual update a label can come out a few ulps below zero when
+    //  base == 0 on tied instances — sma_wave_min_pos orders BIT PATTERNS, where a negative double sorts above +inf:
+    //  clamped here, exactly as the chip-wide relax rounds clamp theirs)
+    const double nd[4] = {base + fmax((sma_c(c.x, mcs, S) + pa.x) - ur, 0.0), base + fmax((sma_c(c.y, mcs, S) + pa.y) - ur, 0.0),
+                          base + fmax((sma_c(c.z, mcs, S) + pb.x) - ur, 0.0), base + fmax((sma_c(c.w, mcs, S) + pb.y) - ur, 0.0)};
     double b1 = INFINITY; int k1 = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -86,7 +86,7 @@ struct GldsDma {
         }
     }
     static __device__ __forceinline__ void dma(unsigned off, const float* base, unsigned ldsaddr) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(ldsaddr) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(ldsaddr) : "memory", "m0");
     }
     // stage `st` <- [k0, k0 + GL_BK) of both operands; Ak = A + k0, Bk = B + k0 (uniform)
     __device__ __forceinline__ void issue(const float* Ak, const float* Bk, int st) const {

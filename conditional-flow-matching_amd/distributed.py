@@ -35,15 +35,19 @@ def shard_seed(base, rank):
     return int(base) + int(rank)
 
 
-def all_gather_samples(x, direct=None):
+def all_gather_samples(x, direct=None, force=False):
     """[B,d] per rank -> [world*B, d] on every rank (identity at world=1).
+
+    ``force=True``: with an initialised process group of ONE rank the collective (or, ``direct``, one send + one
+    receive to the rank itself) is issued anyway instead of returning ``x`` — the N > 1 code on the real backend of a
+    one-GPU box (tests/test_gpu_rccl_world1.py).
 
     Default: one RCCL all-gather.  ``direct=True`` (or CFM_ALLGATHER=direct): the fully connected exchange SURVEY
     8(e) describes — every rank posts world-1 sends of its block and world-1 receives into the output in one
     batch, so each of the 7 xGMI links of an MI355X carries exactly one block each way instead of a ring relaying
     every block over one link.  Which one is faster on an 8-GPU node is not measured here (one GPU per box);
     both give the same bytes (tests/test_distributed_gloo.py runs both over gloo)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return x
     world, rank = dist.get_world_size(), dist.get_rank()
     x = x.contiguous()
@@ -54,6 +58,11 @@ def all_gather_samples(x, direct=None):
         dist.all_gather_into_tensor(out, x)
         return out
     B = x.shape[0]
+    if world == 1:                                 # (forced) the exchange with the only peer there is: this rank
+        ops = [dist.P2POp(dist.isend, x, rank), dist.P2POp(dist.irecv, out[:B], rank)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return out
     out[rank * B:(rank + 1) * B].copy_(x)
     ops = []
     for k in range(1, world):                      # peer order staggered by rank: no two ranks start on the same link

@@ -675,35 +675,43 @@ class OTPlanSampler:
         # slice, in row order (np.random.choice draws one double per call, ref:244).
         rows = torch.arange(n, dtype=torch.int64, device=dev)
         chain = [rows]
-        for t, (kind, sol, M) in enumerate(sols):
-            # get_map's diagnostics per slice (ref:88-96, called at ref:233): a non-finite plan is reported and
-            # np.random.choice raises on it (ref:244); a plan without mass reverts to the uniform plan.  One small
-            # device reduction + read-back per entropic slice (exact slices have neither case).
-            uniform = False
+        # get_map's diagnostics (ref:88-96; the reference calls get_map for every slice before it draws, ref:233): a
+        # non-finite plan is reported and np.random.choice raises on it (ref:244); a plan without mass reverts to the
+        # uniform plan.  ONE small device reduction per entropic slice, ONE read-back for all slices, before the chain of
+        # draws starts (exact slices have neither case).  A potential-form ("dense") slice cannot lose its mass while its
+        # potentials are finite: the row update of the log-domain loop normalises every row to 1 / n by construction —
+        # its check is the finiteness of f and g.
+        diag = []
+        for kind, sol, M in sols:
             if kind == "plan":
-                finite = bool(torch.isfinite(sol).all())
-                total = float(sol.sum()) if finite else float("nan")
-                if not finite:
-                    print("ERROR: p is not finite")
-                    print(sol)
-                    print("Cost mean, max", M.mean(), M.max())
-                    print(X[:, t], X[:, t + 1])
-                    raise ValueError("probabilities contain NaN")
-                uniform = abs(total) < 1e-8
+                diag.append(torch.stack([torch.isfinite(sol).all().double(), torch.nan_to_num(sol, nan=0.0, posinf=0.0, neginf=0.0).sum()]))
             elif kind == "dense":
-                if not bool(torch.isfinite(sol.f).all() and torch.isfinite(sol.g).all()):
-                    print("ERROR: p is not finite")
-                    print("Cost mean, max", M.mean(), M.max())
-                    print(X[:, t], X[:, t + 1])
-                    raise ValueError("probabilities contain NaN")
-            if uniform:
+                diag.append(torch.stack([(torch.isfinite(sol.f).all() & torch.isfinite(sol.g).all()).double(),
+                                         torch.ones((), dtype=torch.float64, device=dev)]))
+        diag = torch.stack(diag).cpu().numpy() if diag else np.zeros((0, 2))
+        sols = list(sols)
+        q = 0
+        for t, (kind, sol, M) in enumerate(sols):
+            if kind == "perm":
+                continue
+            finite, total = bool(diag[q, 0]), float(diag[q, 1]); q += 1
+            if not finite:
+                print("ERROR: p is not finite")
+                if kind == "plan":
+                    print(sol)
+                print("Cost mean, max", M.mean(), M.max())
+                print(X[:, t], X[:, t + 1])
+                raise ValueError("probabilities contain NaN")
+            if abs(total) < 1e-8:
                 if self.warn:
                     warnings.warn("Numerical errors in OT plan, reverting to uniform plan.")
-                sol = torch.full(tuple(M.shape), 1.0 / M.numel(), dtype=torch.float64, device=dev)   # ref:96
-            elif kind == "plan":
-                # a visited row without mass: pi[i] / pi[i].sum() is NaN and np.random.choice raises (ref:244)
-                if bool((sol.sum(1)[rows] <= 0).any()):
-                    raise ValueError("probabilities contain NaN")
+                sols[t] = ("plan", torch.full(tuple(M.shape), 1.0 / M.numel(), dtype=torch.float64, device=dev), M)   # ref:96
+        massless = torch.zeros((), dtype=torch.bool, device=dev)
+        for t, (kind, sol, M) in enumerate(sols):
+            if kind == "plan":
+                # a visited row without mass: pi[i] / pi[i].sum() is NaN and np.random.choice raises (ref:244) — the flag
+                # stays on the device and is read once, behind the last slice (the draws of a failing call are discarded)
+                massless = massless | (sol.sum(1)[rows] <= 0).any()
             u = _u01_to_device(np.random.random_sample(n), dev)
             if kind == "perm":
                 # a permutation plan: row i has the single nonzero pi[i, perm[i]] (the draw is consumed)
@@ -714,6 +722,8 @@ class OTPlanSampler:
                 j = sample_rows_pi(sol.contiguous(), rows, u)
             chain.append(j)
             rows = j
+        if bool(massless):
+            raise ValueError("probabilities contain NaN")
         idx = torch.stack(chain).cpu().numpy()              # [times, n]: the ONE device-to-host copy of the indices
         Xh = np.asarray(X.detach().cpu() if isinstance(X, torch.Tensor) else X)
         return np.stack([Xh[:, t][idx[t]] for t in range(times)], axis=1)

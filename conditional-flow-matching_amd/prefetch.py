@@ -22,15 +22,19 @@ class CouplingPrefetcher:
     """``submit(x0, x1)`` -> handle; ``handle.result()`` -> the tensors, ready for the caller's
     current stream.  ``workers`` couplings can be in flight at once."""
 
-    def __init__(self, flow_matcher, device=None, workers=1, partition=None, priority=0):
+    def __init__(self, flow_matcher, device=None, workers=1, partition=None, priority=0, blocking_sync=True):
         """partition: a ``cfm_amd.streams.ChipPartition`` — every worker then owns TWO streams: one on the partition's
         dense CU subset (cost matrix, sampling, x_t / u_t) and one on its solver subset, onto which the exact
         solver's launches are redirected (``streams.solver_stream``); run the model step on
         ``partition.dense_stream()`` too and the solver's rounds no longer wait for slots the dense products hold.
-        priority: HIP stream priority of the workers' streams when no partition is given (-1 = high)."""
+        priority: HIP stream priority of the workers' streams when no partition is given (-1 = high).
+        blocking_sync: the workers' host waits for the exact solver (one per job) sleep in the driver
+        (``cfm_set_blocking_sync``) instead of spinning on a host core each — 8 ranks x 3 workers would otherwise keep
+        24 cores busy doing nothing."""
         self.fm = flow_matcher
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.partition, self.priority = partition, int(priority)
+        self.blocking_sync = bool(blocking_sync)
         self.workers = max(1, int(workers))
         self._tls = threading.local()
         self._pool = _cf.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="cfm-coupling")
@@ -39,6 +43,8 @@ class CouplingPrefetcher:
         s = getattr(self._tls, "stream", None)
         if s is None:
             torch.cuda.set_device(self.device)
+            from . import _lib
+            _lib.load().cfm_set_blocking_sync(1 if self.blocking_sync else 0)      # thread-local: this worker's waits
             if self.partition is not None:
                 s = self._tls.stream = self.partition.dense_stream()
                 self._tls.solver = self.partition.solver_stream()

@@ -32,7 +32,11 @@ from .models import MLP
 
 
 class RegressionStep:
-    def __init__(self, model, optimizer):
+    def __init__(self, model, optimizer, data_parallel=None):
+        """data_parallel: None — the bucketed gradient all-reduce runs iff torch.distributed is initialised with more than
+        one rank; True — whenever a process group exists, also with ONE rank (the N > 1 composition — communication
+        stream, per-layer events, grad_scale — on the real backend of a one-GPU box); False — never."""
+        self.data_parallel = data_parallel
         net = model.module if hasattr(model, "module") and isinstance(model.module, MLP) else model
         if not isinstance(net, MLP):
             raise TypeError("RegressionStep drives a cfm_amd.MLP vector field")
@@ -124,8 +128,9 @@ class RegressionStep:
 
     def __call__(self, t, xt, ut):
         import torch.distributed as dist
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if world <= 1:
+        have_pg = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if have_pg else 1
+        if self.data_parallel is False or not have_pg or (world <= 1 and not self.data_parallel):
             loss = self.backward_only(t, xt, ut)
             self.opt.step()
             return loss

@@ -1,6 +1,8 @@
 """GPU: cfm_assign_exact_batch_f32 — several assignment problems of one size in one chain of launches.  Every row of the
 result must be what the single solve returns (same kernels, same per-problem state machine) and SciPy's optimum."""
 import numpy as np
+import ctypes
+
 import pytest
 import torch
 
@@ -155,9 +157,11 @@ def test_async_auction_gives_the_synchronous_rounds_permutation(n, kind):
         for _ in range(3):
             a = torch.randn(n, d, generator=g).to(dev); b = (torch.randn(n, d, generator=g) * 0.7 + 0.3).to(dev)
             Ms.append(ot.cost_matrix(a, b))
+    saved = (ctypes.c_int * 3)(); lib.cfm_assign_get_async(saved)
+    assert saved[0] == 2, "the shipped default is mode 2 (every bid in the one auction launch)"
     try:
         res = {}
-        for on in (0, 1):
+        for on in (0, 1, 2):            # 2 = the shipped default: epsilon = 0 rounds inside asg_auction, whole solve = the unpolled head
             lib.cfm_assign_set_async(on, -1, -1)
             singles = [ot.assign_exact(M, return_info=True) for M in Ms]
             batch = ot.assign_exact_batch(Ms)
@@ -166,17 +170,21 @@ def test_async_auction_gives_the_synchronous_rounds_permutation(n, kind):
                 if kind != "ties":
                     assert torch.equal(p, pb)
             res[on] = singles
-        for (p0, i0), (p1, i1), M in zip(res[0], res[1], Ms):
-            if kind == "ties":
-                assert i0["total_cost"] == i1["total_cost"]
-            else:
-                assert torch.equal(p0, p1)
+        for on in (1, 2):
+            for (p0, i0), (p1, i1), M in zip(res[0], res[on], Ms):
+                if kind == "ties":
+                    assert i0["total_cost"] == i1["total_cost"]
+                else:
+                    assert torch.equal(p0, p1), on
         # the asynchronous path really ran: ~10-20 launches per solve instead of ~100 (n <= 4096: the list solver closes
         # the solve in one more launch; beyond, the dense forest's launch count depends on the free rows left)
         if n <= 4096:
             assert res[1][0][1]["stats"][6] < res[0][0][1]["stats"][6]
+            assert res[2][0][1]["stats"][6] <= res[1][0][1]["stats"][6]
     finally:
-        lib.cfm_assign_set_async(1, -1, -1)
+        lib.cfm_assign_set_async(saved[0], saved[1], saved[2])      # what it found (the default), not a hard-coded mode
+        now = (ctypes.c_int * 3)(); lib.cfm_assign_get_async(now)
+        assert list(now) == list(saved)
 
 
 def test_concurrent_lone_solves_on_many_streams_do_not_stall_each_other():

@@ -77,3 +77,42 @@ def test_partitioned_prefetcher_equals_synchronous(dev):
             assert torch.equal(x, y)
     assert np.allclose(sums, [float(x.sum()) for x in ref[-1]])
     part.close()
+
+
+@pytest.mark.parametrize("cus_per_xcd", [4, 2])
+def test_c3_sized_solves_on_a_masked_stream_keep_their_speed(dev, cus_per_xcd):
+    """asg_auction needs its whole grid resident at once; on a CU-masked solver stream (32 / 16 CUs) a lone
+    n = 4096 solve used to launch 64 workgroups of which half could not start before the others left — counted as "all
+    rows unmatched" for the grace (~40 ms), then left out (> 64 free rows: the dense fallback).  The grid is now capped at
+    the CUs the stream may use (hipExtStreamGetCUMask): same permutation, no fallback, and nowhere near the 40 ms."""
+    import time
+    import cfm_amd.optimal_transport as ot
+    from cfm_amd import _lib
+    from cfm_amd.streams import ChipPartition, solver_stream
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(41)
+    Ms = []
+    for _ in range(2):
+        x0 = torch.randn(4096, 64, generator=g).to(dev); x1 = (torch.randn(4096, 64, generator=g) * 0.7 + 0.3).to(dev)
+        Ms.append(ot.cost_matrix(x0, x1))
+    ref = [ot.assign_exact(M).cpu() for M in Ms]
+    fb0 = (ctypes.c_int * 2)(); lib.cfm_assign_debug_fallback(fb0)
+    part = ChipPartition(dev, solver_cus_per_xcd=cus_per_xcd)
+    s_solver, s_dense = part.solver_stream(), part.dense_stream()
+    with torch.cuda.stream(s_dense):
+        with solver_stream(s_solver):
+            ot.assign_exact(Ms[0]); ot.assign_exact_batch(Ms)          # one-time costs (workspaces, launch programs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lone = [ot.assign_exact(M).cpu() for M in Ms]
+            t_lone = (time.perf_counter() - t0) / len(Ms)
+            t0 = time.perf_counter()
+            batch = [p.cpu() for p in ot.assign_exact_batch(Ms)]
+            t_batch = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    fb1 = (ctypes.c_int * 2)(); lib.cfm_assign_debug_fallback(fb1)
+    for r, a, b in zip(ref, lone, batch):
+        assert torch.equal(r, a) and torch.equal(r, b)
+    assert fb1[0] == fb0[0], "a masked-stream solve fell back to the dense machine"
+    assert t_lone < 0.03 and t_batch < 0.03, (t_lone, t_batch)      # ~2-8 ms on 16-32 CUs; the stall was >= 40 ms
+    part.close()
