@@ -756,6 +756,8 @@ def main():
                          "asynchronous auction in the batch entry; last_div: its last phase is cut at stop_frac / last_div")
     ap.add_argument("--solver-sched", default="",
                     help="A/B switch (not used by the default run): 'theta,eps0,eps_last,stop_frac' for cfm_assign_set_params (0 / -1 keep)")
+    ap.add_argument("--public-only", action="store_true",
+                    help="diagnostics: ONE headline region, then only the pipelined loop through the public API, --repeats times")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the C1 / C2 / C5 / roofline legs")
     ap.add_argument("--host-cost", action="store_true",
@@ -886,22 +888,22 @@ def main():
     fb_start = fallbacks()[0]
     regions = []
     cpu0, wall0 = time.process_time(), time.perf_counter()
-    for _ in range(max(1, args.repeats)):
+    for _ in range(1 if args.public_only else max(1, args.repeats)):
         el, gathered = timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple, model_step,
                                     draw, pre, args.pipeline, dev, args.group, couple_group, ramp, tail)
         assert gathered is None or gathered.shape[0] == world * B
         regions.append(el)
     # host CPU time of this rank (all threads: the loop + the prefetch workers + the HIP runtime's own) per step, warm-up
     # steps included in the denominator; with spinning event waits every worker in a solve costs a full core
-    host_cpu_ms = (time.process_time() - cpu0) / (max(1, args.repeats) * (args.steps + args.warmup)) * 1e3
-    host_wall_ms = (time.perf_counter() - wall0) / (max(1, args.repeats) * (args.steps + args.warmup)) * 1e3
+    host_cpu_ms = (time.process_time() - cpu0) / (len(regions) * (args.steps + args.warmup)) * 1e3
+    host_wall_ms = (time.perf_counter() - wall0) / (len(regions) * (args.steps + args.warmup)) * 1e3
     fb_headline = fallbacks()[0] - fb_start
     elapsed = float(np.median(regions))
     # the same loop over a region ten times as long (N = 1): what a step costs once the empty pipeline's fill and its
     # drain (a first coupling nothing overlaps: ~2.6 ms of a 20-step region) are amortised.  Reported next to `value`,
     # never instead of it.
     steady = None
-    if pre is not None and world == 1 and not args.no_legs:
+    if pre is not None and world == 1 and not args.no_legs and not args.public_only:
         ks = 10 * args.steps
         long_regions = [timed_region(D, torch.cuda.synchronize, pool, args.warmup, ks, couple, model_step, draw, pre,
                                      args.pipeline, dev, args.group, couple_group, ramp, tail)[0] for _ in range(3)]
@@ -931,7 +933,7 @@ def main():
     # (the host RNG is then consumed inside the calls — on the worker threads in the pipelined loop).  Both are first
     # asserted BIT-EQUAL to the hand-composed couple() / couple_group() the headline schedule runs, from one RNG state.
     public = None
-    if world == 1 and args.pipeline and args.group > 1 and not args.no_legs:
+    if world == 1 and args.pipeline and args.group > 1 and (not args.no_legs or args.public_only):
         def rng_get():
             return np.random.get_state(), torch.get_rng_state(), torch.cuda.get_rng_state(dev)
 
@@ -1030,7 +1032,7 @@ def main():
         "steady_state": steady,
         "value_public_api": public,
     }
-    if world == 1 and not args.no_legs:
+    if world == 1 and not args.no_legs and not args.public_only:
         with torch.cuda.stream(torch.cuda.Stream()):
             out["roofline"] = assign_roofline(dev, pool, lib_, _lib, ot, B)
             out["c1"] = c1_latency(dev)

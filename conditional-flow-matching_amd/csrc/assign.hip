@@ -111,6 +111,7 @@ struct AsgParams {
     int async_blocks;      // ... on this many workgroups per problem in the batch entry (0: the grid of the other kernels)
     int async_last_div;    // ... the last phase is cut at stop_frac / this
     double async_theta;    // ... its epsilon reduction factor (a phase costs it microseconds, not ~15 launches: gentler scaling pays)
+    int radius_pct;        // list solver: per cent of a phase's trees that must have reached a free column before the radius is set (0: the first one)
 };
 
 // Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
@@ -122,7 +123,7 @@ static std::mutex g_params_mu;
 // async_theta: 40 C3 instances (profiles/r5_async_sweep.txt): theta 5 / 4 / 3 / 2.5 / 2: lone solve 2.33 / 2.28 / 2.08 / 1.92 / 1.93 ms — gentler
 // scaling leaves the list solver 15 free rows instead of 27 and shorter searches (1.04 vs 1.56 ms) for 0.1 ms more auction; the
 // sequential step 2.96 -> 2.56 ms (2.47 at theta 2), the pipelined step 1.07 -> 1.01-1.04 on the same box (1.04-1.05 at theta 2).
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 2, 16, 4, 2.5};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 2, 16, 4, 2.5, 0};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
@@ -151,6 +152,7 @@ extern "C" void cfm_assign_set_async(int on, int blocks, int last_div) {
     if (blocks >= 0) g_params.async_blocks = blocks;
     if (last_div > 0) g_params.async_last_div = last_div;      // (bits 8+: see asg_run)
 }
+extern "C" void cfm_assign_set_radius_pct(int pct) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.radius_pct = pct < 0 ? 0 : (pct > 100 ? 100 : pct); }
 extern "C" void cfm_assign_get_async(int* out3) {
     std::lock_guard<std::mutex> lk(g_params_mu);
     out3[0] = g_params.async_auction; out3[1] = g_params.async_blocks; out3[2] = g_params.async_last_div;
@@ -189,6 +191,7 @@ struct AsgState {
     int st_auction_rounds, st_arr_rounds, st_free_after_arr, st_sap_batches;
     int st_sap_row_scans, st_total_row_scans, st_steps, st_dense_fallbacks;
     int st_ms_phases, st_ms_augmented, wide_blocks, st_list_bids;    // st_list_bids: bids served from a row's bid list
+    int sp_radius_pct, pad1;   // list solver: share of a phase's trees that must reach a free column before its radius is set
     long long t_prev;          // time accounting (100 MHz device clock): every control step books the
     long long t_acc[16];       // time since the previous one on the mode that launch ran in
 };
@@ -1995,7 +1998,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
         h.stop_frac = P.stop_frac; h.round_cap = P.round_cap; h.arr_cap = P.arr_cap;
         h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
         h.fr_min = ~0ull; h.fr_max = 0ull;
-        h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early;
+        h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early; h.sp_radius_pct = P.radius_pct;
         h.tag = 1; h.pad0 = (P.async_last_div & 0xff) | ((P.async_auction >= 2 ? 1 : 0) << 8) | ((P.async_last_div >> 8) << 16);   // (bits 16+: experiment — grace of unstarted workgroups / 64)
         { int rb = 1; while ((1 << rb) <= n) ++rb; h.rb = rb; }     // row ids 0 .. n-1 and the all-ones "none"
         hipLaunchKernelGGL(asg_init, dim3(1), dim3(64), 0, s, asg_carve((char*)ws + (size_t)b * L.stride, n), h);

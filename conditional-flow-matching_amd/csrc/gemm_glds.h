@@ -85,8 +85,12 @@ struct GldsDma {
             lb[q] = la[q] + GL_BM * GL_BK * 4;
         }
     }
+    // (m0: the AMDGPU backend RESERVES m0 — it is never allocated to a value, only written immediately in front of the few
+    //  instructions that consume it (LDS-direct loads, movrel, sendmsg, GWS) — and rejects it on a clobber list with
+    //  "reserved registers ... may lead to undefined behaviour"; the kernels built on this engine contain none of those
+    //  consumers: tools/isa_report.py lists every m0 access of the code object, all of them are this asm's)
     static __device__ __forceinline__ void dma(unsigned off, const float* base, unsigned ldsaddr) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(ldsaddr) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(ldsaddr) : "memory");
     }
     // stage `st` <- [k0, k0 + GL_BK) of both operands; Ak = A + k0, Bk = B + k0 (uniform)
     __device__ __forceinline__ void issue(const float* Ak, const float* Bk, int st) const {

@@ -43,7 +43,11 @@ def report(path, extra=()):
         rows.append(dict(kernel=demangle(name)[:84], vgpr=int(g("vgpr_count")), agpr=int(g("agpr_count")),
                          scratch=int(g("private_segment_fixed_size")), spill=int(g("vgpr_spill_count")),
                          lds=int(g("group_segment_fixed_size")), mfma=body.count("v_mfma"),
-                         acc_w=body.count("v_accvgpr_write"), acc_r=body.count("v_accvgpr_read")))
+                         acc_w=body.count("v_accvgpr_write"), acc_r=body.count("v_accvgpr_read"),
+                         # m0 accesses that do NOT sit directly in front of a global_load_lds (gemm_glds.h writes m0 in
+                         # inline assembly without a clobber: any other consumer of m0 in such a kernel would be at risk)
+                         m0_w=len(re.findall(r"s_mov_b32 m0,", body)), m0_dma=len(re.findall(r"global_load_lds_dword", body)),
+                         m0_other=len(re.findall(r"\bm0\b", body)) - len(re.findall(r"s_mov_b32 m0,", body))))
     return rows
 
 
@@ -54,7 +58,7 @@ def main(argv):
         print(f"== {os.path.basename(f)}")
         for r in report(f, extra):
             print(f"  vgpr {r['vgpr']:3d} agpr {r['agpr']:3d} scratch {r['scratch']:4d} spill {r['spill']:3d} lds {r['lds']:6d} "
-                  f"mfma {r['mfma']:4d} acc_w {r['acc_w']:4d} acc_r {r['acc_r']:4d}  {r['kernel']}")
+                  f"mfma {r['mfma']:4d} acc_w {r['acc_w']:4d} acc_r {r['acc_r']:4d} m0 w/dma/other {r['m0_w']}/{r['m0_dma']}/{r['m0_other']}  {r['kernel']}")
 
 
 if __name__ == "__main__":
