@@ -232,7 +232,7 @@ class _OTMixin:
         next steps of a training loop depend on the data only, so a loop can ask for a few steps ahead
         (``cfm_amd.prefetch.CouplingPrefetcher.submit_group`` does it on a side stream)."""
         batches = list(batches)
-        sols = self.ot_sampler._solve_many(batches)
+        sols = self.ot_sampler._solve_many(batches, throughput=True)
         out = []
         for (x0, x1), sol in zip(batches, sols):
             i, j = self.ot_sampler._indices_from_solution(x0, x1, sol)

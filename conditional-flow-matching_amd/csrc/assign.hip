@@ -111,7 +111,6 @@ struct AsgParams {
     int async_blocks;      // ... on this many workgroups per problem in the batch entry (0: the grid of the other kernels)
     int async_last_div;    // ... the last phase is cut at stop_frac / this
     double async_theta;    // ... its epsilon reduction factor (a phase costs it microseconds, not ~15 launches: gentler scaling pays)
-    int radius_pct;        // list solver: per cent of a phase's trees that must have reached a free column before the radius is set (0: the first one)
 };
 
 // Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
@@ -123,7 +122,7 @@ static std::mutex g_params_mu;
 // async_theta: 40 C3 instances (profiles/r5_async_sweep.txt): theta 5 / 4 / 3 / 2.5 / 2: lone solve 2.33 / 2.28 / 2.08 / 1.92 / 1.93 ms — gentler
 // scaling leaves the list solver 15 free rows instead of 27 and shorter searches (1.04 vs 1.56 ms) for 0.1 ms more auction; the
 // sequential step 2.96 -> 2.56 ms (2.47 at theta 2), the pipelined step 1.07 -> 1.01-1.04 on the same box (1.04-1.05 at theta 2).
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 2, 16, 4, 2.5, 0};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 2, 16, 4, 2.5};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
@@ -152,7 +151,6 @@ extern "C" void cfm_assign_set_async(int on, int blocks, int last_div) {
     if (blocks >= 0) g_params.async_blocks = blocks;
     if (last_div > 0) g_params.async_last_div = last_div;      // (bits 8+: see asg_run)
 }
-extern "C" void cfm_assign_set_radius_pct(int pct) { std::lock_guard<std::mutex> lk(g_params_mu); g_params.radius_pct = pct < 0 ? 0 : (pct > 100 ? 100 : pct); }
 extern "C" void cfm_assign_get_async(int* out3) {
     std::lock_guard<std::mutex> lk(g_params_mu);
     out3[0] = g_params.async_auction; out3[1] = g_params.async_blocks; out3[2] = g_params.async_last_div;
@@ -191,25 +189,11 @@ struct AsgState {
     int st_auction_rounds, st_arr_rounds, st_free_after_arr, st_sap_batches;
     int st_sap_row_scans, st_total_row_scans, st_steps, st_dense_fallbacks;
     int st_ms_phases, st_ms_augmented, wide_blocks, st_list_bids;    // st_list_bids: bids served from a row's bid list
-    int sp_radius_pct, pad1;   // list solver: share of a phase's trees that must reach a free column before its radius is set
     long long t_prev;          // time accounting (100 MHz device clock): every control step books the
     long long t_acc[16];       // time since the previous one on the mode that launch ran in
 };
 static_assert(sizeof(AsgState) <= 512, "AsgState has 512 bytes at the head of the workspace");
 static_assert(offsetof(AsgState, arrive) == 128 && offsetof(AsgState, nF) == 256, "AsgState layout");
-
-// Tuning aid, not part of the ABI: microseconds the last solve on `ws` spent in each mode (slots
-// 0-15, index = MODE_*; launch + gap to the next launch).  Slot 16: the bids of the solve that were served from the
-// row's bid list (512 bytes) instead of a row scan — they are part of stats[5].  Slots 17-31 are zero.  Blocking.
-extern "C" int cfm_assign_debug_times(const void* ws, double* us32) {
-    if (!ws || !us32) return CFM_EINVAL;
-    AsgState h;
-    int rc = cfm_hip(hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost));
-    if (rc) return rc;
-    for (int q = 0; q < 16; ++q) { us32[q] = (double)h.t_acc[q] * 0.01; us32[16 + q] = 0.0; }
-    us32[16] = (double)h.st_list_bids;
-    return 0;
-}
 
 // Control of the bid rounds WITHOUT an arrival: a bid round needs no result of its own launch, only the number of
 // bidders of the PREVIOUS round to decide whether the epsilon phase goes on.  Every workgroup therefore takes that
@@ -232,8 +216,30 @@ struct AsgAuc {
     // phase, bit 31: the phases are over), the hand-over flag, and the bid totals the workgroups add when they leave
     alignas(128) int async_word;
     int async_done, async_scans, async_list;
+    alignas(128) int async_claim;      // row groups handed out so far (asg_auction: a workgroup works on the groups it has claimed)
+    int async_adopted;                 // ... of them adopted by a workgroup that already held one (statistics)
 };
 static_assert(sizeof(AsgAuc) <= 512, "AsgAuc has 512 bytes of the workspace");
+
+// Tuning aid, not part of the ABI: microseconds the last solve on `ws` spent in each mode (slots
+// 0-15, index = MODE_*; launch + gap to the next launch).  Slot 16: the bids of the solve that were served from the
+// row's bid list (512 bytes) instead of a row scan — they are part of stats[5].  Slot 17: row groups of the one-launch auction
+// adopted by a workgroup that already held one; slot 18: claims made.  Slots 19-31 are zero.  Blocking.
+extern "C" int cfm_assign_debug_times(const void* ws, double* us32) {
+    if (!ws || !us32) return CFM_EINVAL;
+    AsgState h;
+    int rc = cfm_hip(hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost));
+    if (rc) return rc;
+    for (int q = 0; q < 16; ++q) { us32[q] = (double)h.t_acc[q] * 0.01; us32[16 + q] = 0.0; }
+    us32[16] = (double)h.st_list_bids;
+    AsgAuc a;                                             // (512 + 2048 bytes into the carving: asg_carve)
+    rc = cfm_hip(hipMemcpy(&a, (const char*)ws + 512 + 2048, sizeof(a), hipMemcpyDeviceToHost));
+    if (rc) return rc;
+    us32[17] = (double)a.async_adopted;                   // row groups of the auction adopted by a workgroup that already held one
+    us32[18] = (double)a.async_claim;                     // claims made (>= the groups: late workgroups claim past the end and leave)
+    return 0;
+}
+
 
 // SAP scan list entry arrays (two copies: current / next)
 struct SList {
@@ -689,12 +695,14 @@ __device__ __forceinline__ int wide_bid(gfp M, const AsgWs& w, const double* p_l
 // few per cent of the rows bid in a typical round.  Thread t checks the workgroup's row t (its last bid arrived with the
 // prologue, the owner rows are in LDS), the unmatched rows go into a queue in LDS, and the waves take them from there.
 #define ASG_BQ 256                    // rows per workgroup this path takes (the grid is chosen accordingly)
+// grp / G: the row group this call bids for — rows grp, grp + G, ... (asg_step: its own blockIdx.x of gridDim.x; asg_auction: a
+// group it has claimed, see there)
 __device__ __forceinline__ int wide_bid_queue(gfp M, const AsgWs& w, const double* p_lds, const int* r_lds, int* bq, int* bq_cnt,
-                                              int my_bc, bool stage_p, int n, double eps, int tag, int rb, int rnd) {
+                                              int my_bc, bool stage_p, int n, double eps, int tag, int rb, int rnd, int grp, int G) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool lists = ASG_BL_ON && (w.cl != nullptr);
     int tq = threadIdx.x; asm volatile("" : "+v"(tq));                  // (opaque: formed per call, never carried — and spilled — across the persistent loop of asg_auction)
-    const int i_chk = blockIdx.x + gridDim.x * tq;                      // row t of this workgroup
+    const int i_chk = grp + G * tq;                                     // row t of the group
     if (i_chk < n && threadIdx.x < ASG_BQ && !bid_matched(w, r_lds, stage_p, my_bc, tag, i_chk, rb))
         bq[atomicAdd(bq_cnt, 1)] = i_chk;
     __syncthreads();
@@ -1348,6 +1356,7 @@ __device__ __forceinline__ void step_ctrl(const AsgWs& w, AsgState* st, int mode
         w.auc->ctl[par ^ 1] = C;
         for (int q = 0; q < 4; ++q) asg_st(&w.auc->bidcnt[q], 0);
         asg_st(&w.auc->async_word, 0); w.auc->async_done = 0; w.auc->async_scans = 0; w.auc->async_list = 0;
+        asg_st(&w.auc->async_claim, 0); w.auc->async_adopted = 0;
         st->mode = MODE_AUCTION;
     } else if (mode == MODE_CONVERT || mode == MODE_MS_FINISH) {
         st->mode = asg_ld(&st->next_mode);
@@ -1484,7 +1493,7 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
         }
         __syncthreads();
         __shared__ int bq[ASG_BQ];
-        const int nb = queue ? wide_bid_queue(M, w, p_lds, r_lds, bq, &sh[1], my_bc, stage_p, n, eps, tag, rb, rnd)
+        const int nb = queue ? wide_bid_queue(M, w, p_lds, r_lds, bq, &sh[1], my_bc, stage_p, n, eps, tag, rb, rnd, (int)blockIdx.x, (int)gridDim.x)
                              : wide_bid(M, w, p_lds, r_lds, wave_gid, n_waves, make_int4(pre_bc, pre_bc1, pre_bc2, pre_bc3), pre_e, pre_T, stage_p, n, eps, tag, rb, rnd);
         if (lane == 0 && nb) atomicAdd(&sh[0], nb);
         __syncthreads();
@@ -1561,6 +1570,8 @@ __global__ __launch_bounds__(WT) void asg_step(AsgWs w0, int n_host, int par, si
 // fallback, 10-20 ms.  Measured (profiles/r5_async_sweep.txt): 64 looks: one region in three at 1.3-2.05 ms per step;
 // 8192 looks: none above 1.1 in 33 regions but one (1.32).
 #define ASG_ASYNC_GRACE 8192
+#define ASG_GROUPS_MAX 512     // row groups of an auction grid (= its gridDim.x: <= 512, asg_run)
+#define ASG_ADOPT_AFTER 8      // iterations (~5 us each) after which a running workgroup starts adopting unclaimed groups, one per iteration
 // wave-uniform values that came out of vector loads: into scalar registers (the loop carries a dozen of them)
 __device__ __forceinline__ double asg_uni_d(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -1571,13 +1582,34 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
     const AsgWs w = asg_shift(w0, stride * blockIdx.y);
     __shared__ int sh[12];
     __shared__ int bq[ASG_BQ];
+    __shared__ short grp_list[ASG_GROUPS_MAX];       // the row groups this workgroup works on (claim order)
+    __shared__ int own_val[ASG_GROUPS_MAX];          // its own reports by group (-1: not one of its groups)
+    __shared__ int cst[6];                           // controller state (its lane 0 only): rounds of the phase, rounds in all, epsilon = 0 rounds, the phase's cut
+                                                     // (in LDS, not registers: values only one lane updates inside the persistent loop cost every lane a VGPR)
     AsgState* st = w.st;
     const int n = n_host;
     const AsgHead H = *reinterpret_cast<const AsgHead*>(st);
     if (H.mode != MODE_AUCTION || H.error || w.auc->async_done) return;
     gfp M = ASG_GLOBAL(H.Mptr);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int G = (int)gridDim.x;
+    const int G = (int)gridDim.x;                    // row groups = the grid the host chose; group g = rows g, g + G, ...
+    // ---- claim a row group.  Rows are NOT tied to blockIdx: the workgroups take the groups in the order they START, and a
+    // running workgroup ADOPTS groups nobody has claimed yet (below).  A phase ends when every group has reported, and
+    // with the static mapping of round 5 a workgroup that could not start — beside the dense products of a training loop
+    // a 1024-thread workgroup waits hundreds of microseconds for an empty CU; two or three auction grids from different
+    // streams can each hold a part of the chip and wait for the rest of it — stalled the whole grid: 27 - 30 ms
+    // (the grace) whenever a chip-sized grid of a lone solve met the grids of two prefetch jobs (profiles/
+    // r6_tail_public.txt), and a fat tail of the pipelined step otherwise.  Now nobody waits for a workgroup that
+    // is not running: its rows are somebody else's after ASG_ADOPT_AFTER iterations, and a workgroup that starts
+    // with nothing left to claim exits at once.
+    if (threadIdx.x == 0) sh[8] = __hip_atomic_fetch_add(&w.auc->async_claim, 1, __ATOMIC_RELAXED, ASG_AGENT);
+    for (int g = threadIdx.x; g < ASG_GROUPS_MAX; g += WT) own_val[g] = -1;
+    __syncthreads();
+    const int first = asg_uni_i(sh[8]);
+    if (first >= G) return;                          // every group is taken: nothing to do for this workgroup
+    if (threadIdx.x == 0) grp_list[0] = (short)first;
+    int ng = 1;                                      // (uniform) groups held
+    const bool controller = (first == 0);            // the first workgroup to start moves the phase word
     const int rb = asg_uni_i(H.rb), mb = rb + ASG_RND_BITS;
     const double theta = asg_uni_d(H.theta), eps_last = asg_uni_d(H.eps_last);
     const double stop_frac = H.stop_frac, stop_early = st->stop_early;
@@ -1589,8 +1621,6 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
     // local view of the schedule: phase index, its epsilon (the controller divides the same way) and tag
     int phase = 0; double eps = asg_uni_d(H.eps);
     int scans_tot = 0, lists_tot = 0;
-    // controller state (workgroup 0, thread 0)
-    int c_rounds = 0, c_total_rounds = 0;
     const int pad0 = asg_uni_i(st->pad0);
     const int last_div = (pad0 & 0xff) > 0 ? (pad0 & 0xff) : 1;
     const bool do_arr = ((pad0 >> 8) & 1) != 0;                      // the epsilon = 0 rounds run here too (below)
@@ -1599,14 +1629,27 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
     //  Measured over 40 C3 instances, profiles/r5_async_sweep.txt: 10 / 16 / 24 iterations leave 36.5 / 32.3 / 28.4 free
     //  rows to the list solver, lone solve 2.42 / 2.43 / 2.33 ms)
     const int arr_cap = 2 * asg_uni_i(H.arr_cap) + 4;
-    int arr_it = 0, c_arr_rounds = 0;
-    const int stop_mid = asg_uni_i((int)(fmax(stop_frac, stop_early) * n)), stop_last = asg_uni_i((int)(stop_frac / last_div * n));
-    bool c_last = (eps / theta) < eps_last;
-    int c_stop = c_last ? stop_last : stop_mid;
+    int arr_it = 0;
+    if (threadIdx.x == 0) {      // (cst[4] / cst[5]: the cut of a middle / the last phase, in rows)
+        const int stop_mid = (int)(fmax(stop_frac, stop_early) * n), stop_last = (int)(stop_frac / last_div * n);
+        cst[0] = 0; cst[1] = 0; cst[2] = 0; cst[3] = ((eps / theta) < eps_last) ? stop_last : stop_mid; cst[4] = stop_mid; cst[5] = stop_last;
+    }
     bool idle = false;
+    int step = 0;                                                    // group-steps done (parity of the LDS counters)
     for (int it = 0; it < ASG_ASYNC_ITER_CAP; ++it) {
         if (idle) __builtin_amdgcn_s_sleep(20);                      // nothing to bid for at the last look: poll a little slower
-        // ---- refresh (past the L1: the keys are raised by other CUs' atomics, the phase word by workgroup 0) ----
+        // ---- adopt: groups nobody has claimed after this workgroup's first ASG_ADOPT_AFTER iterations belong to
+        // workgroups that are not running; take one per iteration (thread 0 decides, the barrier below publishes)
+        if (threadIdx.x == 0) {
+            int got = -1;
+            if (it >= ASG_ADOPT_AFTER && ng < ASG_GROUPS_MAX && asg_ld(&w.auc->async_claim) < G) {
+                got = __hip_atomic_fetch_add(&w.auc->async_claim, 1, __ATOMIC_RELAXED, ASG_AGENT);
+                if (got >= G) got = -1;
+            }
+            if (got >= 0) { grp_list[ng] = (short)got; atomicAdd(&w.auc->async_adopted, 1); }
+            sh[9] = got;
+        }
+        // ---- refresh (past the L1: the keys are raised by other CUs' atomics, the phase word by the controller) ----
         const int word0 = asg_ld(&w.auc->async_word);
         unsigned long long kk[2 * KP];
 #pragma unroll
@@ -1615,15 +1658,7 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
             const int jj = j < n ? j : 0;
             kk[2 * q] = asg_ld(&w.key[jj]); kk[2 * q + 1] = asg_ld(&w.key[jj + 1 < n ? jj + 1 : jj]);
         }
-        // (always the queue form of the round: thread t looks at row t of this workgroup — rows b, b + G, ... —, the
-        //  unmatched ones go to the LDS queue and the waves take them from there)
-        int my_bc = -1;
-        if (threadIdx.x < ASG_BQ && (int)(blockIdx.x + G * threadIdx.x) < n) my_bc = asg_ld(&w.bidcol[blockIdx.x + G * threadIdx.x]);
-        // (the waves of a workgroup may have read different words: thread 0's copy decides for all of them, behind the
-        //  barrier; the counters of this iteration live in the slots of its parity — a slow wave may still be reading
-        //  the previous iteration's)
-        int* shc = sh + 4 * (it & 1);
-        if (threadIdx.x == 0) { shc[0] = 0; shc[1] = 0; sh[2] = word0; }
+        if (threadIdx.x == 0) sh[2] = word0;
 #pragma unroll
         for (int q = 0; q < KP; ++q) {
             const int j = threadIdx.x * 2 + 2 * WT * q;
@@ -1631,10 +1666,12 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
                          *reinterpret_cast<int2*>(r_lds + j) = make_int2(asg_key_row(kk[2 * q], rb), asg_key_row(kk[2 * q + 1], rb)); }
         }
         __syncthreads();
+        // (the waves of a workgroup may have read different words: thread 0's copy decides for all of them)
         const int word = asg_uni_i(sh[2]);
+        if (asg_uni_i(sh[9]) >= 0) ++ng;
         if (word < 0) break;                                         // (uniform) the phases are over
         const int wphase = word & 0xffff;
-        while (phase < wphase) { eps = eps / theta; ++phase; }       // a new phase: every row is unassigned again (new tag)
+        while (phase < wphase) { eps = asg_uni_d(eps / theta); ++phase; }       // a new phase: every row is unassigned again (new tag)
         // The epsilon = 0 rounds (bit 30 of the word; phase = the number of epsilon phases run): the same loop with
         // epsilon = 0 and a fresh tag.  A kept pair is exactly tight whatever the timing: the bid b = p'_j + (second' -
         // best'), from a snapshot p' <= p, leaves c_ij + b = second' <= c_ik + p'_k <= c_ik + p_k for every other k if it
@@ -1646,44 +1683,60 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
         const int rnd = arr ? min(arr_it + 1, (1 << ASG_RND_BITS) - 1) : 0;
         arr_it += arr ? 1 : 0;
         const int slot_tag = (phase + 1) | (arr ? 0x4000 : 0);
-        // ---- bid: the synchronous round's body on this snapshot ----
-        const int nb = wide_bid_queue(M, w, p_lds, r_lds, bq, &shc[1], my_bc, true, n, eps_use, tag, rb, rnd);
-        if (lane == 0 && nb) atomicAdd(&shc[0], nb);
-        __syncthreads();
-        const int mine = asg_uni_i(shc[0]);                               // bids of this iteration = rows found unmatched (+ list-served ones above bit 16)
-        idle = ((mine & 0xffff) == 0);
-        scans_tot += mine & 0xffff; lists_tot += mine >> 16;
-        // ---- report; workgroup 0 decides ----
-        if (threadIdx.x == 0) asg_st(&cnt[blockIdx.x], (slot_tag << 16) | (mine & 0xffff));
-        if (blockIdx.x == 0 && wv == 0) {
-            // (the controller's own slot may not have landed yet: it uses `mine` for itself)
+        // ---- bid, group by group: the synchronous round's body (queue form) on this snapshot — thread t looks at row t of
+        // the group, the unmatched ones go to the LDS queue and the waves take them from there; then the group's report
+        int mine_all = 0;
+        for (int q = 0; q < ng; ++q, ++step) {
+            const int grp = asg_uni_i((int)grp_list[q]);
+            int* shc = sh + 4 * (step & 1);        // (this step's counters: a slow wave may still be reading the previous step's)
+            if (threadIdx.x == 0) { shc[0] = 0; shc[1] = 0; }
+            int my_bc = -1;
+            if (threadIdx.x < ASG_BQ && grp + G * (int)threadIdx.x < n) my_bc = asg_ld(&w.bidcol[grp + G * (int)threadIdx.x]);
+            __syncthreads();
+            const int nb = wide_bid_queue(M, w, p_lds, r_lds, bq, &shc[1], my_bc, true, n, eps_use, tag, rb, rnd, grp, G);
+            if (lane == 0 && nb) atomicAdd(&shc[0], nb);
+            __syncthreads();
+            const int mine = asg_uni_i(shc[0]);                      // bids of this step = rows found unmatched (+ list-served ones above bit 16)
+            mine_all += mine & 0xffff;
+            scans_tot += mine & 0xffff; lists_tot += mine >> 16;
+            if (threadIdx.x == 0) {
+                const int rep = (slot_tag << 16) | (mine & 0xffff);
+                asg_st(&cnt[grp], rep);
+                own_val[grp] = rep;
+            }
+        }
+        idle = (mine_all == 0);
+        // ---- the controller decides ----
+        if (controller && wv == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (own_val: written by lane 0 of this wave)
             int tot = 0;
-            for (int g = lane; g < G; g += 64) {
-                const int c = (g == 0) ? ((slot_tag << 16) | (mine & 0xffff)) : asg_ld(&cnt[g]);
+            int ln = lane; asm volatile("" : "+v"(ln));              // (opaque: the slot address is formed here, not carried — and spilled — across the loop)
+            for (int g = ln; g < G; g += 64) {
+                // (the controller's own slots may not have landed yet: it reads its own reports from LDS)
+                const int ov = own_val[g];
+                const int c = ov >= 0 ? ov : asg_ld(&cnt[g]);
                 const int rg = (n - g + G - 1) / G;
                 // a slot of another phase: all of its rows (its workgroup is about to report).  A slot NEVER written (0
-                // since the init step): its workgroup has not started — all of its rows for the first ASG_ASYNC_GRACE
-                // looks, nothing afterwards: when two chip-sized grids from different streams each hold a part of the
-                // chip, neither may wait for ever for workgroups that cannot start before the other one has finished
-                // (they join whatever phase is on when they do start)
+                // since the init step): nobody has reported for the group yet — all of its rows.  Since the groups are
+                // claimed and adopted nobody waits for a workgroup that is not running; the grace of round 5
+                // (ASG_ASYNC_GRACE looks) remains as a safety net only
                 tot += ((c >> 16) == slot_tag) ? (c & 0xffff) : ((c != 0 || it < grace) ? rg : 0);
             }
             tot = wave_sum_i(tot);
             if (lane == 0) {
                 int nw = 0;                                          // 0: go on; != 0: new word
                 if (arr) {
-                    ++c_arr_rounds;
-                    if (tot == 0 || c_arr_rounds >= arr_cap || it + 8 >= ASG_ASYNC_ITER_CAP) nw = (int)0x80000000u | phase;
+                    const int ca = ++cst[2];
+                    if (tot == 0 || ca >= arr_cap || it + 8 >= ASG_ASYNC_ITER_CAP) nw = (int)0x80000000u | phase;
                 } else {
-                ++c_rounds; ++c_total_rounds;
-                if (tot <= c_stop || c_rounds >= round_cap || it + 8 >= ASG_ASYNC_ITER_CAP) {
+                const int cr = ++cst[0]; ++cst[1];
+                if (tot <= cst[3] || cr >= round_cap || it + 8 >= ASG_ASYNC_ITER_CAP) {
                     const double e2 = eps / theta;
                     if (e2 < eps_last || it + 8 >= ASG_ASYNC_ITER_CAP)
                         nw = (do_arr && it + 8 < ASG_ASYNC_ITER_CAP) ? (0x40000000 | (phase + 1)) : ((int)0x80000000u | (phase + 1));
                     else {
-                        nw = phase + 1; c_rounds = 0;
-                        c_last = (e2 / theta) < eps_last;
-                        c_stop = c_last ? stop_last : stop_mid;
+                        nw = phase + 1; cst[0] = 0;
+                        cst[3] = ((e2 / theta) < eps_last) ? cst[5] : cst[4];
                     }
                 }
                 }
@@ -1691,16 +1744,19 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
             }
         }
     }
-    // ---- leave: the bid totals; workgroup 0 hands the state machine over to the epsilon = 0 rounds ----
+    // ---- leave: the bid totals; the controller hands the state machine over to the epsilon = 0 rounds ----
     if (threadIdx.x == 0) {
         if (scans_tot) atomicAdd(&w.auc->async_scans, scans_tot);
         if (lists_tot) atomicAdd(&w.auc->async_list, lists_tot);
-        if (blockIdx.x == 0) {
+        if (controller) {
+            // (groups never claimed — the whole solve ran on fewer workgroups than groups, all adopted — stay closed for
+            //  workgroups that start after the hand-over: they leave on async_done / the mode)
             const int word = asg_ld(&w.auc->async_word);
             if (word >= 0) asg_st(&w.auc->async_word, (int)0x80000000u | (word & 0xffff));   // (left by the cap)
             const int nph = (word & 0xffff);
             // the epsilon = 0 rounds ran here (c_arr_rounds > 0): the next asg_step launch is the CONVERT step; else it
             // is their first round
+            const int c_arr_rounds = cst[2], c_total_rounds = cst[1];
             AucCtl C;
             C.eps = 0.0; C.mode = c_arr_rounds > 0 ? MODE_CONVERT : MODE_ARR; C.tag = (nph % 254) + 1; C.round = 0; C.phase = nph; C.stop = 0;
             C.arr_round = c_arr_rounds;
@@ -1998,7 +2054,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
         h.stop_frac = P.stop_frac; h.round_cap = P.round_cap; h.arr_cap = P.arr_cap;
         h.cmin_bits = 0xffffffffu; h.cmax_bits = 0u; h.minslack_ord = ~0ull;
         h.fr_min = ~0ull; h.fr_max = 0ull;
-        h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early; h.sp_radius_pct = P.radius_pct;
+        h.sparse = L.sparse; h.handoff = P.handoff; h.stop_early = P.stop_early;
         h.tag = 1; h.pad0 = (P.async_last_div & 0xff) | ((P.async_auction >= 2 ? 1 : 0) << 8) | ((P.async_last_div >> 8) << 16);   // (bits 16+: experiment — grace of unstarted workgroups / 64)
         { int rb = 1; while ((1 << rb) <= n) ++rb; h.rb = rb; }     // row ids 0 .. n-1 and the all-ones "none"
         hipLaunchKernelGGL(asg_init, dim3(1), dim3(64), 0, s, asg_carve((char*)ws + (size_t)b * L.stride, n), h);

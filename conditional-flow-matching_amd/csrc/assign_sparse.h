@@ -382,10 +382,10 @@ __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, in
 // every label below it is final.  The tree of a column is read from its slot hint; a stale hint can only make the
 // radius smaller than intended (it stays >= the smallest free-column label), which costs augmentations of this
 // phase, never correctness.
-// need: the radius is only established once this many trees have reached a free column (1 = as soon as one has).  Any
-// radius >= the true one is valid (it only means more work in this phase); waiting for more trees trades a deeper
-// search for fewer phases (each phase restarts its labels from scratch).
-__device__ __forceinline__ double sp_radius(const SpL& L, int nFC, int lane, double dfree, int need) {
+// (Round 6 measured the alternative — establish the radius only once 30 / 50 / 75 / 100 % of the phase's trees have reached
+//  a free column: fewer phases (4.3 -> 3.6) but deeper ones; 30 - 50 %: the same solver time within noise, 75 %+: 7 - 15 ms.
+//  profiles/r6_sched_sweep.txt.  The first tree to arrive sets it.)
+__device__ __forceinline__ double sp_radius(const SpL& L, int nFC, int lane, double dfree) {
     L.tmin[lane] = ~0ull;
     double d = INFINITY; unsigned sl = 0;
     if (lane < nFC) { const int k = L.fcol[lane]; d = L.dist[k]; sl = L.slot[k] & 63u; }
@@ -394,7 +394,6 @@ __device__ __forceinline__ double sp_radius(const SpL& L, int nFC, int lane, dou
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long tm = L.tmin[lane];
     const double mine = (tm == ~0ull) ? -INFINITY : __longlong_as_double((long long)tm);
-    if (__popcll(__ballot(tm != ~0ull)) < need) return dfree;
     double R = sp_wave_max(mine);
     if (!(R > -INFINITY)) R = INFINITY;
     return fmin(dfree, R);
@@ -419,7 +418,7 @@ __device__ __forceinline__ double sp_rfl_d(double v) {
 // others start the bookkeeping (it is published for the NEXT batch: a stale, larger radius is always valid).
 __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& L,
                                               int n, int nS, int nFC, double dfree,
-                                              int lane, int wv, int plcur, double far_thr, long long* fb, int need) {
+                                              int lane, int wv, int plcur, double far_thr, long long* fb) {
 #ifdef SP_PROFILE
     long long tl = clock64();
 #endif
@@ -504,7 +503,7 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
     sp_sync();
     FB_TICK(2);
     if (swv == SP_NW - 1 && L.ri[SP_RI_FREECHG]) {              // (free-column labels change a few times per phase)
-        const double dnew = sp_radius(L, nFC, lane, dfree, need);
+        const double dnew = sp_radius(L, nFC, lane, dfree);
         if (lane == 0) { L.rd[SP_RD_DFREE] = dnew; L.ri[SP_RI_FREECHG] = 0; }
     }
     FB_TICK(3);
@@ -670,7 +669,6 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
     const int n = st->n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SpL L = sp_carve(lds, n);
-    const int radius_pct = st->sp_radius_pct;
     int nFC = st->nFC, nFree = st->nF;
     int err = (nFree > SP_ROOTS || nFC != nFree) ? 9 : 0;
     for (int k = tid; k < n; k += SP_T) {
@@ -689,8 +687,6 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
     while (nFree > 0 && !err) {
         const int nR = nFree;                 // every free row is a root of this phase (slot s <-> rrow[s])
         ++phases;
-        // trees that must have reached a free column before the phase's radius is established (see sp_radius)
-        int need = (nR * radius_pct + 99) / 100; need = need < 1 ? 1 : (need > nR ? nR : need);
         for (int k = tid; k < n; k += SP_T) {
             L.dist[k] = INFINITY; L.pkey[k] = SP_NOKEY; L.ddone[k] = 0; L.inl[k] = 0; L.slot[k] = 0;
         }
@@ -730,7 +726,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
             if (guard > 8 * n + 64) { err = 6; break; }
             if (nS > 0) {
                 if (!any_dense) {
-                    sp_fast_batch(M, w, L, n, nS, nFC, dfree, lane, wv, plcur, far_thr, fb, need);
+                    sp_fast_batch(M, w, L, n, nS, nFC, dfree, lane, wv, plcur, far_thr, fb);
                 } else {
                     for (int t = wv; t < nS; t += SP_NW) {
                         const double b = L.lbase[t];
@@ -738,7 +734,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                     }
                     sp_sync();
                     if (wv == SP_NW - 1 && L.ri[SP_RI_FREECHG]) {
-                        const double dnew = sp_radius(L, nFC, lane, dfree, need);
+                        const double dnew = sp_radius(L, nFC, lane, dfree);
                         if (lane == 0) { L.rd[SP_RD_DFREE] = dnew; L.ri[SP_RI_FREECHG] = 0; }
                     }
                 }

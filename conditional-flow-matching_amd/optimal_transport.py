@@ -613,17 +613,23 @@ class OTPlanSampler:
             take_rows(y1, j) if y1 is not None else None,
         )
 
-    def _solve_many(self, pairs, workers=3):
+    def _solve_many(self, pairs, workers=3, throughput=False):
         """Solve independent couplings together: exact couplings of one square size as ONE batch of the solver
         (``assign_exact_batch``), everything else concurrently with one host thread + one HIP stream per worker.
-        Returns the ``_solve`` results in order, usable on the caller's stream."""
+        Returns the ``_solve`` results in order, usable on the caller's stream.
+        throughput: the caller couples ahead of a training loop (``sample_location_and_conditional_flow_group``): also a
+        SINGLE exact coupling then goes through the batch entry, i.e. on the throughput grid (<= 64 workgroups) instead of
+        the chip-wide grid of a latency-critical lone solve — a chip-sized persistent auction grid beside the grids of two
+        other prefetch jobs was the 27 - 30 ms stall of round 5's public-API loop (profiles/r6_tail_public.txt)."""
         import concurrent.futures as cf
         import threading
         dev = _lib.require_gpu()
-        if len(pairs) <= 1 or workers <= 1:
+        n0 = pairs[0][0].shape[0] if pairs else 0
+        one_batch = (self.method == "exact" and n0 > 256 and
+                     all(a.shape[0] == n0 and b.shape[0] == n0 for a, b in pairs))
+        if (len(pairs) <= 1 or workers <= 1) and not (throughput and one_batch and len(pairs) == 1):
             return [self._solve(a, b) for a, b in pairs]
-        n0 = pairs[0][0].shape[0]
-        if self.method == "exact" and n0 > 256 and all(a.shape[0] == n0 and b.shape[0] == n0 for a, b in pairs):
+        if one_batch:
             # equal, square sizes beyond the one-workgroup solver: the assignment problems share ONE chain of launches
             # (decided from the shapes: the other cases build their cost matrices inside the workers, once)
             Ms = [self._prepare(a, b)[1] for a, b in pairs]

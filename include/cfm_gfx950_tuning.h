@@ -34,7 +34,6 @@ void cfm_assign_set_bulk(int bulk, int min_n);   /* launches enqueued before the
  * stream may use (CU-masked streams); a grid that cannot hold 1/256 of the rows per workgroup falls back to on = 0. */
 void cfm_assign_set_async(int on, int blocks, int last_div);
 void cfm_assign_get_async(int* out3);            /* {on, blocks, last_div} as set (tests restore what they changed) */
-void cfm_assign_set_radius_pct(int pct);         /* list solver: per cent of a phase's trees that must have reached a free column before the phase's radius is set (0: the first) */
 void cfm_assign_set_small(int on);               /* 0: problems of n <= 256 take the chip-wide machine too */
 void cfm_set_blocking_sync(int on);              /* THIS host thread's solver waits: 1 = sleep in the driver (hipEventBlockingSync) instead of spinning on a core; cfm_amd.prefetch sets it for its worker threads */
 void cfm_ode_set_fused(int on);                  /* 0: layer-per-kernel ODE stages instead of the fused small-field drivers */

@@ -219,5 +219,7 @@ def test_concurrent_lone_solves_on_many_streams_do_not_stall_each_other():
         res = list(pool.map(work, range(6)))
     for q, (outs, dt) in enumerate(res):
         assert all(torch.equal(o, want[q]) for o in outs), q
-        assert dt < 0.1, (q, dt)            # a stalled auction would sit in its loop cap for ~0.3 s; a solve takes ~2 ms alone
+        # six chip-sized grids at once: a workgroup of one grid that cannot start has its rows adopted by the running ones
+        # (round 6) — the mutual wait of round 5 cost the grace, ~30 ms per solve; a solve takes ~1.5 ms alone
+        assert dt < 0.025, (q, dt)
     print("concurrent lone solves, s per solve and thread:", [round(dt, 4) for _, dt in res])

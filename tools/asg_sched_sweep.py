@@ -2,7 +2,7 @@
 solver fewer rows): per configuration the mean lone-solve time over NINST instances, the time booked per mode, the free
 rows handed over, row evaluations; permutations must be identical in every configuration.
     python tools/asg_sched_sweep.py "theta=2.5" "theta=2.5,arr=20" "last_div=16,eps_last=1e-7" ...
-keys: theta eps0 eps_last stop arr last_div stop_early handoff blocks radius  (unset keys = the shipped defaults)
+keys: theta eps0 eps_last stop arr last_div stop_early handoff blocks  (unset keys = the shipped defaults)
 Measurement infrastructure."""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ import cfm_oracle as oracle
 from cfm_amd import _lib
 
 lib = _lib.load(); dev = torch.device("cuda", 0)
-DEF = dict(theta=2.5, eps0=8e-3, eps_last=1e-6, stop=0.02, arr=10, last_div=4, stop_early=0.0, handoff=64, blocks=16, radius=0)
+DEF = dict(theta=2.5, eps0=8e-3, eps_last=1e-6, stop=0.02, arr=10, last_div=4, stop_early=0.0, handoff=64, blocks=16)
 NI = int(os.environ.get("NINST", "16"))
 Ms = []
 for k in range(NI):
@@ -34,7 +34,6 @@ def apply(cfg):
     lib.cfm_assign_set_async(2, int(c["blocks"]), int(c["last_div"]))
     lib.cfm_assign_set_stop_early(c["stop_early"])
     lib.cfm_assign_set_handoff(int(c["handoff"]))
-    lib.cfm_assign_set_radius_pct(int(c["radius"]))
 
 
 perms = {}
@@ -46,7 +45,7 @@ with torch.cuda.stream(torch.cuda.Stream()):
         apply(cfg)
         for M in Ms[:3]:
             ot.assign_exact(M)
-        ts, acc, st = [], np.zeros(16), []
+        ts, acc, st, adopt = [], np.zeros(16), [], []
         fb0 = (ctypes.c_int * 2)(); lib.cfm_assign_debug_fallback(fb0)
         for rep in range(2):
             for q, M in enumerate(Ms):
@@ -54,7 +53,7 @@ with torch.cuda.stream(torch.cuda.Stream()):
                 perm, info = ot.assign_exact(M, return_info=True); torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
                 buf = (ctypes.c_double * 32)(); lib.cfm_assign_debug_times(_lib.ptr(ws), buf)
-                acc += np.array(list(buf))[:16]; st.append(info["stats"])
+                acc += np.array(list(buf))[:16]; st.append(info["stats"]); adopt.append((buf[17], buf[18]))
                 perms.setdefault(q, perm.cpu()); assert torch.equal(perms[q], perm.cpu()), (spec, q)
         fb1 = (ctypes.c_int * 2)(); lib.cfm_assign_debug_fallback(fb1)
         sta = np.array(st, dtype=float)
@@ -68,6 +67,6 @@ with torch.cuda.stream(torch.cuda.Stream()):
             ot.assign_exact_batch(Ms[g0:g0 + 4]); torch.cuda.synchronize(); tb.append(time.perf_counter() - t0)
         print(f"{spec:44s} lone mean {1e3 * np.mean(ts):.3f} med {1e3 * np.median(ts):.3f} max {1e3 * max(ts):.3f} ms | free rows {stm[2]:.1f} (max {sta[:, 2].max():.0f}) "
               f"evals {stm[5]:.0f} batches {stm[3]:.0f} phases {((sta[:, 7].astype(int) >> 8) & 0xff).mean():.1f} | us: auction {acc[2] / nn:.0f} build {acc[11] / nn:.0f} solver {acc[12] / nn:.0f} other {(acc[:11].sum() - acc[2]) / nn:.0f} | "
-              f"batch4 {1e3 * np.median(tb) / 4:.3f} ms/problem | fallbacks {fb1[0] - fb0[0]}", flush=True)
+              f"batch4 {1e3 * np.median(tb) / 4:.3f} ms/problem | fallbacks {fb1[0] - fb0[0]} | groups adopted {np.mean([a for a, _ in adopt]):.1f} claims {np.mean([c for _, c in adopt]):.0f}", flush=True)
 apply({})
 print("permutations identical in every configuration")
