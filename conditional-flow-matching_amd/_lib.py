@@ -19,10 +19,10 @@ if os.environ.get("CFM_LIB_PATH"):      # a variant build for A/B measurements (
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 2      # CFM_ABI_VERSION of include/cfm_gfx950.h
+ABI_VERSION = 3      # CFM_ABI_VERSION of include/cfm_gfx950.h
 
 # ops (include/cfm_gfx950.h)
-OP_SINKHORN, OP_ASSIGN, OP_SAMPLE_DENSE, OP_MLP, OP_ODE, OP_UNBALANCED, OP_COST, OP_MLP_TRAIN = 1, 2, 3, 4, 5, 6, 7, 8
+OP_SINKHORN, OP_ASSIGN, OP_SAMPLE_DENSE, OP_MLP, OP_ODE, OP_UNBALANCED, OP_COST, OP_MLP_TRAIN, OP_TRANSPORT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 VARIANT_ICFM, VARIANT_SB, VARIANT_TARGET, VARIANT_VP = 0, 1, 2, 3
 
 ERRORS = {
@@ -62,7 +62,7 @@ SIGNATURES = {
     "cfm_partial_entropic_f64": (_i, [_vp, _i, _i, _d, _d, _i, _d, _vp, _vp, _vp, _vp]),
     "cfm_assign_exact_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfm_assign_exact_batch_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "cfm_transport_exact_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "cfm_transport_exact_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_perm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cfm_plan_sample_dense": (_i, [_vp, _i, _i, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cfm_plan_sample_pi_f64": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -10,6 +10,7 @@ extern "C" size_t cfm_ode_ws_bytes_internal(int B, int width, int d);
 extern "C" size_t cfm_ub_ws_bytes_internal(int B0, int B1);
 extern "C" size_t cfm_cost_ws_bytes_internal(int B0, int B1, int d);
 extern "C" size_t cfm_mlp_train_ws_bytes_internal(int B, int maxw, int max_params);
+extern "C" size_t cfm_tp_ws_bytes_internal(int B0, int B1);
 
 extern "C" int cfm_abi_version(void) { return CFM_ABI_VERSION; }
 
@@ -26,6 +27,7 @@ extern "C" size_t cfm_workspace_bytes(int op, int B0, int B1, int d) {
         case CFM_OP_UNBALANCED: return cfm_align_up(cfm_ub_ws_bytes_internal(B0, B1), 256);
         case CFM_OP_COST: return d > 0 ? cfm_align_up(cfm_cost_ws_bytes_internal(B0, B1, d), 256) : 0;
         case CFM_OP_MLP_TRAIN: return cfm_align_up(cfm_mlp_train_ws_bytes_internal(B0, B1, d), 256);
+        case CFM_OP_TRANSPORT: return (B0 > 0 && B1 > 0) ? cfm_align_up(cfm_tp_ws_bytes_internal(B0, B1), 256) : 0;
         default: return 0;
     }
 }

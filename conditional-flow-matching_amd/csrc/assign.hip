@@ -1658,7 +1658,12 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
             const int jj = j < n ? j : 0;
             kk[2 * q] = asg_ld(&w.key[jj]); kk[2 * q + 1] = asg_ld(&w.key[jj + 1 < n ? jj + 1 : jj]);
         }
-        if (threadIdx.x == 0) sh[2] = word0;
+        // (the first group's last bids travel with the keys — a dependent round trip per iteration otherwise — and its LDS
+        //  counters are reset in front of the refresh barrier; further, adopted groups pay both inside the loop below)
+        int bc0 = -1;
+        {   int tq = threadIdx.x; asm volatile("" : "+v"(tq));       // (opaque: the address is formed per iteration, not carried — and spilled — across the loop)
+            if (tq < ASG_BQ && first + G * tq < n) bc0 = asg_ld(&w.bidcol[first + G * tq]); }
+        if (threadIdx.x == 0) { sh[2] = word0; int* s0 = sh + 4 * (step & 1); s0[0] = 0; s0[1] = 0; }
 #pragma unroll
         for (int q = 0; q < KP; ++q) {
             const int j = threadIdx.x * 2 + 2 * WT * q;
@@ -1689,10 +1694,13 @@ __global__ __launch_bounds__(WT) void asg_auction(AsgWs w0, int n_host, size_t s
         for (int q = 0; q < ng; ++q, ++step) {
             const int grp = asg_uni_i((int)grp_list[q]);
             int* shc = sh + 4 * (step & 1);        // (this step's counters: a slow wave may still be reading the previous step's)
-            if (threadIdx.x == 0) { shc[0] = 0; shc[1] = 0; }
-            int my_bc = -1;
-            if (threadIdx.x < ASG_BQ && grp + G * (int)threadIdx.x < n) my_bc = asg_ld(&w.bidcol[grp + G * (int)threadIdx.x]);
-            __syncthreads();
+            int my_bc = bc0;
+            if (q > 0) {                           // (uniform)
+                if (threadIdx.x == 0) { shc[0] = 0; shc[1] = 0; }
+                my_bc = -1;
+                if (threadIdx.x < ASG_BQ && grp + G * (int)threadIdx.x < n) my_bc = asg_ld(&w.bidcol[grp + G * (int)threadIdx.x]);
+                __syncthreads();
+            }
             const int nb = wide_bid_queue(M, w, p_lds, r_lds, bq, &shc[1], my_bc, true, n, eps_use, tag, rb, rnd, grp, G);
             if (lane == 0 && nb) atomicAdd(&shc[0], nb);
             __syncthreads();

@@ -3,332 +3,508 @@
 // Replaces pot.emd(a, b, M) (torchcfm/optimal_transport.py:49,79,87) for x0.shape[0] != x1.shape[0]: masses 1 / B0 on
 // the rows, 1 / B1 on the columns.  In integer units (g = gcd(B0, B1)): every row supplies p = B1 / g units, every
 // column takes q = B0 / g, one unit = 1 / lcm(B0, B1) of mass — the TRANSPORTATION problem on the B0 x B1 matrix itself,
-// not the lcm x lcm assignment problem (whose rows / columns are p- and q-fold repeated: the massively tied regime of
-// every assignment solver; optimal_transport.py's exact_plan_rect takes that route up to lcm = 8192 only).
+// not the lcm x lcm assignment problem (optimal_transport.py's exact_plan_rect takes that route up to lcm = 8192 only).
 //
-// Method: successive shortest augmenting paths with node potentials (the Hungarian method for the transportation
-// problem), dense: row duals u, column duals v, reduced costs c - u - v >= 0, flow only on tight entries.
-//   start    u_i = min_j c_ij, v = 0; every row pushes what its cheapest column still takes.
-//   search   from a row r with supply left: labels per column (dist), every scanned column adds ALL its support rows
-//            to the tree at its own label (flow entries are tight), a row in the tree relaxes all columns; the search
-//            stops at the nearest column with demand left.  Duals: u_i += D - d_i on the tree rows, v_j += dist_j - D
-//            on the scanned columns; the path takes min(supply left, demand left, smallest flow on its backward
-//            entries) units.  Repeated until the row is empty, row after row.
-//   finish   fp64 certificate (c - u - v >= -tol everywhere, = 0 on the support), plan = units / lcm, cost.
-// The support is kept as an edge list (a basic solution has < B0 + B1 entries; capacity 2 (B0 + B1), compacted when
-// full, error if that does not help) whose entries are chained per column: "the support rows of column j" and "the
-// entry (i, j)" are a walk down that column's chain (a pass of the wave over the whole list per path hop was most of
-// the first version's time).
-//
-// MI355X shape: ONE wavefront.  The method is a chain of dependent steps (a search step = pick the nearest
-// unscanned column, walk its support, relax one row); all state lives in LDS (<= 112 KiB for B0 + B1 <= 2048), the
-// matrix too when it fits, and a single wave needs no barrier between steps.  Measured (tools/transport_bench.py):
-// 127 x 128 (d = 2) 89 ms — 914 searches, 55 k row relaxations at 1.6 us: a lone wave exposes every LDS round trip
-// (~100 cycles, four per pass over the columns) — 255 x 256 0.66 s, 200 x 333 (d = 16) 0.30 s; the first version
-// (whole-list passes instead of the column chains, shuffle reductions: 155 ms / 1.3 s / 0.59 s) took 2.7 s (d = 64) to
-// 10.9 s (d = 2) at 512 x 500 and 25 s at 1000 x 1024.  Nearly equal sizes cascade partial flows down long chains
-// (round-3 host prototypes counted them; the same finding held for an auction), so this is the EXACT path for the
-// sizes of the reference's tutorials and tests — the Python side sends B0 + B1 <= 512 here — not a fast one, and not
-// for 4096 vs 4000.  (POT's network simplex on the host: about a millisecond at 127 x 128.)
+// Method (round 6; rounds 3-5 ran one shortest augmenting path per search on ONE wavefront: 914 searches and 96 ms at
+// 127 x 128): the primal-dual method with a TREE PUSH per phase, one workgroup of 16 waves, all node state in LDS.
+// Orientation: R <= C (the smaller side supplies; a transposed copy is made when B0 > B1).  State: integer flows x on
+// the R x C grid, row duals u, column duals v with reduced costs c - u - v >= 0 and flow only on tight entries; rows
+// with supply left ("sources"), columns with demand left ("sinks").  A phase:
+//   distances  d(.) = the shortest residual distance of every node TO the nearest sink, by label-correcting sweeps
+//              (Bellman-Ford, everything in parallel): a row relaxes over all columns (d_i = min_j rc_ij + d_j, a wave
+//              per row), a non-sink column takes the smallest label of the rows it carries flow from (backward entries
+//              cost 0; over an arc list of the support, a thread per arc, 64-bit LDS atomic minima).  A label only ever
+//              moves on a STRICT decrease, so the next-hop pointers (row -> column nh, column -> row nr) form a forest
+//              into the sinks, zero-cost cycles included (the classical predecessor-subgraph argument, which holds for
+//              relaxations on stale values).
+//   duals      u_i += min(d_i, D), v_j -= min(d_j, D), D = the largest source label: feasibility is kept, every forest
+//              arc below D becomes tight.
+//   push       EVERY source sends ALL its supply down the forest at once: rows forward everything (their arcs are
+//              uncapacitated), a column forwards up to the flow of its backward entry, a sink absorbs up to its demand;
+//              one hop per round, integer atomics.  What is stuck in front of a saturated entry or a full sink goes
+//              back ONE hop to the rows that sent it (they keep it as supply; a row in the middle of a path may become
+//              a source that way — the pseudo-flow stays complementary-slack).  At least one unit per sink with a
+//              source in its tree arrives: the phases terminate.
+// 127 x 128 from the greedy start: 56 phases / 1.3 k sweeps (numpy prototype, scratch/tp_proto.py; equal to HiGHS on
+// every case tried) instead of 914 searches / 55 k row relaxations.
+//   warm start (optional, `sigma`): an optimal assignment of the R rows to distinct columns (the square solver on the
+//              matrix padded with C - R zero rows: cfm_assign_exact_f32) — its duals are recovered by label correcting
+//              (v_j <= v_sigma(i) + c_ij - c_i,sigma(i)), every row fills its column, and what is left is p - q units per
+//              row against the C - R open columns: for R = C - 1 (127 vs 128, 511 vs 512: the sizes the lcm route cannot
+//              take) ONE phase — a single shortest-path forest into the one open column carries every row's last unit.
+//   finish     a chip-wide pass writes the plan (units / lcm) and checks in fp64: c - u - v >= -tol everywhere, = 0 on
+//              the support, row sums p, column sums q.
+// Exactness never depends on the warm start (an invalid or non-optimal sigma is detected and ignored).
 #include "cfm_common.h"
 #include <mutex>
 
 #define TP_NMAX 2048            // B0 + B1
-#define TP_BIG 1.0e300
+#define TP_T 1024
+#define TP_NW (TP_T / 64)
+#define TP_ARC_PER_NODE 6       // capacity of the support's arc list (a basic solution has < R + C arcs; pushes add a few)
+#define TP_INF_BITS 0x7ff0000000000000ull
 
 struct TpArgs {
-    const float* M; int B0, B1, p, q;
-    double* plan; double* total_cost; int* info;
-    int stage_m; int ecap; long long scan_cap;
+    const float* M; int R, C, p, q;      // oriented: R <= C, row-major R x C
+    int* x;                              // flows [R * C] (global: the export pass reads them; the solver works there unless staged)
+    double* u; double* v;                // duals, exported for the certificate
+    float* cmax;                         // max |M|
+    const int* sigma;                    // optional warm start (row -> distinct column), or nullptr
+    int* info; int stage; int max_phases;
 };
 
-// wave64 DPP reductions (row_shr within 16-lane rows, then row_bcast 15 / 31; the result is read from lane 63): the
-// shuffle form costs 18 dependent LDS-crossbar round trips per arg-min, and a lone wave hides none of them
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ int tp_dpp_i(int oldv, int v) { return __builtin_amdgcn_update_dpp(oldv, v, CTRL, ROWMASK, 0xf, false); }
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double tp_dpp_d(double oldv, double v) {
-    const int lo = tp_dpp_i<CTRL, ROWMASK>(__double2loint(oldv), __double2loint(v));
-    const int hi = tp_dpp_i<CTRL, ROWMASK>(__double2hiint(oldv), __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double tp_wave_min_d(double v) {
-    v = fmin(v, tp_dpp_d<0x111, 0xf>(INFINITY, v));
-    v = fmin(v, tp_dpp_d<0x112, 0xf>(INFINITY, v));
-    v = fmin(v, tp_dpp_d<0x114, 0xf>(INFINITY, v));
-    v = fmin(v, tp_dpp_d<0x118, 0xf>(INFINITY, v));
-    v = fmin(v, tp_dpp_d<0x142, 0xa>(INFINITY, v));
-    v = fmin(v, tp_dpp_d<0x143, 0xc>(INFINITY, v));
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ int tp_wave_min_i(int v) {
-    v = min(v, tp_dpp_i<0x111, 0xf>(0x7fffffff, v));
-    v = min(v, tp_dpp_i<0x112, 0xf>(0x7fffffff, v));
-    v = min(v, tp_dpp_i<0x114, 0xf>(0x7fffffff, v));
-    v = min(v, tp_dpp_i<0x118, 0xf>(0x7fffffff, v));
-    v = min(v, tp_dpp_i<0x142, 0xa>(0x7fffffff, v));
-    v = min(v, tp_dpp_i<0x143, 0xc>(0x7fffffff, v));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ void tp_argmin(double& d, int& j) {          // wave arg-min, ties to the smaller index; uniform
-    const double dm = tp_wave_min_d(d);
-    j = tp_wave_min_i(d == dm ? j : 0x7fffffff);
-    d = dm;
-}
+struct TpL {
+    double *u, *dr, *v;
+    unsigned long long* dkey;            // bits of the column's label d_j (>= +0: orders like the value)
+    int *e, *nh, *pushed, *f, *t, *tin, *nr, *nrk, *chg;
+    unsigned* arcs; int* misc;
+    float* Ms; int* xs;                  // staged matrix / flows (row stride C / C + 1)
+};
+// misc slots
+#define TP_M_CHANGED 0
+#define TP_M_NARC 1
+#define TP_M_MOVED 2
+#define TP_M_ERR 3
+#define TP_M_ANY 4
 
-// index of the entry (i, j) — a walk down column j's list (every lane reads the same words) — or -1
-__device__ __forceinline__ int tp_find(const int* er, const int* enext, const int* chead, int cap, int i, int j) {
-    int e = chead[j];
-    for (int w = 0; e >= 0 && w <= cap; ++w) {
-        if (er[e] == i) return e;
-        e = enext[e];
-    }
-    return -1;
+static inline size_t tp_state_bytes(int R, int C) {
+    const size_t ecap = (size_t)TP_ARC_PER_NODE * (R + C);
+    return (size_t)R * (8 + 8 + 4 + 4 + 4) + (size_t)C * (8 + 8 + 4 * 7) + ecap * 4 + 64 + 64;
 }
+static inline size_t tp_stage_bytes(int R, int C) { return (size_t)R * C * 4 + (size_t)R * (C + 1) * 4 + 32; }
 
-__global__ __launch_bounds__(64) void tp_solve(TpArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x;
-    const int B0 = A.B0, B1 = A.B1, p = A.p, q = A.q, ecap = A.ecap;
-    // ---- carve LDS: columns, rows, edges, (matrix)
-    char* z = lds;
-    double* dist = (double*)z; z += 8 * (size_t)B1;
-    double* v = (double*)z; z += 8 * (size_t)B1;
-    double* u = (double*)z; z += 8 * (size_t)B0;
-    double* dr = (double*)z; z += 8 * (size_t)B0;
-    int* pred = (int*)z; z += 4 * (size_t)B1;
-    int* rd = (int*)z; z += 4 * (size_t)B1;
-    int* scn = (int*)z; z += 4 * (size_t)B1;
-    int* par = (int*)z; z += 4 * (size_t)B0;
-    int* rs = (int*)z; z += 4 * (size_t)B0;
-    int* intree = (int*)z; z += 4 * (size_t)B0;
-    int* tlist = (int*)z; z += 4 * (size_t)B0;
-    int* er = (int*)z; z += 4 * (size_t)ecap;
-    int* ec = (int*)z; z += 4 * (size_t)ecap;
-    int* eu = (int*)z; z += 4 * (size_t)ecap;
-    int* enext = (int*)z; z += 4 * (size_t)ecap;     // entries of one column are chained: chead[j] -> ... -> -1
-    int* chead = (int*)z; z += 4 * (size_t)B1;
+__device__ __forceinline__ TpL tp_carve(char* z, int R, int C, bool stage) {
+    TpL L;
+    L.u = (double*)z; z += 8 * (size_t)R;
+    L.dr = (double*)z; z += 8 * (size_t)R;
+    L.v = (double*)z; z += 8 * (size_t)C;
+    L.dkey = (unsigned long long*)z; z += 8 * (size_t)C;
+    L.e = (int*)z; z += 4 * (size_t)R;
+    L.nh = (int*)z; z += 4 * (size_t)R;
+    L.pushed = (int*)z; z += 4 * (size_t)R;
+    L.f = (int*)z; z += 4 * (size_t)C;
+    L.t = (int*)z; z += 4 * (size_t)C;
+    L.tin = (int*)z; z += 4 * (size_t)C;
+    L.nr = (int*)z; z += 4 * (size_t)C;
+    L.nrk = (int*)z; z += 4 * (size_t)C;
+    L.chg = (int*)z; z += 4 * (size_t)C;
+    L.misc = (int*)z; z += 64;
+    L.arcs = (unsigned*)z; z += 4 * (size_t)TP_ARC_PER_NODE * (R + C);
     z = (char*)(((uintptr_t)z + 15) & ~(uintptr_t)15);
-    const float* Mx = A.M;
-    if (A.stage_m) {
-        float* ms = (float*)z;
-        for (size_t k = lane; k < (size_t)B0 * B1; k += 64) ms[k] = A.M[k];
-        Mx = ms;
-    }
-    int ne = 0, status = 1;
-    long long scans = 0; int searches = 0;
-    float cmax_abs = 0.f;
-    for (int j = lane; j < B1; j += 64) { v[j] = 0.0; rd[j] = q; scn[j] = 0; chead[j] = -1; }
-    for (int i = lane; i < B0; i += 64) { intree[i] = 0; rs[i] = p; }
+    L.Ms = nullptr; L.xs = nullptr;
+    if (stage) { L.Ms = (float*)z; z += 4 * (size_t)R * C; L.xs = (int*)z; }
+    return L;
+}
+
+// wave arg-min of (value, index), ties to the smaller index; result uniform
+__device__ __forceinline__ void tp_argmin(double& d, int& j) {
+    const double dm = wave_min_d(d);
+    int jj = (d == dm) ? j : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) jj = min(jj, __shfl_xor(jj, o, 64));
+    d = dm; j = jj;
+}
+// inclusive prefix sum over the wave
+__device__ __forceinline__ int tp_scan(int v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if ((int)(threadIdx.x & 63) >= o) v += t; }
+    return v;
+}
+
+template <bool STAGE>
+struct TpMat {
+    const float* M; int* x; int C, xs;       // xs: row stride of the flows
+    __device__ __forceinline__ float c(int i, int j) const { return M[(size_t)i * C + j]; }
+    __device__ __forceinline__ int* xp(int i, int j) const { return x + (size_t)i * xs + j; }
+};
+
+__device__ __forceinline__ void tp_arc_append(const TpL& L, int ecap, int i, int j) {
+    const int k = atomicAdd(&L.misc[TP_M_NARC], 1);
+    if (k < ecap) L.arcs[k] = ((unsigned)i << 16) | (unsigned)j;
+    // (past the capacity: the list is rebuilt from the flows before it is read again — tp_arcs_rebuild)
+}
+
+// the arc list from the flows themselves (start of the solve; when lazy deletion has filled it)
+template <bool STAGE>
+__device__ __forceinline__ void tp_arcs_rebuild(const TpL& L, const TpMat<STAGE>& A, int R, int C, int ecap) {
+    if (threadIdx.x == 0) L.misc[TP_M_NARC] = 0;
     __syncthreads();
-    // ---- start: row minima, greedy push into the cheapest column
-    for (int i = 0; i < B0; ++i) {
-        double bd = TP_BIG; int bj = 0x7fffffff;
-        for (int j = lane; j < B1; j += 64) {
-            const float c = Mx[(size_t)i * B1 + j];
-            cmax_abs = fmaxf(cmax_abs, fabsf(c));
+    for (size_t k = threadIdx.x; k < (size_t)R * C; k += TP_T) {
+        const int i = (int)(k / C), j = (int)(k % C);
+        if (*A.xp(i, j) > 0) tp_arc_append(L, ecap, i, j);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && L.misc[TP_M_NARC] > ecap) L.misc[TP_M_ERR] = -10;      // the support itself does not fit
+    __syncthreads();
+}
+
+template <bool STAGE>
+__global__ __launch_bounds__(TP_T) void tp_pd_solve(TpArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int R = P.R, C = P.C, p = P.p, q = P.q;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ double red[TP_NW];
+    const TpL L = tp_carve(lds, R, C, STAGE);
+    const int ecap = TP_ARC_PER_NODE * (R + C);
+    TpMat<STAGE> A;
+    A.C = C;
+    if (STAGE) {
+        for (size_t k = tid; k < (size_t)R * C; k += TP_T) L.Ms[k] = P.M[k];
+        A.M = L.Ms; A.x = L.xs; A.xs = C + 1;          // (odd stride: a column of the flows is read without bank conflicts)
+        for (size_t k = tid; k < (size_t)R * (C + 1); k += TP_T) L.xs[k] = 0;
+    } else {
+        A.M = P.M; A.x = P.x; A.xs = C;
+        for (size_t k = tid; k < (size_t)R * C; k += TP_T) P.x[k] = 0;
+    }
+    if (tid < 16) L.misc[tid] = 0;
+    for (int j = tid; j < C; j += TP_T) { L.v[j] = 0.0; L.f[j] = q; L.t[j] = 0; L.tin[j] = 0; L.nr[j] = -1; L.nrk[j] = 0x7fffffff; L.chg[j] = 0; }
+    for (int i = tid; i < R; i += TP_T) { L.e[i] = p; L.pushed[i] = 0; L.nh[i] = -1; }
+    __syncthreads();
+    // ---- max |M| (the certificate's tolerance), row minima
+    float cm = 0.f;
+    for (int i = wv; i < R; i += TP_NW) {
+        double bd = INFINITY; int bj = 0x7fffffff;
+        for (int j = lane; j < C; j += 64) {
+            const float c = A.c(i, j);
+            cm = fmaxf(cm, fabsf(c));
             if ((double)c < bd) { bd = (double)c; bj = j; }
         }
         tp_argmin(bd, bj);
-        const int dlt = min(p, rd[bj]);
-        __syncthreads();
-        if (lane == 0) {
-            u[i] = bd;
-            if (dlt > 0) { er[ne] = i; ec[ne] = bj; eu[ne] = dlt; enext[ne] = chead[bj]; chead[bj] = ne; rs[i] = p - dlt; rd[bj] -= dlt; }
-        }
-        if (dlt > 0) ++ne;
-        __syncthreads();
+        if (lane == 0) { L.u[i] = bd; L.nh[i] = bj; }        // (nh: the cheapest column, for the greedy start)
     }
-    cmax_abs = wave_max_f(cmax_abs);
-    // ---- rows with supply left: shortest augmenting paths
-    for (int r = 0; r < B0 && status == 1; ++r) {
-        int guard = 0;
-        while (status == 1) {
-            __syncthreads();
-            if (rs[r] <= 0) break;
-            if (++guard > p + 1) { status = -5; break; }          // every augmentation moves >= 1 unit of the row
-            ++searches;
-            // root
-            const double ur = u[r];
-            for (int j = lane; j < B1; j += 64) {
-                dist[j] = ((double)Mx[(size_t)r * B1 + j] - ur) - v[j]; pred[j] = r; scn[j] = 0;
-            }
-            ++scans;
-            int nt = 1;
-            if (lane == 0) { intree[r] = 1; dr[r] = 0.0; par[r] = -1; tlist[0] = r; }
-            __syncthreads();
-            int jsink = -1; double D = 0.0;
-            for (int it = 0; it <= B1; ++it) {
-                double bd = TP_BIG; int bj = 0x7fffffff;
-                for (int j = lane; j < B1; j += 64)
-                    if (!scn[j] && (dist[j] < bd || (dist[j] == bd && j < bj))) { bd = dist[j]; bj = j; }
-                tp_argmin(bd, bj);
-                if (bj == 0x7fffffff) { status = -6; break; }      // nothing left to scan and no demand reached
-                D = bd;
-                if (rd[bj] > 0) { jsink = bj; break; }
-                __syncthreads();
-                if (lane == 0) scn[bj] = 1;
-                // the support rows of column bj join the tree at label D and relax every column
-                __syncthreads();
-                int e = chead[bj];
-                for (int w = 0; e >= 0 && w <= ecap; ++w) {
-                    const int i = er[e], units = eu[e], nx = enext[e];
-                    if (units > 0 && !intree[i]) {
-                        __syncthreads();
-                        if (lane == 0) { intree[i] = 1; dr[i] = D; par[i] = bj; tlist[nt] = i; }
-                        ++nt; ++scans;
-                        const double ui = u[i];
-                        for (int j = lane; j < B1; j += 64) {
-                            if (scn[j] || j == bj) continue;
-                            const double nd = D + (((double)Mx[(size_t)i * B1 + j] - ui) - v[j]);
-                            if (nd < dist[j]) { dist[j] = nd; pred[j] = i; }
-                        }
-                        __syncthreads();
-                    }
-                    e = nx;
-                }
-                __syncthreads();
-                if (scans > A.scan_cap) { status = -7; break; }
-            }
-            if (status != 1) break;
-            if (jsink < 0) { status = -6; break; }
-            __syncthreads();
-            // duals: tree rows up by D - d_i, scanned columns down by D - dist_j
-            for (int k = lane; k < nt; k += 64) { const int i = tlist[k]; u[i] += D - dr[i]; }
-            for (int j = lane; j < B1; j += 64) if (scn[j]) v[j] += dist[j] - D;
-            __syncthreads();
-            // bottleneck along the path (backward entries: a tree row and the column it came from)
-            int dlt = min(rs[r], rd[jsink]);
-            {
-                int j = jsink;
-                for (int hop = 0; hop <= B0; ++hop) {
-                    const int i = pred[j], pj = par[i];
-                    if (pj < 0) break;
-                    const int e = tp_find(er, enext, chead, ecap, i, pj);
-                    if (e < 0) { status = -8; break; }
-                    dlt = min(dlt, eu[e]);
-                    j = pj;
-                }
-            }
-            if (status != 1) break;
-            if (dlt <= 0) { status = -9; break; }
-            // push dlt units
-            {
-                int j = jsink;
-                for (int hop = 0; hop <= B0 && status == 1; ++hop) {
-                    const int i = pred[j], pj = par[i];
-                    int e = tp_find(er, enext, chead, ecap, i, j);
-                    __syncthreads();
-                    if (e >= 0) { if (lane == 0) eu[e] += dlt; }
-                    else {
-                        if (ne >= ecap) {
-                            // compaction: drop the empty entries (one lane; rare)
-                            if (lane == 0) {
-                                int w = 0;
-                                for (int k = 0; k < ne; ++k) if (eu[k] > 0) { er[w] = er[k]; ec[w] = ec[k]; eu[w] = eu[k]; ++w; }
-                                for (int k = 0; k < B1; ++k) chead[k] = -1;
-                                for (int k = 0; k < w; ++k) { enext[k] = chead[ec[k]]; chead[ec[k]] = k; }
-                                dist[0] = (double)w;      // (dist is dead here: hand the count to the wave)
-                            }
-                            __syncthreads();
-                            ne = (int)dist[0];
-                            __syncthreads();
-                            if (ne >= ecap) { status = -10; break; }
-                        }
-                        if (lane == 0) { er[ne] = i; ec[ne] = j; eu[ne] = dlt; enext[ne] = chead[j]; chead[j] = ne; }
-                        ++ne;
-                    }
-                    __syncthreads();
-                    if (pj < 0) break;
-                    e = tp_find(er, enext, chead, ecap, i, pj);
-                    if (e < 0) { status = -8; break; }
-                    __syncthreads();
-                    if (lane == 0) eu[e] -= dlt;
-                    __syncthreads();
-                    j = pj;
-                }
-            }
-            if (status != 1) break;
-            __syncthreads();
-            if (lane == 0) { rs[r] -= dlt; rd[jsink] -= dlt; }
-            for (int k = lane; k < nt; k += 64) intree[tlist[k]] = 0;
-            __syncthreads();
-        }
-    }
+    cm = wave_max_f(cm);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(&L.misc[8]), __float_as_uint(cm));     // (>= 0: orders like the bits)
     __syncthreads();
-    // ---- certificate, plan, cost
-    int bad = 0;
-    if (status == 1) {
-        const double tol = 1e-10 * fmax((double)cmax_abs, 1e-30);
-        for (int j = lane; j < B1; j += 64) if (rd[j] != 0) ++bad;
-        for (int i = 0; i < B0; ++i) {
-            const double ui = u[i];
-            for (int j = lane; j < B1; j += 64)
-                if ((((double)Mx[(size_t)i * B1 + j] - ui) - v[j]) < -tol) ++bad;
+    const float cmax_abs = __uint_as_float((unsigned)L.misc[8]);
+    // ---- warm start: sigma must map the rows to DISTINCT columns; its duals come from label correcting
+    bool warm = false;
+    if (P.sigma != nullptr) {
+        for (int i = tid; i < R; i += TP_T) {
+            const int s = P.sigma[i];
+            if (s < 0 || s >= C || atomicAdd(&L.chg[s], 1) != 0) L.misc[TP_M_ERR] = 1;
         }
-        double tot = 0.0;
-        const double L = (double)B0 * (double)p;
-        for (int e = lane; e < ne; e += 64) {
-            if (eu[e] <= 0) continue;
-            const int i = er[e], j = ec[e];
-            const double c = (double)Mx[(size_t)i * B1 + j];
-            if (fabs((c - u[i]) - v[j]) > tol) ++bad;
-            tot += c * (double)eu[e];
-            A.plan[(size_t)i * B1 + j] = (double)eu[e] / L;
+        __syncthreads();
+        warm = (L.misc[TP_M_ERR] == 0);
+        __syncthreads();
+        for (int j = tid; j < C; j += TP_T) { L.chg[j] = 0; L.dkey[j] = d2ord(0.0); }
+        if (tid == 0) L.misc[TP_M_ERR] = 0;
+        __syncthreads();
+        if (warm) {
+            // v_j = min(0, min_i (v_sigma(i) - c_i,sigma(i) + c_ij)): sweeps until nothing moves; no negative cycle iff sigma is
+            // an optimal assignment of the rows to its own columns — more than C + 2 sweeps: sigma is not, and is dropped
+            int sweeps = 0;
+            for (;;) {
+                if (tid == 0) L.misc[TP_M_CHANGED] = 0;
+                __syncthreads();
+                for (int i = wv; i < R; i += TP_NW) {
+                    const int s = P.sigma[i];
+                    const double base = ord2d(L.dkey[s]) - (double)A.c(i, s);
+                    for (int j = lane; j < C; j += 64) {
+                        const unsigned long long k = d2ord(base + (double)A.c(i, j));
+                        if (k < L.dkey[j]) { atomicMin(&L.dkey[j], k); L.misc[TP_M_CHANGED] = 1; }
+                    }
+                }
+                __syncthreads();
+                const int chg = L.misc[TP_M_CHANGED];
+                __syncthreads();
+                if (!chg) break;
+                if (++sweeps > C + 2) { warm = false; break; }
+            }
         }
-        tot = wave_sum_d(tot) / L;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
-        if (bad) status = -11;
-        if (lane == 0 && A.total_cost) *A.total_cost = tot;
+        if (warm) {
+            for (int j = tid; j < C; j += TP_T) L.v[j] = ord2d(L.dkey[j]);
+            __syncthreads();
+            for (int i = tid; i < R; i += TP_T) {
+                const int s = P.sigma[i];
+                L.u[i] = (double)A.c(i, s) - L.v[s];
+                const int m = min(p, q);
+                *A.xp(i, s) = m; L.e[i] = p - m; L.f[s] = q - m;
+            }
+        }
+        __syncthreads();
     }
-    if (lane == 0 && A.info) {
-        int nsup = 0;
-        for (int e = 0; e < ne; ++e) nsup += eu[e] > 0 ? 1 : 0;
-        A.info[0] = status; A.info[1] = searches; A.info[2] = (int)(scans > 0x7fffffffLL ? 0x7fffffff : scans);
-        A.info[3] = nsup; A.info[4] = bad; A.info[5] = p; A.info[6] = q; A.info[7] = A.stage_m;
+    if (!warm) {
+        // greedy start: u_i = min_j c_ij, v = 0; the rows, in order, push what their cheapest column still takes
+        for (int j = tid; j < C; j += TP_T) L.v[j] = 0.0;
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 0; i < R; ++i) {
+                const int j = L.nh[i];
+                const int m = min(L.e[i], L.f[j]);
+                if (m > 0) { *A.xp(i, j) = m; L.e[i] -= m; L.f[j] -= m; }
+            }
+        }
+        __syncthreads();
+    }
+    tp_arcs_rebuild(L, A, R, C, ecap);
+    int phases = 0, sweeps_tot = 0, status = 1;
+    // ---- phases
+    for (;;) {
+        // supply left?
+        int any = 0;
+        for (int i = tid; i < R; i += TP_T) any |= (L.e[i] > 0) ? 1 : 0;
+        any = __syncthreads_or(any);
+        if (!any) break;
+        if (L.misc[TP_M_ERR] < 0) { status = L.misc[TP_M_ERR]; break; }
+        if (++phases > P.max_phases) { status = -5; break; }
+        if (L.misc[TP_M_NARC] > ecap - (R + C)) { tp_arcs_rebuild(L, A, R, C, ecap); if (L.misc[TP_M_ERR] < 0) { status = L.misc[TP_M_ERR]; break; } }
+        // labels: sinks 0, everything else unreached
+        for (int j = tid; j < C; j += TP_T) { L.dkey[j] = (L.f[j] > 0) ? 0ull : TP_INF_BITS; L.nr[j] = -1; L.nrk[j] = 0x7fffffff; L.chg[j] = 0; L.t[j] = 0; L.tin[j] = 0; }
+        for (int i = tid; i < R; i += TP_T) { L.dr[i] = INFINITY; L.nh[i] = -1; L.pushed[i] = 0; }
+        __syncthreads();
+        int guard = 0;
+        for (;;) {
+            ++sweeps_tot;
+            if (tid == 0) { L.misc[TP_M_CHANGED] = 0; L.misc[TP_M_ANY] = 0; }
+            __syncthreads();
+            // rows from columns
+            for (int i = wv; i < R; i += TP_NW) {
+                const double ui = L.u[i];
+                double bd = INFINITY; int bj = 0x7fffffff;
+                for (int j = lane; j < C; j += 64) {
+                    const unsigned long long kj = L.dkey[j];
+                    if (kj < TP_INF_BITS) {
+                        const double cand = fmax(((double)A.c(i, j) - ui) - L.v[j], 0.0) + __longlong_as_double((long long)kj);
+                        if (cand < bd) { bd = cand; bj = j; }
+                    }
+                }
+                tp_argmin(bd, bj);
+                if (lane == 0 && bd < L.dr[i]) { L.dr[i] = bd; L.nh[i] = bj; L.misc[TP_M_CHANGED] = 1; }
+            }
+            __syncthreads();
+            // columns from the rows they carry flow from (the arc list; lazily deleted entries are skipped)
+            const int narc = min(L.misc[TP_M_NARC], ecap);
+            for (int k = tid; k < narc; k += TP_T) {
+                const unsigned a = L.arcs[k]; const int i = (int)(a >> 16), j = (int)(a & 0xffffu);
+                if (L.f[j] > 0 || *A.xp(i, j) <= 0) continue;
+                const unsigned long long nb = (unsigned long long)__double_as_longlong(L.dr[i]);
+                if (nb < L.dkey[j]) {
+                    const unsigned long long old = atomicMin(&L.dkey[j], nb);
+                    if (old > nb) { L.chg[j] = 1; L.misc[TP_M_ANY] = 1; }
+                }
+            }
+            __syncthreads();
+            if (L.misc[TP_M_ANY]) {
+                // the row behind each lowered label (ties: the lowest row)
+                for (int k = tid; k < narc; k += TP_T) {
+                    const unsigned a = L.arcs[k]; const int i = (int)(a >> 16), j = (int)(a & 0xffffu);
+                    if (!L.chg[j] || *A.xp(i, j) <= 0) continue;
+                    if ((unsigned long long)__double_as_longlong(L.dr[i]) == L.dkey[j]) atomicMin(&L.nrk[j], i);
+                }
+                __syncthreads();
+                for (int j = tid; j < C; j += TP_T)
+                    if (L.chg[j]) { L.nr[j] = L.nrk[j]; L.nrk[j] = 0x7fffffff; L.chg[j] = 0; }
+                if (tid == 0) L.misc[TP_M_CHANGED] = 1;
+            }
+            __syncthreads();
+            const int chg = L.misc[TP_M_CHANGED];
+            __syncthreads();
+            if (!chg) break;
+            if (++guard > 4 * (R + C) + 16) { status = -6; break; }
+        }
+        if (status != 1) break;
+        // ---- duals: D = the largest source label
+        double dmax = 0.0; int bad = 0;
+        for (int i = tid; i < R; i += TP_T) if (L.e[i] > 0) { const double d = L.dr[i]; if (!(d < INFINITY)) bad = 1; else dmax = fmax(dmax, d); }
+        dmax = wave_max_d(dmax);
+        if (lane == 0) red[wv] = dmax;
+        bad = __syncthreads_or(bad);
+        if (bad) { status = -7; break; }
+        double D = red[0];
+#pragma unroll
+        for (int w2 = 1; w2 < TP_NW; ++w2) D = fmax(D, red[w2]);
+        for (int i = tid; i < R; i += TP_T) L.u[i] += fmin(L.dr[i], D);
+        for (int j = tid; j < C; j += TP_T) { const double dj = __longlong_as_double((long long)L.dkey[j]); L.v[j] -= fmin(dj, D); }
+        __syncthreads();
+        // ---- push: every source sends all it has down the forest
+        for (int i = tid; i < R; i += TP_T) {
+            const int m = L.e[i];
+            if (m > 0) {
+                const int j = L.nh[i];
+                int* xp = A.xp(i, j);
+                const int old = *xp; *xp = old + m;                      // (entry (i, nh_i): this thread's alone in this step)
+                if (old == 0) tp_arc_append(L, ecap, i, j);
+                atomicAdd(&L.t[j], m); L.pushed[i] = m; L.e[i] = 0;
+            }
+        }
+        __syncthreads();
+        for (int round = 0; round <= R + C + 2; ++round) {
+            int moved = 0;
+            for (int j = tid; j < C; j += TP_T) {
+                const int tj = L.t[j];
+                if (tj <= 0) continue;
+                if (L.f[j] > 0) {
+                    const int a = min(tj, L.f[j]);
+                    L.f[j] -= a; L.t[j] = tj - a; moved = 1;
+                } else if (L.nr[j] >= 0) {
+                    const int i2 = L.nr[j];
+                    int* cp = A.xp(i2, j);
+                    const int cap = *cp, m = min(tj, cap);
+                    if (m > 0) {
+                        *cp = cap - m; L.t[j] = tj - m;                  // (nobody adds to (nr_j, j): nh[nr_j] != j in a forest)
+                        const int j2 = L.nh[i2];
+                        const int old = atomicAdd(A.xp(i2, j2), m);
+                        if (old == 0) tp_arc_append(L, ecap, i2, j2);
+                        atomicAdd(&L.pushed[i2], m); atomicAdd(&L.tin[j2], m);
+                        moved = 1;
+                    }
+                }
+            }
+            moved = __syncthreads_or(moved);
+            for (int j = tid; j < C; j += TP_T) { const int a = L.tin[j]; if (a) { L.t[j] += a; L.tin[j] = 0; } }
+            __syncthreads();
+            if (!moved) break;
+        }
+        // ---- what is stuck in front of a saturated entry / a full sink goes back one hop, rows in index order
+        for (int j = wv; j < C; j += TP_NW) {
+            int rem = L.t[j];
+            if (rem <= 0) continue;                                      // (uniform)
+            for (int base = 0; base < R && rem > 0; base += 64) {
+                const int i = base + lane;
+                const int amt = (i < R && L.nh[i] == j) ? L.pushed[i] : 0;
+                const int incl = tp_scan(amt), excl = incl - amt;
+                const int take = max(0, min(amt, rem - excl));
+                if (take > 0) { *A.xp(i, j) -= take; L.e[i] += take; L.pushed[i] -= take; }
+                rem -= min(rem, __shfl(incl, 63, 64));
+            }
+            if (lane == 0) { L.t[j] = 0; if (rem != 0) L.misc[TP_M_ERR] = -8; }
+        }
+        __syncthreads();
+    }
+    if (status == 1 && L.misc[TP_M_ERR] < 0) status = L.misc[TP_M_ERR];
+    // ---- export: duals, flows (staged), bookkeeping; the plan / certificate pass follows
+    for (int j = tid; j < C; j += TP_T) { P.v[j] = L.v[j]; if (L.f[j] != 0 && status == 1) L.misc[TP_M_ERR] = -9; }
+    for (int i = tid; i < R; i += TP_T) P.u[i] = L.u[i];
+    if (STAGE) for (size_t k = tid; k < (size_t)R * C; k += TP_T) P.x[k] = L.xs[(k / C) * (size_t)(C + 1) + (k % C)];
+    __syncthreads();
+    if (tid == 0) {
+        if (status == 1 && L.misc[TP_M_ERR] < 0) status = L.misc[TP_M_ERR];
+        *P.cmax = cmax_abs;
+        P.info[0] = status; P.info[1] = phases; P.info[2] = sweeps_tot; P.info[5] = p; P.info[6] = q;
+        P.info[7] = (STAGE ? 1 : 0) | (warm ? 2 : 0);
     }
 }
 
-static size_t tp_lds_state(int B0, int B1, int ecap) {
-    return (size_t)B1 * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)B0 * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)ecap * 16 + 32;
+// Plan + certificate: one wave per oriented row.  plan is [B0, B1]; the oriented problem is its transpose when B0 > B1.
+__global__ __launch_bounds__(256) void tp_export(const float* M, const int* x, const double* u, const double* v, const float* cmax,
+                                                 int R, int C, int p, int q, int transposed, double* plan, double* total_cost,
+                                                 int* colsum, int* info, unsigned* ticket) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4, w0 = blockIdx.x * 4 + wv;
+    const double tol = 1e-10 * fmax((double)*cmax, 1e-30);
+    const double L = (double)R * (double)p;
+    const bool ok = info[0] == 1;
+    int bad = 0, nsup = 0; double tot = 0.0;
+    for (int i = w0; i < R; i += nw) {
+        const double ui = u[i];
+        int rs = 0;
+        for (int j = lane; j < C; j += 64) {
+            const double c = (double)M[(size_t)i * C + j];
+            const int xv = x[(size_t)i * C + j];
+            const double rc = (c - ui) - v[j];
+            if (rc < -tol || xv < 0) ++bad;
+            if (xv > 0) { if (fabs(rc) > tol) ++bad; tot += c * (double)xv; ++nsup; atomicAdd(&colsum[j], xv); }
+            rs += xv;
+            const size_t o = transposed ? (size_t)j * R + i : (size_t)i * C + j;
+            plan[o] = ok ? (double)xv / L : 0.0;
+        }
+        rs = wave_sum_i(rs);
+        if (rs != p) ++bad;
+    }
+    tot = wave_sum_d(tot); bad = wave_sum_i(bad); nsup = wave_sum_i(nsup);
+    if (lane == 0) {
+        if (tot != 0.0) atomicAdd(total_cost, tot / L);
+        if (bad) atomicAdd(&info[4], bad);
+        if (nsup) atomicAdd(&info[3], nsup);
+    }
+    // the last workgroup checks the column sums and closes the status
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0; }
+    __syncthreads();
+    if (last) {
+        __threadfence();
+        int b2 = 0;
+        for (int j = threadIdx.x; j < C; j += 256) if (__hip_atomic_load(&colsum[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q) ++b2;
+        b2 = __syncthreads_or(b2);
+        if (threadIdx.x == 0) {
+            const int viol = __hip_atomic_load(&info[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (b2 ? 1 : 0);
+            info[4] = viol;
+            if (info[0] == 1 && viol) info[0] = -11;
+        }
+    }
+}
+
+__global__ void tp_transpose(const float* M, int B0, int B1, float* Mt) {      // Mt[j][i] = M[i][j]
+    __shared__ float tile[32][33];
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + threadIdx.x;
+        tile[r][threadIdx.x] = (i < B0 && j < B1) ? M[(size_t)i * B1 + j] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int j = j0 + r, i = i0 + threadIdx.x;
+        if (i < B0 && j < B1) Mt[(size_t)j * B0 + i] = tile[threadIdx.x][r];
+    }
 }
 
 static int tp_gcd(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 
-extern "C" int cfm_transport_exact_f32(const float* M, int B0, int B1, double* plan, double* total_cost, int* info,
-                                       void* stream) {
-    if (!M || !plan || !info || B0 < 1 || B1 < 1) return CFM_EINVAL;
+// workspace: [Mt: R*C floats (B0 > B1 only)] [x: R*C ints] [u: R doubles] [v: C doubles] [colsum: C ints] [cmax, ticket: 64 B]
+extern "C" size_t cfm_tp_ws_bytes_internal(int B0, int B1) {
+    const size_t N = (size_t)B0 * B1;
+    const int R = B0 < B1 ? B0 : B1, C = B0 < B1 ? B1 : B0;
+    return cfm_align_up(4 * N, 256) + cfm_align_up(4 * N, 256) + cfm_align_up(8 * (size_t)R, 256) + cfm_align_up(8 * (size_t)C, 256)
+           + cfm_align_up(4 * (size_t)C, 256) + 256;
+}
+
+extern "C" int cfm_transport_exact_f32(const float* M, int B0, int B1, const int* sigma, double* plan, double* total_cost,
+                                       int* info, void* ws, void* stream) {
+    if (!M || !plan || !info || !total_cost || !ws || B0 < 1 || B1 < 1) return CFM_EINVAL;
     if (B0 + B1 > TP_NMAX) return CFM_EINVAL;
+    if (((uintptr_t)ws & 15) != 0) return CFM_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     static int raised_d[CFM_MAX_DEVICES];
     static std::once_flag once_d[CFM_MAX_DEVICES];
     const int dvi = cfm_device_index();
     int& raised = raised_d[dvi];
     std::call_once(once_d[dvi], [&raised] {
-        hipError_t e = hipFuncSetAttribute((const void*)tp_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)tp_pd_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tp_pd_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         raised = (e == hipSuccess) ? 1 : -1;
     });
     if (raised < 0) return CFM_EINVAL;
-    const int g = tp_gcd(B0, B1);
+    const int transposed = B0 > B1 ? 1 : 0;
+    const int R = transposed ? B1 : B0, C = transposed ? B0 : B1;
+    const int g = tp_gcd(R, C);
+    const size_t N = (size_t)R * C;
+    char* z = (char*)ws;
+    float* Mt = (float*)z; z += cfm_align_up(4 * N, 256);
+    int* x = (int*)z; z += cfm_align_up(4 * N, 256);
+    double* u = (double*)z; z += cfm_align_up(8 * (size_t)R, 256);
+    double* v = (double*)z; z += cfm_align_up(8 * (size_t)C, 256);
+    int* colsum = (int*)z; z += cfm_align_up(4 * (size_t)C, 256);
+    float* cmax = (float*)z; unsigned* ticket = (unsigned*)(z + 16);
+    int rc = cfm_hip(hipMemsetAsync(info, 0, 8 * sizeof(int), s)); if (rc) return rc;
+    rc = cfm_hip(hipMemsetAsync(total_cost, 0, sizeof(double), s)); if (rc) return rc;
+    rc = cfm_hip(hipMemsetAsync(colsum, 0, cfm_align_up(4 * (size_t)C, 256) + 256, s)); if (rc) return rc;
+    const float* Mo = M;
+    if (transposed) {
+        hipLaunchKernelGGL(tp_transpose, dim3((B1 + 31) / 32, (B0 + 31) / 32), dim3(32, 8), 0, s, M, B0, B1, Mt);
+        Mo = Mt;
+    }
     TpArgs A;
-    A.M = M; A.B0 = B0; A.B1 = B1; A.p = B1 / g; A.q = B0 / g;
-    A.plan = plan; A.total_cost = total_cost; A.info = info;
-    A.ecap = 2 * (B0 + B1);
-    const size_t state = tp_lds_state(B0, B1, A.ecap);
-    const size_t mbytes = (size_t)B0 * B1 * sizeof(float);
-    const size_t budget = 158 * 1024;
+    A.M = Mo; A.R = R; A.C = C; A.p = C / g; A.q = R / g; A.x = x; A.u = u; A.v = v; A.cmax = cmax; A.sigma = sigma; A.info = info;
+    A.max_phases = 64 * (R + C) + 1024;
+    const size_t state = tp_state_bytes(R, C), budget = 158 * 1024;
     if (state > budget) return CFM_EINVAL;
-    A.stage_m = (state + mbytes + 16 <= budget) ? 1 : 0;
-    A.scan_cap = 4000000LL;       // status -7 beyond (1000 x 1024, d = 8: 2.0 M row relaxations, 25 s): bounds the run time of a single-wave kernel
-    const size_t lds = state + (A.stage_m ? mbytes + 16 : 0);
-    int rc = cfm_hip(hipMemsetAsync(plan, 0, sizeof(double) * (size_t)B0 * B1, s));
-    if (rc) return rc;
-    rc = cfm_hip(hipMemsetAsync(info, 0, 8 * sizeof(int), s));
-    if (rc) return rc;
-    hipLaunchKernelGGL(tp_solve, dim3(1), dim3(64), lds, s, A);
+    A.stage = (state + tp_stage_bytes(R, C) <= budget) ? 1 : 0;
+    const size_t lds = state + (A.stage ? tp_stage_bytes(R, C) : 0);
+    if (A.stage) hipLaunchKernelGGL(tp_pd_solve<true>, dim3(1), dim3(TP_T), lds, s, A);
+    else hipLaunchKernelGGL(tp_pd_solve<false>, dim3(1), dim3(TP_T), lds, s, A);
+    int grid = (R + 3) / 4; if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(tp_export, dim3(grid), dim3(256), 0, s, Mo, x, u, v, cmax, R, C, A.p, A.q, transposed, plan, total_cost, colsum, info, ticket);
     return cfm_status();
 }

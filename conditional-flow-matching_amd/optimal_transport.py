@@ -154,27 +154,45 @@ _RECT_EXACT_MAX = 8192
 _RECT_SCIPY_MAX = 1024      # padded LSAP between batches of very different sizes (sample_plan_with_scipy)
 
 
-# cfm_transport_exact_f32 takes B0 + B1 <= 2048 (all solver state in the LDS of one CU), but it is an exact path, not a
-# fast one: 127 x 128 89 ms, 255 x 256 0.66 s, 512 x 500 seconds.  exact_plan_rect sends it sizes up to:
-_RECT_TRANSPORT_MAX = 512
+# cfm_transport_exact_f32 (round 6: primal-dual phases with a tree push, one workgroup) takes B0 + B1 <= 2048 — the node
+# state of the solver lives in the LDS of one CU.  With the assignment warm start sizes that differ by one take ONE phase.
+_RECT_TRANSPORT_MAX = 2048
+# the warm start solves a max(B0, B1)-sized SQUARE assignment problem on the matrix padded with zero rows: worth it while
+# the padding is small (identical zero rows are the tied regime of the square solver)
+_RECT_WARM_PAD_FRAC = 0.25
 
 
-def transport_exact(M):
-    """Exact OT plan between uniform marginals of different sizes on the B0 x B1 matrix itself (successive shortest
-    paths, cfm_transport_exact_f32): device fp64 [B0,B1] plan and its cost.  Raises unless the fp64 certificate holds."""
+def transport_exact(M, warm_start=None, return_info=False):
+    """Exact OT plan between uniform marginals of different sizes on the B0 x B1 matrix itself (primal-dual phases,
+    cfm_transport_exact_f32): device fp64 [B0,B1] plan and its cost.  Raises unless the fp64 certificate holds.
+    warm_start: None — decide from the sizes; True / False — force.  The warm start is an optimal assignment of the
+    smaller side's rows to distinct indices of the larger side (``assign_exact`` on the matrix padded with zero rows);
+    the solver validates it and never depends on it."""
     lib = _lib.load()
     B0, B1 = M.shape
     dev = M.device
     M = M.contiguous()
+    R, C = min(B0, B1), max(B0, B1)
+    if warm_start is None:
+        warm_start = (C - R) <= _RECT_WARM_PAD_FRAC * C and C >= 8
+    sigma = None
+    if warm_start and C > R:
+        Ms = torch.zeros((C, C), dtype=torch.float32, device=dev)
+        Ms[:R] = M if B0 <= B1 else M.t()
+        sigma = assign_exact(Ms)[:R].contiguous()
     plan = torch.empty((B0, B1), dtype=torch.float64, device=dev)
     tot = torch.empty(1, dtype=torch.float64, device=dev)
     info = torch.empty(8, dtype=torch.int32, device=dev)
-    check(lib.cfm_transport_exact_f32(ptr(M), B0, B1, ptr(plan), ptr(tot), ptr(info), stream_ptr()),
+    ws = _lib.workspace(_lib.OP_TRANSPORT, B0, B1, 0, dev)
+    check(lib.cfm_transport_exact_f32(ptr(M), B0, B1, ptr(sigma), ptr(plan), ptr(tot), ptr(info), ptr(ws), stream_ptr()),
           "cfm_transport_exact_f32")
     st = info.cpu()
     if int(st[0]) != 1:
-        raise CfmBackendError(f"transportation solver stopped with status {int(st[0])} (searches {int(st[1])}, "
-                              f"row relaxations {int(st[2])}, violations {int(st[4])})")
+        raise CfmBackendError(f"transportation solver stopped with status {int(st[0])} (phases {int(st[1])}, "
+                              f"sweeps {int(st[2])}, violations {int(st[4])})")
+    if return_info:
+        return plan, float(tot.cpu()[0]), {"phases": int(st[1]), "sweeps": int(st[2]), "support": int(st[3]),
+                                           "staged": bool(int(st[7]) & 1), "warm_start_used": bool(int(st[7]) & 2)}
     return plan, float(tot.cpu()[0])
 
 

@@ -39,7 +39,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define CFM_ABI_VERSION 2
+#define CFM_ABI_VERSION 3
 
 /* error codes (negative) */
 #define CFM_EINVAL   (-1)  /* bad shape / null pointer / unsupported size      */
@@ -56,6 +56,7 @@ extern "C" {
 #define CFM_OP_UNBALANCED    6   /* also the partial (Dykstra) solver */
 #define CFM_OP_COST          7   /* cfm_sqeuclid_cost_ws_f32 (B0, B1, d)  */
 #define CFM_OP_MLP_TRAIN     8   /* cfm_mlp_backward_f32 (B, widest layer, largest weight's element count) */
+#define CFM_OP_TRANSPORT     9   /* cfm_transport_exact_f32 (B0, B1, 0) */
 
 /* variants for cfm_sample_xt_ut_f32 (reference class in parentheses) */
 #define CFM_VARIANT_ICFM   0  /* ConditionalFlowMatcher / ExactOT...          */
@@ -208,14 +209,22 @@ int cfm_assign_exact_batch_f32(const float* const* M, int nb, int B, int* const*
 
 /* K4r — exact OT between uniform marginals of DIFFERENT sizes (masses 1/B0 on the rows, 1/B1 on the columns).
  * Replaces  pot.emd(a, b, M)  for x0.shape[0] != x1.shape[0]   torchcfm/optimal_transport.py:49,79,87
- * Successive shortest augmenting paths on the B0 x B1 matrix itself (every row supplies B1/g units, every column
- * takes B0/g, g = gcd; no lcm x lcm expansion), one wavefront, all state in LDS.  B0 + B1 <= 2048 (CFM_EINVAL beyond).
+ * The transportation problem on the B0 x B1 matrix itself (every row supplies B1/g units, every column takes B0/g,
+ * g = gcd; no lcm x lcm expansion): the primal-dual method with one shortest-path forest into the open columns and a
+ * push of ALL open supply down that forest per phase — one workgroup, node state in LDS (matrix and flows too when they
+ * fit), then a chip-wide plan / certificate pass.  B0 + B1 <= 2048 (CFM_EINVAL beyond).
+ * sigma (device int32[min(B0,B1)], or NULL): optional warm start — an optimal assignment of the rows of the SMALLER side
+ * to distinct indices of the larger side (the square solver on the matrix padded with zero rows gives one); it is
+ * validated (distinct, in range, its duals must exist) and ignored otherwise: the result never depends on it.  With
+ * it, sizes that differ by one (127 vs 128: the case the lcm route cannot take) need ONE phase.
  * plan [B0,B1] fp64 (written whole: zero off the support, units / lcm on it); *total_cost = <plan, M>;
  * info (device int32[8]): {status (1 = optimal and certified in fp64: reduced costs >= -1e-10 max|M|, zero on the
- * support, marginals exact; < 0 = failed, nothing certified), searches, row relaxations, support size, violations,
- * units per row, units per column, matrix staged in LDS}.  Asynchronous on `stream`; the caller reads info[0]. */
-int cfm_transport_exact_f32(const float* M, int B0, int B1, double* plan, double* total_cost, int* info,
-                            void* stream);
+ * support, marginals exact; < 0 = failed, nothing certified), phases, label-correcting sweeps, support size, violations,
+ * units per row, units per column of the oriented problem, bit 0: matrix staged in LDS, bit 1: warm start used}.
+ * ws: cfm_workspace_bytes(CFM_OP_TRANSPORT,B0,B1,0) bytes, 16-byte aligned.  Asynchronous on `stream`; the caller
+ * reads info[0]. */
+int cfm_transport_exact_f32(const float* M, int B0, int B1, const int* sigma, double* plan, double* total_cost,
+                            int* info, void* ws, void* stream);
 
 /* K6 (exact path) — draw n index pairs from the permutation plan.
  * Replaces sample_map()                      torchcfm/optimal_transport.py:116-121

@@ -49,7 +49,8 @@ def test_python_binding_covers_header(lib_built):
 
 def test_workspace_sizes(lib_built):
     lib = lib_built.load()
-    assert lib.cfm_abi_version() == lib_built.ABI_VERSION == 2
+    assert lib.cfm_abi_version() == lib_built.ABI_VERSION == 3
+    assert lib.cfm_workspace_bytes(9, 127, 128, 0) >= 2 * 4 * 127 * 128 and lib.cfm_workspace_bytes(9, 128, 127, 0) == lib.cfm_workspace_bytes(9, 127, 128, 0)
     for op in (1, 2, 3, 4, 5, 6, 7):
         n = lib.cfm_workspace_bytes(op, 4096, 4096, 784)
         assert n > 0 and n % 256 == 0

@@ -277,11 +277,11 @@ def test_exact_rectangular_plan(dev, B0, B1):
 
 
 def test_exact_rectangular_large_lcm_refused(dev):
-    """Unequal sizes whose lcm expansion is too large AND that are beyond what the transportation solver is sent
-    (B0 + B1 <= 512; 127 vs 128 is solved now: tests/test_gpu_transport.py) are refused, not approximated."""
+    """Unequal sizes whose lcm expansion is too large AND that are beyond the transportation solver (B0 + B1 <= 2048 since
+    round 6; 1000 vs 1001 is solved now: tests/test_gpu_transport.py) are refused, not approximated."""
     from cfm_amd.optimal_transport import OTPlanSampler
     with pytest.raises(NotImplementedError):
-        OTPlanSampler(method="exact").get_map(_rand(1000, 2, 1), _rand(1001, 2, 2))
+        OTPlanSampler(method="exact").get_map(_rand(1500, 2, 1), _rand(1501, 2, 2))
 
 
 # ------------------------------------------------------------------ K6 sampling
