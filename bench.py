@@ -48,6 +48,24 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+def thread_cpu_seconds():
+    """CPU seconds (user + system) of every thread of this process, by thread name: which threads the host side of a rank
+    keeps busy (the loop, the prefetch workers, the HIP runtime's own)."""
+    out = {}
+    try:
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                comm = open(f"/proc/self/task/{tid}/comm").read().strip()
+                f = open(f"/proc/self/task/{tid}/stat").read().rsplit(")", 1)[1].split()
+                out[f"{comm}:{tid}"] = (int(f[11]) + int(f[12])) / tick
+            except OSError:
+                pass
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
 def newest_profile(name):
     """profiles/rNN_<name> of the latest round that has one (the committed rocprofv3 summaries bench.py quotes)."""
     import glob
@@ -887,6 +905,7 @@ def main():
         return int(fb[0]), int(fb[1])
     fb_start = fallbacks()[0]
     regions = []
+    thr0 = thread_cpu_seconds()
     cpu0, wall0 = time.process_time(), time.perf_counter()
     for _ in range(1 if args.public_only else max(1, args.repeats)):
         el, gathered = timed_region(D, torch.cuda.synchronize, pool, args.warmup, args.steps, couple, model_step,
@@ -897,6 +916,11 @@ def main():
     # steps included in the denominator; with spinning event waits every worker in a solve costs a full core
     host_cpu_ms = (time.process_time() - cpu0) / (len(regions) * (args.steps + args.warmup)) * 1e3
     host_wall_ms = (time.perf_counter() - wall0) / (len(regions) * (args.steps + args.warmup)) * 1e3
+    thr1 = thread_cpu_seconds()
+    wall_regions = time.perf_counter() - wall0
+    # busiest threads over the headline regions: CPU seconds / wall seconds of the regions (1.0 = a core kept busy)
+    host_threads = sorted(((k.split(":")[0], round((v - thr0.get(k, 0.0)) / wall_regions, 3)) for k, v in thr1.items()),
+                          key=lambda kv: -kv[1])[:8]
     fb_headline = fallbacks()[0] - fb_start
     elapsed = float(np.median(regions))
     # the same loop over a region ten times as long (N = 1): what a step costs once the empty pipeline's fill and its
@@ -1006,7 +1030,7 @@ def main():
         "ms_per_step_p95": float(np.percentile(regions, 95)) / args.steps * 1e3,
         "regions_above_1p15x_median": int(sum(r > 1.15 * elapsed for r in regions)),
         "dense_fallbacks": fb_headline, "host_cpu_ms_per_step": host_cpu_ms, "host_wall_ms_per_step": host_wall_ms,
-        "blocking_sync": bool(args.blocking_sync),
+        "blocking_sync": bool(args.blocking_sync), "host_threads_busy_fraction": host_threads,
         "config": {"workload": "C3: MNIST-shaped d=784, B=4096 per GPU, ExactOptimalTransportConditionalFlowMatcher "
                                "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd (fp32-MFMA HIP kernels) + fused Adam (HIP)"
                                + ("; one all-gather of the final x_t over RCCL inside the timed region" if world > 1 else ""),

@@ -384,7 +384,9 @@ __device__ __forceinline__ void sp_entry(gfp M, const AsgWs& w, const SpL& L, in
 // phase, never correctness.
 // (Round 6 measured the alternative — establish the radius only once 30 / 50 / 75 / 100 % of the phase's trees have reached
 //  a free column: fewer phases (4.3 -> 3.6) but deeper ones; 30 - 50 %: the same solver time within noise, 75 %+: 7 - 15 ms.
-//  profiles/r6_sched_sweep.txt.  The first tree to arrive sets it.)
+//  profiles/r6_sched_sweep.txt.  The first tree to arrive sets it.  Also measured and removed: pulling the 2 MiB of
+//  candidate lists into the solver's own L2 before the searches start (the build kernel wrote them from every XCD): the
+//  time per batch did not move (3.9 us with and without).)
 __device__ __forceinline__ double sp_radius(const SpL& L, int nFC, int lane, double dfree) {
     L.tmin[lane] = ~0ull;
     double d = INFINITY; unsigned sl = 0;

@@ -50,7 +50,7 @@ def test_transport_cost_equals_the_lp_optimum(B0, B1, d, warm):
 
 def test_transport_is_deterministic_and_staged_equals_global():
     """Same input, same plan (the pushes are integer sums, the returns go in row order); and the LDS-staged form
-    (127 x 128 fits) against the global-memory form of the same kernel (a 127 x 129 problem does not fit)."""
+    (127 x 128 fits) and the global-memory form of the same kernel (140 x 163 does not fit), each against the LP."""
     import cfm_amd.optimal_transport as ot
     from cfm_amd import _lib
     dev = _lib.require_gpu()
@@ -58,9 +58,10 @@ def test_transport_is_deterministic_and_staged_equals_global():
     p1, c1, i1 = ot.transport_exact(M, warm_start=False, return_info=True)
     p2, c2, i2 = ot.transport_exact(M, warm_start=False, return_info=True)
     assert i1["staged"] and torch.equal(p1, p2) and c1 == c2 and i1["phases"] == i2["phases"]
-    M2 = _cloud_cost(127, 131, 2, 6, dev)
+    M2 = _cloud_cost(140, 163, 2, 6, dev)
     p3, c3, i3 = ot.transport_exact(M2, warm_start=False, return_info=True)
-    assert not i3["staged"]
+    p4, c4, i4 = ot.transport_exact(M2, warm_start=False, return_info=True)
+    assert not i3["staged"] and torch.equal(p3, p4) and c3 == c4
     assert c3 == pytest.approx(_lp_cost(M2.cpu().numpy()), rel=1e-9)
 
 
