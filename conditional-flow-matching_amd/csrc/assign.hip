@@ -75,6 +75,7 @@
 #include <string.h>
 #include <mutex>
 #include <atomic>
+#include <time.h>
 
 enum { MODE_UMIN0 = 0,     // u_i = min_j c_ij, cost range, key / bid state reset          (f1)
        MODE_INITRED = 1,   // initial prices: p_j = max_i (u_i - c_ij), straight into the keys (f1)
@@ -1842,14 +1843,26 @@ static thread_local AsgGraph g_graphs[ASG_GRAPH_SLOTS];
 static thread_local unsigned g_graph_use[ASG_GRAPH_SLOTS];
 static thread_local unsigned g_graph_clock = 0;
 static thread_local int g_graph_off = 0;      // this thread's streams cannot be captured: plain launches from now on
-// The host wait of a solve (ONE hipEventSynchronize per solve since round 5): with HIP's default an event wait SPINS on
-// a host core; a coupling worker of a training loop (cfm_amd.prefetch: 3 per rank, 8 ranks per node) would burn a core
-// each for the whole solve.  cfm_set_blocking_sync(1) makes this THREAD's solver events hipEventBlockingSync: the wait
-// sleeps in the kernel driver and is woken by the completion interrupt (tens of microseconds later than a spin would
-// notice — once per job of several couplings, not per step).  Thread-local: a latency-critical lone solve on the
-// caller's own thread keeps the spin.
+// The host wait of a solve (ONE per solve since round 5): with HIP's default an event wait SPINS on a host core; a
+// coupling worker of a training loop (cfm_amd.prefetch: 3 per rank, 8 ranks per node) burns a core each for the whole
+// solve.  cfm_set_blocking_sync(1) makes this THREAD's solver waits yield: its events carry hipEventBlockingSync AND the
+// wait itself is a poll (hipEventQuery) with a 20 us sleep in between — on this stack (ROCm 7, torch 2.10) a
+// "blocking" event wait was measured to spin exactly like the default (tools/probe/blocking_sync_probe.py: thread CPU
+// time == wall time for torch.cuda.Event(blocking=True) and for hipEventBlockingSync alike), so the flag alone buys
+// nothing.  The poll notices completion up to one sleep (~60 us with the kernel's timer slack) late — once per job of
+// several couplings, not per step.  Thread-local: a latency-critical lone solve on the caller's own thread keeps the spin.
 static thread_local int g_blocking_sync = 0;
 extern "C" void cfm_set_blocking_sync(int on) { g_blocking_sync = on ? 1 : 0; }
+static hipError_t asg_wait(hipEvent_t ev) {
+    if (!g_blocking_sync) return hipEventSynchronize(ev);
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        (void)hipGetLastError();                  // (hipErrorNotReady is sticky in hipGetLastError otherwise)
+        struct timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+    }
+}
 static hipError_t asg_events(AsgGraph& G) {
     if (G.ev_blocking != g_blocking_sync) {
         for (int q = 0; q < 2; ++q) if (G.ev[q]) { (void)hipEventDestroy(G.ev[q]); G.ev[q] = nullptr; }
@@ -2141,7 +2154,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     const bool head_is_whole = L.async_auction >= 2 && L.sparse && bulk > 0;
     if (head_is_whole) {
         rc = issue(0, false); if (rc) return rc;
-        rc = cfm_hip(hipEventSynchronize(G.ev[0])); if (rc) return rc;
+        rc = cfm_hip(asg_wait(G.ev[0])); if (rc) return rc;
         const int* hs = g_pinned;
         int open_ = 0;
         for (int b = 0; b < nb; ++b) {
@@ -2157,7 +2170,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     int result = 0;
     for (;;) {
         rc = issue(cur ^ 1); if (rc) return rc;
-        rc = cfm_hip(hipEventSynchronize(G.ev[cur])); if (rc) return rc;
+        rc = cfm_hip(asg_wait(G.ev[cur])); if (rc) return rc;
         const int* hs = g_pinned + 16 * ASG_BATCH_MAX * cur;
         int open_ = 0;
         for (int b = 0; b < nb; ++b) {
@@ -2172,7 +2185,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
     }
     // the look-ahead chunk is still in flight: it is a string of no-ops on a finished state, but the
     // workspace (and the pinned slot it copies into) must not be reused under it
-    rc = cfm_hip(hipEventSynchronize(G.ev[cur ^ 1]));
+    rc = cfm_hip(asg_wait(G.ev[cur ^ 1]));
     return rc ? rc : result;
 }
 

@@ -213,6 +213,8 @@ static int mlp_backward_impl(const float* const* acts, const float* const* preac
         const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
         int S = 1;
         while (S < MLP_MAX_SPLITS && tiles * S < 256 && B / (2 * S) >= 64) S *= 2;
+        // (round 6, forced split counts at C3: S = 4 / 8 / 16 (this rule) / 32: forward + MSE + backward 444 / 413 / 410 / 477 us —
+        //  profiles/r6_experiments.txt)
         const size_t np = (size_t)N * K;
         if (used + (size_t)S * (np + 2 * (size_t)N) > pool_floats) return CFM_EINVAL;      // more layers than the workspace was sized for
         float* part = pool + used; used += (size_t)S * np;

@@ -30,6 +30,20 @@ def main(d):
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:24]:
         v2 = sorted(v)
         print(f"  {k:48s} {len(v):7d} {sum(v) / len(v) / 1e3:9.1f} {v2[int(0.99 * (len(v2) - 1))] / 1e3:9.1f} {v2[-1] / 1e3:9.1f} {sum(v) / 1e6:9.1f}")
+    # per stream: the longest gaps between consecutive kernels behind the start-up part (a coupling job that waits)
+    t_lo2 = t0 + 0.4 * (ks[-1][1] - t0)
+    bystream = collections.defaultdict(list)
+    for s, e, k, st, wg, gr in ks:
+        if s >= t_lo2:
+            bystream[st].append((s, e, k))
+    print("longest gaps between consecutive kernels of one stream (us, at ms, stream, before -> after):")
+    gl = []
+    for st, lst in bystream.items():
+        lst.sort()
+        for (s0, e0, k0), (s1, e1, k1) in zip(lst, lst[1:]):
+            gl.append((s1 - e0, e0, st, k0, k1))
+    for g, at, st, k0, k1 in sorted(gl, reverse=True)[:20]:
+        print(f"  {g / 1e3:9.1f}  t={(at - t0) / 1e6:9.2f}  stream {st}  {k0} -> {k1}")
     print("longest kernel instances (start ms, dur us, name, stream, grid):")
     for s, e, k, st, wg, gr in sorted(ks, key=lambda r: -(r[1] - r[0]))[:25]:
         print(f"  t={(s - t0) / 1e6:9.2f}  {(e - s) / 1e3:9.1f}  {k:40s} stream {st} grid {gr}")
@@ -55,6 +69,9 @@ def main(d):
     for r in rows(d, "*hip_api_trace.csv"):
         api.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Start_Timestamp"]), r["Function"], r.get("Thread_Id", "?")))
     if api:
+        # (the first 40 % of the trace is start-up: module loads, first launches, workspace allocation)
+        t_lo = t0 + 0.4 * (ks[-1][1] - t0)
+        api = [a for a in api if a[1] >= t_lo]
         agg2 = collections.defaultdict(list)
         for du, s, f, th in api:
             agg2[f].append(du)
