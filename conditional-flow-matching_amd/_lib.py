@@ -96,6 +96,7 @@ EXTRA_SIGNATURES = {
     "cfm_assign_set_small": (None, [_i]),
     "cfm_assign_set_async": (None, [_i, _i, _i]),
     "cfm_assign_get_async": (None, [_vp]),
+    "cfm_assign_set_async_min_n": (None, [_i]),
     "cfm_assign_debug_small": (None, [_vp]),
     "cfm_assign_debug_solver": (_i, [_vp, _i, _vp]),
     "cfm_plan_zero_entries_f64": (_i, [_vp, _vp, _i, _vp]),

@@ -19,7 +19,7 @@
 // correctness never depends on the guess.  Four kernels, one per register / LDS
 // profile (no oversized LDS reservation):
 //
-//   asg_auction  (round 5; 1024 <= n <= 8192) every bid of the solve — the epsilon > 0 phases and the epsilon = 0
+//   asg_auction  (round 5; 512 <= n <= 8192) every bid of the solve — the epsilon > 0 phases and the epsilon = 0
 //              stage — in ONE launch without global rounds: see "asynchronous phase A" below.  The synchronous
 //              rounds of asg_step (phases A / B as described here) remain the path of the other sizes, the
 //              fallback of a failed list certificate, and the A/B reference (cfm_assign_set_async(0, ...)).
@@ -108,10 +108,12 @@ struct AsgParams {
     int bulk;              // asg_step launches enqueued before the first poll (n >= bulk_min_n)
     int bulk_min_n;
     int small;             // 1: problems of 2 <= n <= 256 take the one-workgroup solver (assign_small.h)
-    int async_auction;     // 1: the epsilon > 0 phases run in ONE launch without global rounds (asg_auction; 1024 <= n <= 8192)
+    int async_auction;     // 1: the epsilon > 0 phases run in ONE launch without global rounds (asg_auction; async_min_n <= n <= 8192)
     int async_blocks;      // ... on this many workgroups per problem in the batch entry (0: the grid of the other kernels)
     int async_last_div;    // ... the last phase is cut at stop_frac / this
     double async_theta;    // ... its epsilon reduction factor (a phase costs it microseconds, not ~15 launches: gentler scaling pays)
+    int async_min_n;       // ... smallest n it is used for (round 6: 512 — n = 512, d = 2: 2.86 ms against 3.60 on the synchronous rounds; at
+                           //     n <= 256 the one-workgroup solver stays ahead: C1 0.92 against 1.68 ms; gpurun_out -> profiles/r6_experiments.txt)
 };
 
 // Process-wide tuning defaults.  A solve works on a snapshot taken under the lock, so setters
@@ -123,7 +125,7 @@ static std::mutex g_params_mu;
 // async_theta: 40 C3 instances (profiles/r5_async_sweep.txt): theta 5 / 4 / 3 / 2.5 / 2: lone solve 2.33 / 2.28 / 2.08 / 1.92 / 1.93 ms — gentler
 // scaling leaves the list solver 15 free rows instead of 27 and shorter searches (1.04 vs 1.56 ms) for 0.1 ms more auction; the
 // sequential step 2.96 -> 2.56 ms (2.47 at theta 2), the pipelined step 1.07 -> 1.01-1.04 on the same box (1.04-1.05 at theta 2).
-static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 1024, 1, 2, 16, 4, 2.5};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
+static AsgParams g_params = {5.0, 8e-3, 1e-6, 0.02, 4000, 10, 10, 800000, 1, 64, 0.0, 0, 96, 512, 1, 2, 16, 4, 2.5, 512};   // (10 epsilon = 0 rounds: measured 2.35 ms per C3 solve against 2.56 with 15 and 2.46 with 8 once the forest phases ran in the list solver)
 static AsgParams asg_params_snapshot() { std::lock_guard<std::mutex> lk(g_params_mu); return g_params; }
 
 extern "C" void cfm_assign_set_params(double theta, double eps0_frac, double eps_last_frac,
@@ -152,6 +154,7 @@ extern "C" void cfm_assign_set_async(int on, int blocks, int last_div) {
     if (blocks >= 0) g_params.async_blocks = blocks;
     if (last_div > 0) g_params.async_last_div = last_div;      // (bits 8+: see asg_run)
 }
+extern "C" void cfm_assign_set_async_min_n(int n) { std::lock_guard<std::mutex> lk(g_params_mu); if (n >= 64) g_params.async_min_n = n; }
 extern "C" void cfm_assign_get_async(int* out3) {
     std::lock_guard<std::mutex> lk(g_params_mu);
     out3[0] = g_params.async_auction; out3[1] = g_params.async_blocks; out3[2] = g_params.async_last_div;
@@ -2064,7 +2067,7 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
         int c = asg_stream_cus(s);
         if ((long)L.blocks_auction * nb > c) L.blocks_auction = c / nb > 0 ? c / nb : 1;
     }
-    L.async_auction = (P.async_auction && n >= 1024 && n <= WIDE_PLDS_MAX && (raised & 1) && (long)L.blocks_auction * ASG_BQ >= n) ? P.async_auction : 0;
+    L.async_auction = (P.async_auction && n >= P.async_min_n && n <= WIDE_PLDS_MAX && (raised & 1) && (long)L.blocks_auction * ASG_BQ >= n) ? P.async_auction : 0;
     for (int b = 0; b < nb; ++b) {
         AsgState h;
         memset(&h, 0, sizeof(h));

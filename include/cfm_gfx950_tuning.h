@@ -29,10 +29,11 @@ void cfm_assign_set_bulk(int bulk, int min_n);   /* launches enqueued before the
 /* on = 2 (the DEFAULT): every bid of a solve — the epsilon > 0 phases AND the epsilon = 0 rounds — in the one-launch
  * asynchronous auction (asg_auction), the whole solve as one unpolled program of 12 launches; on = 1: only the epsilon > 0
  * phases there, the epsilon = 0 rounds as synchronous launches; on = 0: every round a launch (the A/B reference; always
- * the path of n < 1024 and n > 8192).  blocks >= 0: workgroups per problem of the auction in the batch entry (0: as the
+ * the path of n < 512 and n > 8192).  blocks >= 0: workgroups per problem of the auction in the batch entry (0: as the
  * other kernels); last_div > 0: its last phase is cut at stop_frac / last_div.  The grid is capped at the CUs the
  * stream may use (CU-masked streams); a grid that cannot hold 1/256 of the rows per workgroup falls back to on = 0. */
 void cfm_assign_set_async(int on, int blocks, int last_div);
+void cfm_assign_set_async_min_n(int n);          /* smallest n that takes the one-launch auction (default 512; >= 64) */
 void cfm_assign_get_async(int* out3);            /* {on, blocks, last_div} as set (tests restore what they changed) */
 void cfm_assign_set_small(int on);               /* 0: problems of n <= 256 take the chip-wide machine too */
 void cfm_set_blocking_sync(int on);              /* THIS host thread's solver waits: 1 = sleep in the driver (hipEventBlockingSync) instead of spinning on a core; cfm_amd.prefetch sets it for its worker threads */

@@ -136,9 +136,9 @@ def test_sizes_beyond_the_lds_price_snapshot(B, check_scipy):
         assert oracle.assignment_cost(Mh, p) == pytest.approx(oracle.assignment_cost(Mh, ref), rel=1e-12)
 
 
-@pytest.mark.parametrize("n,kind", [(1024, "geo"), (1500, "geo"), (2048, "uniform"), (4096, "ties"), (4096, "geo784"), (8192, "geo")])
+@pytest.mark.parametrize("n,kind", [(512, "geo"), (640, "ties"), (777, "geo"), (1024, "geo"), (1500, "geo"), (2048, "uniform"), (4096, "ties"), (4096, "geo784"), (8192, "geo")])
 def test_async_auction_gives_the_synchronous_rounds_permutation(n, kind):
-    """The one-launch asynchronous phase A (asg_auction, default for 1024 <= n <= 8192) against the synchronous bid
+    """The one-launch asynchronous phase A (asg_auction, default for 512 <= n <= 8192 since round 6) against the synchronous bid
     rounds (cfm_assign_set_async(0, ...)): nothing downstream trusts phase A, so both must end in the SAME certified
     optimum — identical permutations on generic costs, identical optimal cost on heavily tied ones — for single solves
     and for the batch entry (which runs the auction on its own, smaller grid)."""
