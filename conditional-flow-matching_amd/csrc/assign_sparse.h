@@ -71,8 +71,11 @@ struct SpL {
     unsigned char* rdn;          // [SP_ROOTS] root row already relaxed over its full matrix row
 };
 // scratch slots
-#define SP_RI_NPL 64     // pending-list length (atomic append counter)
-#define SP_RI_NS 65      // entries in the scan list
+#define SP_RI_NPL 64     // [2] pending-list lengths (atomic append counters), one per list of the ping-pong pair
+#define SP_RI_CSELF 72   // [2] entries wanted for the scan list by the barrier-free bookkeeping step (by source list)
+#define SP_RD_NMIN 54    // [2] bit patterns: running smallest / largest label filed into each pending list (sp_file and the
+#define SP_RD_NMAX 56    //     bookkeeping step's re-filing) — what lets a step start without a reduction over the list
+#define SP_RI_NS 71      // entries in the scan list
 #define SP_RI_FLAG 66
 #define SP_RI_FREECHG 68 // a free column's label was lowered since the radius was last computed
 #define SP_RD_DFREE 48   // radius of the phase
@@ -309,8 +312,13 @@ __device__ __forceinline__ void sp_file(const SpL& L, int k, double label, int p
     if (label <= far_thr) {
         const unsigned old = atomicOr(w, SP_INL_NEAR << sh);
         if (!((old >> sh) & SP_INL_NEAR)) {
-            const int pos = atomicAdd(&L.ri[SP_RI_NPL], 1);
+            const int pos = atomicAdd(&L.ri[SP_RI_NPL + plcur], 1);
             (plcur ? L.pl[1] : L.pl[0])[pos] = (unsigned short)k;
+            // the list's running minimum (the next bookkeeping step starts from it without a pass over the list): ONE
+            // fire-and-forget LDS atomic.  (Measured, profiles/r6_experiments.txt 9: a read-compare-update pair per bound
+            // + 700 cycles per batch; a second same-address atomic for the maximum + 1 700; a per-lane range folded by
+            // the wave + 600.  The running maximum only feeds the window heuristic: the re-filing keeps it.)
+            atomicMin(reinterpret_cast<unsigned long long*>(L.rd) + SP_RD_NMIN + plcur, (unsigned long long)__double_as_longlong(label));
         }
     } else {
         atomicOr(w, SP_INL_FAR << sh);
@@ -535,18 +543,31 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
 #define SP_RD_CMAX 53
 #define SP_RI_CNP 69     // live pending entries
 #define SP_RI_CSEL 70    // entries wanted for the scan list (may exceed SP_CAP)
-template <int NSL>
+struct SpRange { double dmin, dmax; int npend; };
+// FAST = false: the exact step — the label range of the live entries by a reduction over the list (two barriers inside).
+// FAST = true (round 6): NO barrier inside.  The range comes from the list's running minimum / maximum (every filing and
+// every re-filing keeps them: sp_file, below), the counters of the list being built were reset by the solver loop in
+// front of the batch.  The running minimum can be STALE-LOW (an entry that set it was lowered out of the list's range or
+// died under a smaller radius): the window then may select nothing although entries are pending — the loop falls back
+// to the exact step for that one batch.  Stale-high cannot happen for a pending entry: a label only enters the list
+// through sp_file / the re-filing, both of which record it.
+template <int NSL, bool FAST>
 __device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double dfree, double delta,
-                                               double far_thr) {
+                                               double far_thr, SpRange* rng) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int npl = L.ri[SP_RI_NPL];
+    const int npl = L.ri[SP_RI_NPL + plcur];
     const int nwav = npl >= SP_T ? SP_NW : (npl + 63) / 64;        // waves that hold entries (uniform)
     const bool active = wv < nwav;
     const unsigned short* src = plcur ? L.pl[1] : L.pl[0];
     unsigned short* dst = plcur ? L.pl[0] : L.pl[1];
+    unsigned long long* mm = reinterpret_cast<unsigned long long*>(L.rd);
     int kk[NSL]; double dd[NSL]; bool have[NSL], live[NSL];
     double lmin = INFINITY, lmax = 0.0; int np = 0;
-    if (tid == 0) {
+    double dmin, dmax; int npend;
+    if (FAST) {
+        dmin = __longlong_as_double((long long)mm[SP_RD_NMIN + plcur]); dmax = fmax(dmin, __longlong_as_double((long long)mm[SP_RD_NMAX + plcur]));
+        npend = npl;
+    } else if (tid == 0) {
         L.rd[SP_RD_CMIN] = INFINITY; L.rd[SP_RD_CMAX] = 0.0; L.ri[SP_RI_CNP] = 0; L.ri[SP_RI_CSEL] = 0;
     }
 #pragma unroll
@@ -559,24 +580,28 @@ __device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double d
                 kk[e] = src[t];
                 dd[e] = L.dist[kk[e]];
                 live[e] = dd[e] < dfree;
-                if (live[e]) { lmin = fmin(lmin, dd[e]); lmax = fmax(lmax, dd[e]); ++np; }
+                if (!FAST && live[e]) { lmin = fmin(lmin, dd[e]); lmax = fmax(lmax, dd[e]); ++np; }
             }
         }
     }
-    double wmin = INFINITY, wmax = 0.0; int wnp = 0;
-    if (active) { wmin = sp_wave_min(lmin); wmax = sp_wave_max(lmax); wnp = sp_wave_total(np); }
-    sp_sync();                                      // everybody has read the list length; the words above are reset
-    if (active && lane == 0 && wnp > 0) {
-        atomicMin(reinterpret_cast<unsigned long long*>(&L.rd[SP_RD_CMIN]), (unsigned long long)__double_as_longlong(wmin));
-        atomicMax(reinterpret_cast<unsigned long long*>(&L.rd[SP_RD_CMAX]), (unsigned long long)__double_as_longlong(wmax));
-        atomicAdd(&L.ri[SP_RI_CNP], wnp);
+    if (!FAST) {
+        double wmin = INFINITY, wmax = 0.0; int wnp = 0;
+        if (active) { wmin = sp_wave_min(lmin); wmax = sp_wave_max(lmax); wnp = sp_wave_total(np); }
+        sp_sync();                                      // everybody has read the list length; the words above are reset
+        if (active && lane == 0 && wnp > 0) {
+            atomicMin(reinterpret_cast<unsigned long long*>(&L.rd[SP_RD_CMIN]), (unsigned long long)__double_as_longlong(wmin));
+            atomicMax(reinterpret_cast<unsigned long long*>(&L.rd[SP_RD_CMAX]), (unsigned long long)__double_as_longlong(wmax));
+            atomicAdd(&L.ri[SP_RI_CNP], wnp);
+        }
+        if (tid == 0) {                                 // the list being built: its counter and its running range
+            L.ri[SP_RI_NPL + (plcur ^ 1)] = 0; mm[SP_RD_NMIN + (plcur ^ 1)] = 0x7ff0000000000000ull; mm[SP_RD_NMAX + (plcur ^ 1)] = 0ull;
+        }
+        sp_sync();
+        dmin = L.rd[SP_RD_CMIN]; dmax = L.rd[SP_RD_CMAX]; npend = L.ri[SP_RI_CNP];
     }
-    if (tid == 0) L.ri[SP_RI_NPL] = 0;              // from here on: the append counter of the list being built
-    sp_sync();
-    const double dmin = L.rd[SP_RD_CMIN], dmax = L.rd[SP_RD_CMAX];
-    const int npend = L.ri[SP_RI_CNP];
     if (!(far_thr < INFINITY) && delta < INFINITY && npend > 2 * SP_CAP) far_thr = dmin + SP_FARMULT * delta;
     const double tau = dmin + delta;
+    int* csel = FAST ? &L.ri[SP_RI_CSELF + plcur] : &L.ri[SP_RI_CSEL];
     if (active) {
         bool want[NSL]; int wpos[NSL]; int wtot = 0;
 #pragma unroll
@@ -588,10 +613,11 @@ __device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double d
         }
         int woff = 0;
         if (wtot > 0) {
-            if (lane == 0) woff = atomicAdd(&L.ri[SP_RI_CSEL], wtot);
+            if (lane == 0) woff = atomicAdd(csel, wtot);
             woff = __builtin_amdgcn_readfirstlane(woff);
         }
         bool keep[NSL]; int kpos[NSL]; int ktot = 0;
+        double kmin = INFINITY, kmax = 0.0;
 #pragma unroll
         for (int e = 0; e < NSL; ++e) {
             const bool sel = want[e] && (woff + wpos[e]) < SP_CAP;      // the wants past the cap stay pending
@@ -600,10 +626,17 @@ __device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double d
             const unsigned long long mk = __ballot(keep[e]);
             kpos[e] = ktot + __popcll(mk & ((1ull << lane) - 1ull));
             ktot += __popcll(mk);
+            if (keep[e]) { kmin = fmin(kmin, dd[e]); kmax = fmax(kmax, dd[e]); }
         }
         int koff = 0;
         if (ktot > 0) {
-            if (lane == 0) koff = atomicAdd(&L.ri[SP_RI_NPL], ktot);
+            // the kept entries are re-filed: their labels go into the running range of the list being built
+            const double wkmin = sp_wave_min(kmin), wkmax = sp_wave_max(kmax);
+            if (lane == 0) {
+                koff = atomicAdd(&L.ri[SP_RI_NPL + (plcur ^ 1)], ktot);
+                atomicMin(&mm[SP_RD_NMIN + (plcur ^ 1)], (unsigned long long)__double_as_longlong(wkmin));
+                atomicMax(&mm[SP_RD_NMAX + (plcur ^ 1)], (unsigned long long)__double_as_longlong(wkmax));
+            }
             koff = __builtin_amdgcn_readfirstlane(koff);
         }
 #pragma unroll
@@ -626,23 +659,23 @@ __device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double d
         L.ri[125] += npl;
 #endif
     }
-    // (the caller's barrier follows; nS = min(CSEL, SP_CAP) and the window adaptation are read from LDS after it)
+    rng->dmin = dmin; rng->dmax = dmax; rng->npend = npend;
+    // (the caller's barrier follows; nS = min(selected, SP_CAP) and the window adaptation are read from LDS after it)
     return delta;
 }
 // after the caller's barrier: the scan-list length and the adapted window (every thread computes the same)
-__device__ __forceinline__ double sp_collect_result(const SpL& L, double delta, int* nS) {
-    const int nsel = L.ri[SP_RI_CSEL], npend = L.ri[SP_RI_CNP];
-    const double dmin = L.rd[SP_RD_CMIN], dmax = L.rd[SP_RD_CMAX];
+__device__ __forceinline__ double sp_collect_result(const SpL& L, double delta, int* nS, int nsel, const SpRange& r) {
     *nS = nsel < SP_CAP ? nsel : SP_CAP;
     // adapt the window: aim at 32 .. 64 entries per batch
-    if (nsel > SP_CAP) delta = 0.5 * fmin(delta, dmax - dmin);
-    else if (nsel < SP_TLO && npend > nsel) delta = fmax(2.0 * delta, (dmax - dmin) * (1.0 / 64.0));
+    if (nsel > SP_CAP) delta = 0.5 * fmin(delta, r.dmax - r.dmin);
+    else if (nsel < SP_TLO && r.npend > nsel) delta = fmax(2.0 * delta, (r.dmax - r.dmin) * (1.0 / 64.0));
     return delta;
 }
 // (the near list rarely exceeds 1024 entries: one entry per thread then, without the code of the other three slots)
-__device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double dfree, double delta, double far_thr) {
-    if (L.ri[SP_RI_NPL] <= SP_T) return sp_collect_n<1>(L, plcur, dfree, delta, far_thr);
-    return sp_collect_n<SP_IPT>(L, plcur, dfree, delta, far_thr);
+template <bool FAST>
+__device__ __forceinline__ double sp_collect_all(const SpL& L, int plcur, double dfree, double delta, double far_thr, SpRange* rng) {
+    if (L.ri[SP_RI_NPL + plcur] <= SP_T) return sp_collect_n<1, FAST>(L, plcur, dfree, delta, far_thr, rng);
+    return sp_collect_n<SP_IPT, FAST>(L, plcur, dfree, delta, far_thr, rng);
 }
 
 #ifdef SP_PROFILE
@@ -717,7 +750,12 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 if (rdense) L.ri[SP_RI_ANYD] = 1;
             }
         }
-        if (tid == 0) { L.ri[SP_RI_NPL] = 0; L.rd[SP_RD_DFREE] = INFINITY; L.rd[SP_RD_FAR] = INFINITY; L.ri[SP_RI_FREECHG] = 0; }
+        if (tid == 0) {
+            L.ri[SP_RI_NPL] = 0; L.ri[SP_RI_NPL + 1] = 0; L.rd[SP_RD_DFREE] = INFINITY; L.rd[SP_RD_FAR] = INFINITY; L.ri[SP_RI_FREECHG] = 0;
+            unsigned long long* mm = reinterpret_cast<unsigned long long*>(L.rd);
+            mm[SP_RD_NMIN] = mm[SP_RD_NMIN + 1] = 0x7ff0000000000000ull; mm[SP_RD_NMAX] = mm[SP_RD_NMAX + 1] = 0ull;
+            L.ri[SP_RI_CSELF] = 0; L.ri[SP_RI_CSELF + 1] = 0;
+        }
         sp_sync();
         int nS = nR, plcur = 0;
         bool any_dense = L.ri[SP_RI_ANYD] != 0;
@@ -728,6 +766,13 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
 
         for (int guard = 0;; ++guard) {
             if (guard > 8 * n + 64) { err = 6; break; }
+            // (in front of the batch, i.e. of its barrier: the counters the barrier-free bookkeeping step behind it appends
+            //  to — the OTHER pending list, last read a whole step ago — and this step's selection counter)
+            if (tid == 0) {
+                unsigned long long* mm = reinterpret_cast<unsigned long long*>(L.rd);
+                L.ri[SP_RI_NPL + (plcur ^ 1)] = 0; mm[SP_RD_NMIN + (plcur ^ 1)] = 0x7ff0000000000000ull; mm[SP_RD_NMAX + (plcur ^ 1)] = 0ull;
+                L.ri[SP_RI_CSELF + plcur] = 0;
+            }
             if (nS > 0) {
                 if (!any_dense) {
                     sp_fast_batch(M, w, L, n, nS, nFC, dfree, lane, wv, plcur, far_thr, fb);
@@ -749,13 +794,24 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
             }
             // (the batch's radius is published by the last wave after the batch's barrier: it is read below, behind
             //  the barriers of the bookkeeping, which itself still works with the previous, larger one)
-            delta = sp_collect_all(L, plcur, dfree, delta, far_thr);
+            SpRange rng;
+            delta = sp_collect_all<true>(L, plcur, dfree, delta, far_thr, &rng);
             sp_sync();
+            delta = sp_collect_result(L, delta, &nS, L.ri[SP_RI_CSELF + plcur], rng);
             dfree = L.rd[SP_RD_DFREE];
-            delta = sp_collect_result(L, delta, &nS); far_thr = L.rd[SP_RD_FAR]; plcur ^= 1; any_dense = false;
+            far_thr = L.rd[SP_RD_FAR]; plcur ^= 1; any_dense = false;
             SP_TICK(2);
             if (nS > 0) continue;
-            if (L.ri[SP_RI_NPL] > 0) { err = 7; break; }   // tau >= dmin always selects something
+            if (L.ri[SP_RI_NPL + plcur] > 0) {
+                // entries are pending but the window selected none: the running minimum was stale — the exact step, once
+                sp_sync();
+                delta = sp_collect_all<false>(L, plcur, dfree, delta, far_thr, &rng);
+                sp_sync();
+                delta = sp_collect_result(L, delta, &nS, L.ri[SP_RI_CSEL], rng); far_thr = L.rd[SP_RD_FAR]; plcur ^= 1;
+                SP_TICK(2);
+                if (nS > 0) continue;
+                if (L.ri[SP_RI_NPL + plcur] > 0) { err = 7; break; }   // tau >= dmin always selects something
+            }
 
             // ---- near list empty: re-bucket the flagged far columns (all threads, O(n))
             {
@@ -789,11 +845,11 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                         const int k = e * SP_T + tid;
                         if (far[e]) { near[off2++] = (unsigned short)k; L.inl[k] = (unsigned char)SP_INL_NEAR; }
                     }
-                    if (tid == 0) { L.ri[SP_RI_NPL] = nmove; L.rd[SP_RD_FAR] = far_thr; }
+                    if (tid == 0) { L.ri[SP_RI_NPL + plcur] = nmove; L.rd[SP_RD_FAR] = far_thr; }
                     sp_sync();
-                    delta = sp_collect_all(L, plcur, dfree, delta, far_thr);
+                    delta = sp_collect_all<false>(L, plcur, dfree, delta, far_thr, &rng);
                     sp_sync();
-                    delta = sp_collect_result(L, delta, &nS); far_thr = L.rd[SP_RD_FAR]; plcur ^= 1;
+                    delta = sp_collect_result(L, delta, &nS, L.ri[SP_RI_CSEL], rng); far_thr = L.rd[SP_RD_FAR]; plcur ^= 1;
                     SP_TICK(2);
                     if (nS > 0) continue;
                     err = 8; break;                          // fmin_ <= far_thr: something must be selected

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+BENCH_POOL=1 NINST=16 timeout 300 python tools/asg_sched_sweep.py "theta=2.5" "theta=2.5" "theta=2.5" 2>&1 | grep -v "amdgpu.ids" > gpurun_out/r6_sweep14.txt
+timeout 1500 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_assign_batch.py tests/test_gpu_kernels.py tests/test_gpu_partition.py tests/test_gpu_prefetch.py -x -q -m gpu 2>&1 | tail -3 >> gpurun_out/r6_sweep14.txt
+python tools/asg_report.py 2>&1 | grep -v amdgpu | grep "^\[\|mean solve\|SOLVER" >> gpurun_out/r6_sweep14.txt
+cat gpurun_out/r6_sweep14.txt
