@@ -531,7 +531,7 @@ __device__ __forceinline__ void sp_fast_batch(gfp M, const AsgWs& w, const SpL& 
 // Publishes nS, the new list length and far_thr; every thread returns the same adapted delta.
 // The solver is instruction-issue bound, so only as many waves as the list needs take part (thread <-> entry, up to
 // SP_IPT entries per thread for lists beyond 1024): the others go straight to the barriers.
-#define SP_FARMULT 3.0   // the near list holds the labels within this many windows of the smallest one (measured: 3 -> 1.82 ms, 5 -> 1.96, 8 -> 1.92 of solver time at C3)
+#define SP_FARMULT 3.0   // the near list holds the labels within this many windows of the smallest one (measured: 3 -> 1.82 ms, 5 -> 1.96, 8 -> 1.92 of solver time at C3 in round 3; round 6, on the barrier-free step: 1 / 1.5 / 2 / 3 / 4 -> 0.94-1.01 ms, all within run-to-run noise)
 #define SP_RI_WANT 16    // 16 per-wave selection counts
 #define SP_RI_KEEP 96    // 16 per-wave keep counts
 // (round 3, after the cycle counters: the 16 waves no longer reduce the partial minima / counts redundantly and there
