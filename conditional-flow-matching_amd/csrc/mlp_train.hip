@@ -41,22 +41,28 @@ enum { EPI_PLAIN = 0, EPI_SELU_GRAD = 1 };
 //   A_KMAJOR = false: A(i,k) = A[i * lda + k]      true: A(i,k) = A[k * lda + i]
 //   B_KMAJOR = false: B(k,j) = Bm[j * ldb + k]     true: B(k,j) = Bm[k * ldb + j]
 // grid: x = tiles_m * tiles_n (XCD-remapped), y = split index s; split s writes C + s * split_stride.
+// the arguments of one product (a kernel argument of the single and of the paired launch)
+struct GemmArgs {
+    const float* A; int lda; const float* Bm; int ldb; float* C; int ldc; size_t split_stride;
+    const float* H;            // EPI_SELU_GRAD: pre-activations [M, ldc]
+    int M, N, Kc, k_chunk, tiles_n;
+    float* colsum;             // A_KMAJOR: sum_k A(i, k) per split -> colsum[s * M + i]
+    const float* tvec;         // A_KMAJOR: weights t[k] of a second column sum
+    float* tsum;               //   sum_k A(i, k) t[k] per split -> tsum[s * M + i]
+};
+
 template <int BM, int BN, int BK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VECA, bool VECB>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A, int lda,
-                                                     const float* __restrict__ Bm, int ldb,
-                                                     float* __restrict__ C, int ldc, size_t split_stride,
-                                                     const float* __restrict__ H,     // EPI_SELU_GRAD: pre-activations [M, ldc]
-                                                     int M, int N, int Kc, int k_chunk, int tiles_n,
-                                                     float* __restrict__ colsum = nullptr,     // A_KMAJOR: sum_k A(i, k) per split -> colsum[s * M + i]
-                                                     const float* __restrict__ tvec = nullptr, // A_KMAJOR: weights t[k] of a second column sum
-                                                     float* __restrict__ tsum = nullptr) {     //   sum_k A(i, k) t[k] per split -> tsum[s * M + i]
+__device__ __forceinline__ void gemm_tile(float* __restrict__ lds, unsigned lid, int split, const GemmArgs& G) {
     using Core = GemmCore<BM, BN, BK, A_KMAJOR, B_KMAJOR, VECA, VECB>;
-    __shared__ __attribute__((aligned(16))) float lds[Core::LDS_FLOATS];
-    const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
+    const float* __restrict__ A = G.A; const float* __restrict__ Bm = G.Bm; float* __restrict__ C = G.C;
+    const float* __restrict__ H = G.H; float* __restrict__ colsum = G.colsum; const float* __restrict__ tvec = G.tvec;
+    float* __restrict__ tsum = G.tsum;
+    const int lda = G.lda, ldb = G.ldb, ldc = G.ldc, M = G.M, N = G.N, Kc = G.Kc, k_chunk = G.k_chunk, tiles_n = G.tiles_n;
+    const size_t split_stride = G.split_stride;
     const int tm = lid / tiles_n, tn = lid % tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
     const int tid = threadIdx.x;
-    const int k_begin = blockIdx.y * k_chunk;
+    const int k_begin = split * k_chunk;
     const int k_end = (k_begin + k_chunk < Kc) ? k_begin + k_chunk : Kc;
 
     // bias gradient rides along: the workgroups of the first tile column add up their A tile (dz) over k, from the
@@ -85,12 +91,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
     g.zero();
     g.run(lds, A, lda, row0, M, Bm, ldb, col0, N, k_begin, k_end, post);
     if (A_KMAJOR && do_colsum && row0 + tid < M) {
-        colsum[(size_t)blockIdx.y * M + row0 + tid] = csum;
-        if (do_tsum) tsum[(size_t)blockIdx.y * M + row0 + tid] = wsum;
+        colsum[(size_t)split * M + row0 + tid] = csum;
+        if (do_tsum) tsum[(size_t)split * M + row0 + tid] = wsum;
     }
 
     constexpr int EU = Core::EU, EM = Core::EM, ER = Core::ER;
-    float* Cs = C + (size_t)blockIdx.y * split_stride;
+    float* Cs = C + (size_t)split * split_stride;
     const int gc = col0 + Core::col_lo();
     const bool pair = EU == 2 && (ldc & 1) == 0 && gc + 1 < N;
 #pragma unroll
@@ -118,6 +124,33 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
                 for (int u = 0; u < EU; ++u) if (gc + u < N) po[u] = v[u];
             }
         }
+    }
+}
+
+
+// grid: x = tiles_m * tiles_n (XCD-remapped), y = split index s; split s writes C + s * split_stride.
+template <int BM, int BN, int BK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VECA, bool VECB>
+__global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs G) {
+    using Core = GemmCore<BM, BN, BK, A_KMAJOR, B_KMAJOR, VECA, VECB>;
+    __shared__ __attribute__((aligned(16))) float lds[Core::LDS_FLOATS];
+    gemm_tile<BM, BN, BK, A_KMAJOR, B_KMAJOR, EPI, VECA, VECB>(lds, cfm_xcd_remap(blockIdx.x, gridDim.x), (int)blockIdx.y, G);
+}
+
+// dgrad and wgrad of ONE layer in one launch (round 6): both read dz_l and nothing of each other.  A 1-D grid: the
+// dgrad tiles first (their contraction is the long one: 512 - 784 against 256 per wgrad split), then tiles x splits of
+// wgrad; 64 x 64 x 32 tiles and 16-byte loads on both (the launcher falls back to two launches otherwise).  Same tile
+// routine, same bits.  14 -> 11 launches per C3 model step.
+__global__ __launch_bounds__(256) void gemm_pair_f32_mfma(GemmArgs D, int tiles_d, GemmArgs Wg, int tiles_w, int splits_w) {
+    using CoreD = GemmCore<64, 64, 32, false, true, true, true>;
+    using CoreW = GemmCore<64, 64, 32, true, true, true, true>;
+    constexpr int LDSF = CoreD::LDS_FLOATS > CoreW::LDS_FLOATS ? CoreD::LDS_FLOATS : CoreW::LDS_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    const int b = (int)blockIdx.x;
+    if (b < tiles_d) {
+        gemm_tile<64, 64, 32, false, true, EPI_SELU_GRAD, true, true>(lds, cfm_xcd_remap((unsigned)b, (unsigned)tiles_d), 0, D);
+    } else {
+        const int q = b - tiles_d;
+        gemm_tile<64, 64, 32, true, true, EPI_PLAIN, true, true>(lds, cfm_xcd_remap((unsigned)(q % tiles_w), (unsigned)tiles_w), q / tiles_w, Wg);
     }
 }
 
@@ -151,20 +184,31 @@ int cfm_gemm_pick_tile(long M, long N, long splits);      // mlp.hip
 int cfm_mlp_launch_layer(const float* X, int lda, const float* W, int ldw, const float* bias, const float* t,
                          int t_per_row, int tcol, int B, int K, int N, float* out, bool act, hipStream_t s, float* zout);
 
+static GemmArgs gemm_args(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, size_t split_stride,
+                          const float* H, int M, int N, int Kc, int k_chunk, int tiles_n, float* colsum, const float* tvec,
+                          float* tsum) {
+    GemmArgs G;
+    G.A = A; G.lda = lda; G.Bm = Bm; G.ldb = ldb; G.C = C; G.ldc = ldc; G.split_stride = split_stride; G.H = H;
+    G.M = M; G.N = N; G.Kc = Kc; G.k_chunk = k_chunk; G.tiles_n = tiles_n; G.colsum = colsum; G.tvec = tvec; G.tsum = tsum;
+    return G;
+}
+
 template <bool AK, bool BK_, int EPI, bool VA, bool VB>
 static void launch_gemm_t(int tile, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, size_t split_stride,
                           const float* H, int M, int N, int Kc, int k_chunk, int S, hipStream_t s, float* colsum,
                           const float* tvec, float* tsum) {
     if (tile == 0) {
         const int tm = (M + 127) / 128, tn = (N + 127) / 128;
-        hipLaunchKernelGGL((gemm_f32_mfma<128, 128, 16, AK, BK_, EPI, VA, VB>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
-                           split_stride, H, M, N, Kc, k_chunk, tn, colsum, tvec, tsum);
+        hipLaunchKernelGGL((gemm_f32_mfma<128, 128, 16, AK, BK_, EPI, VA, VB>), dim3(tm * tn, S), dim3(256), 0, s,
+                           gemm_args(A, lda, Bm, ldb, C, ldc, split_stride, H, M, N, Kc, k_chunk, tn, colsum, tvec, tsum));
     } else {
         const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-        hipLaunchKernelGGL((gemm_f32_mfma<64, 64, 32, AK, BK_, EPI, VA, VB>), dim3(tm * tn, S), dim3(256), 0, s, A, lda, Bm, ldb, C, ldc,
-                           split_stride, H, M, N, Kc, k_chunk, tn, colsum, tvec, tsum);
+        hipLaunchKernelGGL((gemm_f32_mfma<64, 64, 32, AK, BK_, EPI, VA, VB>), dim3(tm * tn, S), dim3(256), 0, s,
+                           gemm_args(A, lda, Bm, ldb, C, ldc, split_stride, H, M, N, Kc, k_chunk, tn, colsum, tvec, tsum));
     }
 }
+
+static bool gemm_vec_ok(const float* p, int ld, int extent) { return (ld % 4 == 0) && ((uintptr_t)p & 15) == 0 && (extent % 4 == 0); }
 
 template <bool AK, bool BK_, int EPI>
 static int launch_gemm(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, size_t split_stride,
@@ -175,8 +219,8 @@ static int launch_gemm(const float* A, int lda, const float* Bm, int ldb, float*
     const int tile = cfm_gemm_pick_tile(M, N, S);
     // 16-byte loads per operand: K-contiguous needs Kc % 4 == 0 (k_chunk is a multiple of 32), K-major needs the row
     // extent % 4 == 0; both need the pitch % 4 == 0 and an aligned base
-    const bool va = (lda % 4 == 0) && ((uintptr_t)A & 15) == 0 && ((AK ? M : Kc) % 4 == 0);
-    const bool vb = (ldb % 4 == 0) && ((uintptr_t)Bm & 15) == 0 && ((BK_ ? N : Kc) % 4 == 0);
+    const bool va = gemm_vec_ok(A, lda, AK ? M : Kc);
+    const bool vb = gemm_vec_ok(Bm, ldb, BK_ ? N : Kc);
 #define CFM_LG(VA_, VB_) launch_gemm_t<AK, BK_, EPI, VA_, VB_>(tile, A, lda, Bm, ldb, C, ldc, split_stride, H, M, N, Kc, k_chunk, S, s, colsum, tvec, tsum)
     if (va) { if (vb) CFM_LG(true, true); else CFM_LG(true, false); }
     else    { if (vb) CFM_LG(false, true); else CFM_LG(false, false); }
@@ -187,8 +231,8 @@ static int launch_gemm(const float* A, int lda, const float* Bm, int ldb, float*
 // Backward through all layers.  acts[l] = h_l (l = 0: the network input [B, dims[0]]; l = 1 .. n-1: the
 // saved hidden activations), preact[l] = z_l for l = 1 .. n-1 (preact[0] unused); dout [B, dims[n]].
 // Writes dW[l] ([dims[l+1], dims[l]]), db[l] and, if dx is not NULL, the input gradient [B, dims[0]].
-// Launches: per layer one wgrad (bias column sums ride along) and one dgrad, then ONE reduction of every
-// split-K partial (weights and biases of all layers).
+// Launches: per layer ONE launch for wgrad (bias column sums ride along) + dgrad (round 6; two where the shapes do not allow
+// the pair), then ONE reduction of every split-K partial (weights and biases of all layers).
 // tvec != NULL: the network input is [acts[0] (B x dims[0] - 1, pitch dims[0] - 1), tvec (B)] — the time column is
 // kept apart (the fused regression step never concatenates it); its weight gradient is the weighted column sum.
 // extra: one more job for the final reduction (the loss partials of the fused step), or NULL.
@@ -221,8 +265,26 @@ static int mlp_backward_impl(const float* const* acts, const float* const* preac
         float* bpart = pool + used; used += (size_t)S * N;
         float* tpart = nullptr;
         if (split_t) { tpart = pool + used; used += (size_t)S * N; }
-        int rc = launch_gemm<true, true, EPI_PLAIN>(dz, N, acts[l], K, part, K, np, nullptr, N, K, B, S, s, bpart,
+        // dgrad of the same layer: dz_prev[B,K] = (dz[B,N] . W[N,K]) * selu'(z_prev) — reads dz_l like wgrad and nothing of it:
+        // ONE launch for both when both run on 64 x 64 tiles with 16-byte loads (every hidden layer at C3)
+        float* dprev = (l > 0) ? gbuf[l & 1] : nullptr;
+        int rc = 0;
+        bool paired = false;
+        if (l > 0 && cfm_gemm_pick_tile(N, K, S) == 2 && cfm_gemm_pick_tile(B, K, 1) == 2 &&
+            gemm_vec_ok(dz, N, N) && gemm_vec_ok(acts[l], K, K) && gemm_vec_ok(W[l], K, K) && gemm_vec_ok(dz, N, N)) {
+            int k_chunk_w = (B + S - 1) / S; k_chunk_w = (k_chunk_w + 31) / 32 * 32;
+            const int k_chunk_d = (N + 31) / 32 * 32;
+            const int tnw = (K + 63) / 64, tiles_w = ((N + 63) / 64) * tnw;
+            const int tnd = (K + 63) / 64, tiles_d = ((B + 63) / 64) * tnd;
+            const GemmArgs Ga = gemm_args(dz, N, W[l], K, dprev, K, 0, preact[l], B, K, N, k_chunk_d, tnd, nullptr, nullptr, nullptr);
+            const GemmArgs Gw = gemm_args(dz, N, acts[l], K, part, K, np, nullptr, N, K, B, k_chunk_w, tnw, bpart, nullptr, nullptr);
+            hipLaunchKernelGGL(gemm_pair_f32_mfma, dim3(tiles_d + tiles_w * S), dim3(256), 0, s, Ga, tiles_d, Gw, tiles_w, S);
+            rc = cfm_status();
+            paired = true;
+        } else {
+            rc = launch_gemm<true, true, EPI_PLAIN>(dz, N, acts[l], K, part, K, np, nullptr, N, K, B, S, s, bpart,
                                                     split_t ? tvec : nullptr, tpart);
+        }
         if (rc) return rc;
         T.job[T.count++] = ReduceJob{part, dW[l], np, np, S, split_t ? K : 0, Kfull, 0};
         T.job[T.count++] = ReduceJob{bpart, db[l], (unsigned long long)N, (unsigned long long)N, S, 0, 0, 0};
@@ -238,10 +300,11 @@ static int mlp_backward_impl(const float* const* acts, const float* const* preac
         }
         // dgrad: dz_prev[B,K] = (dz[B,N] . W[N,K]) * selu'(z_prev)
         if (l > 0) {
-            float* dst = gbuf[l & 1];
-            rc = launch_gemm<false, true, EPI_SELU_GRAD>(dz, N, W[l], K, dst, K, 0, preact[l], B, K, N, 1, s);
-            if (rc) return rc;
-            dz = dst;
+            if (!paired) {
+                rc = launch_gemm<false, true, EPI_SELU_GRAD>(dz, N, W[l], K, dprev, K, 0, preact[l], B, K, N, 1, s);
+                if (rc) return rc;
+            }
+            dz = dprev;
         } else if (dx) {
             rc = launch_gemm<false, true, EPI_PLAIN>(dz, N, W[0], Kfull, dx, Kfull, 0, nullptr, B, Kfull, N, 1, s);
             if (rc) return rc;
