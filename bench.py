@@ -865,7 +865,7 @@ def main():
         if args.mode != "train":
             return
         if reg is not None:
-            # forward (time column fused) + MSE + backward + [gradient all-reduce] + Adam: 11 launches of the library
+            # forward (time column fused) + MSE + backward + [gradient all-reduce] + Adam: 10 launches of the library
             reg(t, xt, ut)
             return
         opt.zero_grad(set_to_none=True)

@@ -35,7 +35,10 @@ __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, in
                                                  const float* __restrict__ tptr, float tval,
                                                  int t_per_row, int tcol, int B, int K, int N,
                                                  float* __restrict__ out, int tiles_n,
-                                                 float* __restrict__ zout = nullptr) {
+                                                 float* __restrict__ zout = nullptr,
+                                                 const float* __restrict__ mse_u = nullptr,      // regression step, last layer: out = (2 / n) (v - u) and
+                                                 float mse_scale = 0.f, float mse_inv_n = 0.f,   // mse_partial[workgroup] = sum (v - u)^2 / n  (round 6: no
+                                                 float* __restrict__ mse_partial = nullptr) {    // separate MSE launch, no second pass over v)
     using Core = GemmCore<BM, BN, BK, false, false, VECA, VECB>;
     __shared__ __attribute__((aligned(16))) float lds[Core::LDS_FLOATS];
     const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, in
         }
     }
     const bool pair = EU == 2 && (N & 1) == 0 && gc + 1 < N;       // 8-byte aligned store of both columns
+    float lsum = 0.f;
 #pragma unroll
     for (int m = 0; m < EM; ++m) {
 #pragma unroll
@@ -71,6 +75,11 @@ __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, in
                 if (tcol >= 0) x = fmaf(tv, wt[u], x);
                 z[u] = x;
                 v[u] = ACT ? selu_f(x) : x;
+                if (!ACT && mse_u != nullptr && gc + u < N) {
+                    const float dlt = v[u] - mse_u[(size_t)gr * N + gc + u];
+                    lsum = fmaf(dlt, dlt, lsum);
+                    v[u] = dlt * mse_scale;
+                }
             }
             float* po = out + (size_t)gr * N + gc;
             if (pair) {
@@ -82,6 +91,13 @@ __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, in
                     if (gc + u < N) { po[u] = v[u]; if (zout) zout[(size_t)gr * N + gc + u] = z[u]; }
             }
         }
+    }
+    if (!ACT && mse_partial != nullptr) {        // (uniform) this workgroup's share of the loss, in a fixed order
+        __shared__ float msh[4];
+        lsum = wave_sum_f(lsum);
+        if ((threadIdx.x & 63) == 0) msh[threadIdx.x >> 6] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) mse_partial[blockIdx.x] = ((msh[0] + msh[1]) + (msh[2] + msh[3])) * mse_inv_n;
     }
 }
 
@@ -103,13 +119,14 @@ int cfm_gemm_pick_tile(long M, long N, long splits) {
 template <bool ACT, bool VECA, bool VECB>
 static void launch_layer_t(int tile, const float* X, int lda, const float* W, int ldw, const float* bias,
                            const float* t, float tval, int t_per_row, int tcol, int B, int K, int N, float* out,
-                           hipStream_t s, float* zout) {
+                           hipStream_t s, float* zout, const float* mse_u = nullptr, float mse_scale = 0.f, float mse_inv_n = 0.f,
+                           float* mse_partial = nullptr) {
     if (tile == 0) {
         const int tm = (B + 127) / 128, tn = (N + 127) / 128;
-        hipLaunchKernelGGL((mlp_layer<128, 128, 16, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
+        hipLaunchKernelGGL((mlp_layer<128, 128, 16, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout, mse_u, mse_scale, mse_inv_n, mse_partial);
     } else {
         const int tm = (B + 63) / 64, tn = (N + 63) / 64;
-        hipLaunchKernelGGL((mlp_layer<64, 64, 32, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout);
+        hipLaunchKernelGGL((mlp_layer<64, 64, 32, ACT, VECA, VECB>), dim3(tm * tn), dim3(256), 0, s, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, tn, zout, mse_u, mse_scale, mse_inv_n, mse_partial);
     }
 }
 
@@ -117,11 +134,13 @@ static void launch_layer_t(int tile, const float* X, int lda, const float* W, in
 // (K % 4 == 0, row pitch % 4 == 0, aligned base): the 785-wide rows of a time-varying first layer do not.
 static int launch_layer(const float* X, int lda, const float* W, int ldw, const float* bias,
                         const float* t, float tval, int t_per_row, int tcol, int B, int K, int N, float* out,
-                        bool act, hipStream_t s, float* zout = nullptr) {
+                        bool act, hipStream_t s, float* zout = nullptr, const float* mse_u = nullptr, float mse_scale = 0.f,
+                        float mse_inv_n = 0.f, float* mse_partial = nullptr, int* mse_blocks = nullptr) {
     const int tile = cfm_gemm_pick_tile(B, N, 1);
+    if (mse_blocks) *mse_blocks = (tile == 0) ? ((B + 127) / 128) * ((N + 127) / 128) : ((B + 63) / 64) * ((N + 63) / 64);
     const bool va = (K % 4 == 0) && (lda % 4 == 0) && ((uintptr_t)X & 15) == 0;
     const bool vb = (K % 4 == 0) && (ldw % 4 == 0) && ((uintptr_t)W & 15) == 0;
-#define CFM_LL(ACT_, VA_, VB_) launch_layer_t<ACT_, VA_, VB_>(tile, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, s, zout)
+#define CFM_LL(ACT_, VA_, VB_) launch_layer_t<ACT_, VA_, VB_>(tile, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, s, zout, mse_u, mse_scale, mse_inv_n, mse_partial)
     if (act) { if (va) { if (vb) CFM_LL(true, true, true); else CFM_LL(true, true, false); }
                else    { if (vb) CFM_LL(true, false, true); else CFM_LL(true, false, false); } }
     else     { if (va) { if (vb) CFM_LL(false, true, true); else CFM_LL(false, true, false); }
@@ -134,6 +153,12 @@ static int launch_layer(const float* X, int lda, const float* W, int ldw, const 
 int cfm_mlp_launch_layer(const float* X, int lda, const float* W, int ldw, const float* bias, const float* t,
                          int t_per_row, int tcol, int B, int K, int N, float* out, bool act, hipStream_t s, float* zout) {
     return launch_layer(X, lda, W, ldw, bias, t, 0.f, t_per_row, tcol, B, K, N, out, act, s, zout);
+}
+// the last layer of the fused regression step: out = (2 / n) (v - u), one loss partial per workgroup (*n_partials of them)
+int cfm_mlp_launch_layer_mse(const float* X, int lda, const float* W, int ldw, const float* bias, const float* t,
+                             int t_per_row, int tcol, int B, int K, int N, float* out, hipStream_t s, const float* u,
+                             float scale, float inv_n, float* partial, int* n_partials) {
+    return launch_layer(X, lda, W, ldw, bias, t, 0.f, t_per_row, tcol, B, K, N, out, false, s, nullptr, u, scale, inv_n, partial, n_partials);
 }
 
 // Forward through all layers.  dims[0] counts the time column when the net is

@@ -163,9 +163,28 @@ struct ReduceTable { ReduceJob job[2 * MLP_MAX_LAYERS + 2]; int count; };
 __global__ __launch_bounds__(256) void reduce_splits_multi(ReduceTable T) {
     for (int q = blockIdx.y; q < T.count; q += gridDim.y) {
         const ReduceJob J = T.job[q];
+        if (J.pad == 1) {
+            // ONE number out of S partials (the loss: one partial per workgroup of the last layer, ~ 800 of them): lane l
+            // adds partials l, l + 64, ... in order, then a fixed tree over the wave — deterministic, and not 800
+            // dependent loads in one thread
+            if (blockIdx.x == 0 && threadIdx.x < 64) {
+                float v = 0.f;
+                for (int s2 = threadIdx.x; s2 < J.S; s2 += 64) v += J.partial[s2];
+                v = wave_sum_f(v);
+                if (threadIdx.x == 0) J.out[0] = v;
+            }
+            continue;
+        }
         for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < J.n; e += (size_t)gridDim.x * 256) {
             float v = J.partial[e];
-            for (int s = 1; s < J.S; ++s) v += J.partial[(size_t)s * J.stride + e];
+            // (8 partials in flight per thread, added in split order: the same sums as one load at a time)
+            for (int s0 = 1; s0 < J.S; s0 += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = (s0 + u < J.S) ? J.partial[(size_t)(s0 + u) * J.stride + e] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (s0 + u < J.S) v += t[u];
+            }
             if (J.cols > 0) J.out[(e / (unsigned)J.cols) * (size_t)J.ld_out + (e % (unsigned)J.cols)] = v;
             else J.out[e] = v;
         }
@@ -173,16 +192,20 @@ __global__ __launch_bounds__(256) void reduce_splits_multi(ReduceTable T) {
 }
 
 #define MLP_MAX_SPLITS 32
+#define MLP_LOSS_PARTIALS 4096
 extern "C" size_t cfm_mlp_train_ws_bytes_internal(int B, int maxw, int max_params) {
     // two [B, maxw] gradient buffers + per-layer split-K partials (weights and biases; <= MLP_MAX_LAYERS layers
     // are sized here by the largest one: callers pass the largest dims[l] * dims[l+1])
-    // (+ 1 KiB of loss partials for cfm_mlp_regression_step_f32, + slack)
-    return sizeof(float) * ((size_t)2 * B * maxw + (size_t)MLP_MAX_SPLITS * ((size_t)max_params + maxw) * 4) + 2048;
+    // (+ MLP_LOSS_PARTIALS loss partials for cfm_mlp_regression_step_f32: one per workgroup of the last layer)
+    return sizeof(float) * ((size_t)2 * B * maxw + (size_t)MLP_MAX_SPLITS * ((size_t)max_params + maxw) * 4) + 4 * MLP_LOSS_PARTIALS;
 }
 
 int cfm_gemm_pick_tile(long M, long N, long splits);      // mlp.hip
 int cfm_mlp_launch_layer(const float* X, int lda, const float* W, int ldw, const float* bias, const float* t,
                          int t_per_row, int tcol, int B, int K, int N, float* out, bool act, hipStream_t s, float* zout);
+int cfm_mlp_launch_layer_mse(const float* X, int lda, const float* W, int ldw, const float* bias, const float* t,
+                             int t_per_row, int tcol, int B, int K, int N, float* out, hipStream_t s, const float* u,
+                             float scale, float inv_n, float* partial, int* n_partials);
 
 static GemmArgs gemm_args(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, size_t split_stride,
                           const float* H, int M, int N, int Kc, int k_chunk, int tiles_n, float* colsum, const float* tvec,
@@ -357,7 +380,8 @@ __global__ __launch_bounds__(256) void mse_grad(float* __restrict__ v, const flo
 // not time varying (dims[0] = columns of xt); otherwise dims[0] = columns of xt + 1 and the time column is never
 // materialised: forward adds its rank-1 term in the first layer's epilogue, backward takes its weight gradient
 // as a weighted column sum.  g [B, dims[n]] receives d loss / d v (the caller may ignore it); *loss a device float.
-// 13 launches for the 4-layer field, all kernels of this library (no eager elementwise ops in between).
+// 10 launches for the 4-layer field (round 6: dgrad + wgrad of a layer share one, the MSE rides in the last layer's
+// epilogue), all kernels of this library (no eager elementwise ops in between).
 extern "C" int cfm_mlp_regression_step_f32(const float* xt, const float* t, const float* ut,
                                            const float* const* W, const float* const* b, const int* dims, int n_layers,
                                            int B, float* const* hidden, float* const* preact, float* g,
@@ -369,33 +393,45 @@ extern "C" int cfm_mlp_regression_step_f32(const float* xt, const float* t, cons
     hipStream_t s = (hipStream_t)stream;
     const int has_t = t != nullptr;
     if (has_t && dims[0] < 2) return CFM_EINVAL;
-    // forward, keeping h_l and z_l
+    int maxw = 0; size_t maxp = 0;
+    for (int l = 0; l <= n_layers; ++l) maxw = dims[l] > maxw ? dims[l] : maxw;
+    for (int l = 0; l < n_layers; ++l) { const size_t p = (size_t)dims[l] * dims[l + 1]; maxp = p > maxp ? p : maxp; }
+    float* lpart = (float*)((char*)ws + cfm_mlp_train_ws_bytes_internal(B, maxw, (int)maxp) - 4 * MLP_LOSS_PARTIALS);
+    const size_t nel = (size_t)B * dims[n_layers];
+    const float inv_n = 1.0f / (float)nel;
+    // forward, keeping h_l and z_l; the LAST layer's epilogue forms the loss gradient seed g = (2 / n) (v - u) and one
+    // loss partial per workgroup (round 6: the MSE was a launch of its own and a second pass over v)
     const float* cur = xt;
+    int n_lpart = MSE_BLOCKS;
+    bool mse_fused = false;
     for (int l = 0; l < n_layers; ++l) {
         const bool last = (l == n_layers - 1);
         const bool first_t = (l == 0 && has_t);
         const int K = first_t ? dims[0] - 1 : dims[l];
         float* dst = last ? g : hidden[l];
-        int rc = cfm_mlp_launch_layer(cur, K, W[l], dims[l], b[l], first_t ? t : nullptr, first_t ? 1 : 0, first_t ? K : -1,
+        int rc;
+        const long last_wgs = (long)((B + 63) / 64) * ((dims[l + 1] + 63) / 64);      // (an upper bound: the 128 x 128 form has fewer)
+        if (last && last_wgs <= MLP_LOSS_PARTIALS) {
+            rc = cfm_mlp_launch_layer_mse(cur, K, W[l], dims[l], b[l], first_t ? t : nullptr, first_t ? 1 : 0, first_t ? K : -1,
+                                          B, K, dims[l + 1], dst, s, ut, 2.0f * inv_n, inv_n, lpart, &n_lpart);
+            mse_fused = true;
+        } else {
+            rc = cfm_mlp_launch_layer(cur, K, W[l], dims[l], b[l], first_t ? t : nullptr, first_t ? 1 : 0, first_t ? K : -1,
                                       B, K, dims[l + 1], dst, !last, s, last ? nullptr : preact[l]);
+        }
         if (rc) return rc;
         cur = dst;
     }
-    // loss + its gradient seed
-    int maxw = 0; size_t maxp = 0;
-    for (int l = 0; l <= n_layers; ++l) maxw = dims[l] > maxw ? dims[l] : maxw;
-    for (int l = 0; l < n_layers; ++l) { const size_t p = (size_t)dims[l] * dims[l + 1]; maxp = p > maxp ? p : maxp; }
-    float* lpart = (float*)((char*)ws + cfm_mlp_train_ws_bytes_internal(B, maxw, (int)maxp) - 2048);   // MSE_BLOCKS floats
-    const size_t nel = (size_t)B * dims[n_layers];
-    const float inv_n = 1.0f / (float)nel;
-    hipLaunchKernelGGL(mse_grad, dim3(MSE_BLOCKS), dim3(256), 0, s, g, ut, nel, 2.0f * inv_n, inv_n, lpart);
-    int rc = cfm_status();
-    if (rc) return rc;
+    if (!mse_fused) {
+        hipLaunchKernelGGL(mse_grad, dim3(MSE_BLOCKS), dim3(256), 0, s, g, ut, nel, 2.0f * inv_n, inv_n, lpart);
+        const int rc = cfm_status();
+        if (rc) return rc;
+    }
     // backward (+ the loss partials in its final reduction)
     const float* acts[MLP_MAX_LAYERS]; const float* zs[MLP_MAX_LAYERS];
     acts[0] = xt; zs[0] = nullptr;
     for (int l = 1; l < n_layers; ++l) { acts[l] = hidden[l - 1]; zs[l] = preact[l - 1]; }
-    const ReduceJob lj = ReduceJob{lpart, loss, 1ull, 1ull, MSE_BLOCKS, 0, 0, 0};
+    const ReduceJob lj = ReduceJob{lpart, loss, 1ull, 1ull, n_lpart, 0, 0, 1};      // (pad = 1: one number out of n_lpart partials)
     return mlp_backward_impl(acts, zs, W, dims, n_layers, B, g, dW, db, nullptr, ws, s, has_t ? t : nullptr, &lj, layer_done);
 }
 
