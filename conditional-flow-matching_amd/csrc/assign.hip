@@ -2223,7 +2223,7 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
         Q.theta = P.theta; Q.eps0_frac = P.eps0_frac; Q.eps_last_frac = P.eps_last_frac;
         Q.stop_frac = P.stop_frac;
         Q.round_cap = P.round_cap; Q.arr_cap = P.arr_cap > 15 ? P.arr_cap : 15; Q.total_cap = 20000;   // (the one-workgroup solver was tuned with 15)
-        Q.bid_cap = P.small >= 2 ? P.small - 1 : 1;      // cfm_assign_set_small(k >= 2): k - 1 bids per wave and round
+        Q.reserved = 0;
         int* status = (int*)ws;
         rc0 = cfm_hip(hipMemsetAsync(status, 0, 64, s));
         if (rc0) return rc0;

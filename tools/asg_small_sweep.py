@@ -31,13 +31,21 @@ def timeit(M):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / 10 * 1e6
 
 
-print("config: " + " ".join(k for k, _ in inst) + " | sum")
-for theta in (3.0, 5.0, 8.0, 12.0, 20.0):
-    for eps0 in (2e-3, 8e-3, 3e-2):
-        for cap in (1, 2):
-            lib.cfm_assign_set_params(theta, eps0, 0, -1, 0, -1, 0); lib.cfm_assign_set_small(cap + 1 if cap > 1 else 1)
-            ts = []
-            for k, M in inst:
-                ts.append(timeit(M))
-                assert torch.equal(ot.assign_exact(M).cpu(), ref[k]), (k, theta, eps0)
-            print(f"theta {theta:4.0f} eps0 {eps0:.0e} cap {cap}: " + " ".join(f"{t:5.0f}" for t in ts) + f" | {sum(ts):6.0f}")
+def stats():
+    buf = (ctypes.c_int * 16)(); lib.cfm_assign_debug_small(buf); return list(buf)
+
+
+print("config: " + " ".join(k for k, _ in inst) + " | sum | free rows per instance")
+grid = [(th, e0, el, sf, ac) for th in (3.0, 5.0, 8.0) for e0 in (8e-3,) for el in (1e-6,) for sf in (0.02,) for ac in (15,)]
+grid += [(5.0, 8e-3, el, 0.02, 15) for el in (3e-7, 3e-6, 1e-5)]
+grid += [(5.0, 8e-3, 1e-6, sf, 15) for sf in (0.0, 0.01, 0.05)]
+grid += [(5.0, 8e-3, 1e-6, 0.02, ac) for ac in (30, 60)]
+grid += [(5.0, e0, 1e-6, 0.02, 15) for e0 in (2e-3, 3e-2)]
+grid += [(8.0, 8e-3, 3e-7, 0.01, 30), (3.0, 8e-3, 3e-7, 0.01, 30)]
+for theta, eps0, el, sf, ac in grid:
+    lib.cfm_assign_set_params(theta, eps0, el, sf, 0, ac, 0)
+    ts, fr = [], []
+    for k, M in inst:
+        ts.append(timeit(M)); fr.append(stats()[2])
+        assert torch.equal(ot.assign_exact(M).cpu(), ref[k]), (k, theta, eps0)
+    print(f"theta {theta:3.0f} eps0 {eps0:.0e} last {el:.0e} stop {sf:.2f} arr {ac:2d}: " + " ".join(f"{t:5.0f}" for t in ts) + f" | {sum(ts):6.0f} | " + " ".join(str(f) for f in fr))
