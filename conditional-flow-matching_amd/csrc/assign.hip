@@ -2220,7 +2220,8 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
         int rc0 = asg_pinned();
         if (rc0) return rc0;
         SmaParams Q;
-        Q.theta = P.theta; Q.eps0_frac = P.eps0_frac; Q.eps_last_frac = P.eps_last_frac;
+        Q.theta = P.async_theta;            // (its epsilon phases are asynchronous since round 6: theta 2-3 measured 10 % ahead of 5, tools/asg_small_sweep.py)
+        Q.eps0_frac = P.eps0_frac; Q.eps_last_frac = P.eps_last_frac;
         Q.stop_frac = P.stop_frac;
         Q.round_cap = P.round_cap; Q.arr_cap = P.arr_cap > 15 ? P.arr_cap : 15; Q.total_cap = 20000;   // (the one-workgroup solver was tuned with 15)
         Q.reserved = 0;

@@ -45,10 +45,6 @@
 #define SMA_NW (SMA_T / 64)
 #define SMA_NH (SMA_T / 32)     // half-waves = row owners
 #define SMA_N 256
-#define SMA_NS 8            // searches in flight (phase C)
-#ifndef SMA_NB
-#define SMA_NB SMA_NS
-#endif
 #define SMA_OB 9            // owner bits of a phase A object word (owner + 1; 0 = none)
 #define SMA_RB 8            // row id bits of a phase B object word
 #define SMA_QB 6            // round bits (epsilon = 0 rounds)
@@ -64,24 +60,20 @@ struct alignas(16) SmaShared {
     unsigned long long key[SMA_N];      // phase A: price << 9 | owner + 1;  phase B: price << 14 | round << 8 | row
     double pd[SMA_N];                   // prices (integer valued): live copy in phase A, the round's snapshot in phase B
     double u[SMA_N];                    // row duals (phase C)
-    double dist[SMA_NS][SMA_N];         // search labels (one set per search in flight)
+    double dist[SMA_N];                 // search labels
     unsigned pi[SMA_N];                 // phase A: copies of the prices on the grid of the integer codes
     short arow[SMA_N];                  // row -> column or -1
     short bidcol[SMA_N];                // row -> column it bid for in this round or -1 (phase B)
     short colrow[SMA_N];                // column -> row or -1 (phase C)
-    short pred[SMA_NS][SMA_N];          // column -> row that labelled it
+    short pred[SMA_N];                  // column -> row that labelled it
     short freelist[SMA_N];
-    unsigned char done[SMA_NS][SMA_N];  // column closed by the search
-    unsigned char cm[SMA_N];            // columns closed by the searches of this batch that were applied
+    unsigned char done[SMA_N];          // column closed by the search
     unsigned fm[2][SMA_NH];             // phase B, per half-wave: bit r = row (half + 32 r) is unmatched
     int nfree[2];
+    unsigned pmin[2];                   // phase A: the lowest price at the end of a phase (even / odd phases)
     int actl[4];                        // phase A: [0] objects without an owner, [1] cut flag, [2] bids, [3] a wave passed its total cap
-    int snext[SMA_NS];                  // per search: the row to scan next or -1
-    int sfound[SMA_NS];                 // the free column it reached or -1
-    int serr[SMA_NS];
-    double sbase[SMA_NS];               // label of the row to scan next
-    double sdfin[SMA_NS];               // shortest path length
-    int ctl[8];                         // [3] free rows, [4] certificate, [5] a search overlaps an applied one
+    double ctld[4];                     // search hand-over: [0] label of the next row, [1] shortest path length
+    int ctl[8];                         // search hand-over: [0] next row or -1, [1] found column, [2] error; [3] free rows, [4] certificate
     unsigned long long red[SMA_NW + 2];
     double redd[2 * SMA_NW + 2];
 };
@@ -220,6 +212,16 @@ __device__ __forceinline__ float sma_entry(const float (&c)[8], int j, int lane)
     return __int_as_float(__builtin_amdgcn_ds_bpermute(4 * ((j >> 3) + (lane & 32)), __float_as_int(v)));
 }
 
+// LDS atomics without a result, as single instructions: the compiler's atomic optimiser wraps an atomicOr / atomicAnd /
+// atomicSub whose result is unused in a wave-wide reduction (mbcnt, DPP scan, readlane: ~40 instructions) — two lanes
+// of a wave issue these, with different addresses.
+__device__ __forceinline__ unsigned sma_lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
+__device__ __forceinline__ void sma_lds_or(unsigned* p, unsigned v) { asm volatile("ds_or_b32 %0, %1" :: "v"(sma_lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void sma_lds_and(unsigned* p, unsigned v) { asm volatile("ds_and_b32 %0, %1" :: "v"(sma_lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void sma_lds_dec(int* p) { asm volatile("ds_sub_u32 %0, %1" :: "v"(sma_lds_addr(p)), "v"(1u) : "memory"); }
+__device__ __forceinline__ void sma_lds_minu(unsigned* p, unsigned v) { asm volatile("ds_min_u32 %0, %1" :: "v"(sma_lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void sma_lds_max(int* p, int v) { asm volatile("ds_max_i32 %0, %1" :: "v"(sma_lds_addr(p)), "v"(v) : "memory"); }
+
 // whole-wave minimum of a u32 (6 DPP steps), uniform result
 __device__ __forceinline__ unsigned sma_wave_min_u32(unsigned x) {
     asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -232,11 +234,11 @@ __device__ __forceinline__ unsigned sma_wave_min_u32(unsigned x) {
     return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
-// One Dijkstra scan of search sx by the WAVE whose half (row & 1) holds `row`: the other half takes columns 4..7 of every lane of
+// One Dijkstra scan by the WAVE whose half (row & 1) holds `row`: the other half takes columns 4..7 of every lane of
 // the owner (v_permlane32_swap_b32: lanes 32..63 of the first operand <-> lanes 0..31 of the second), so a lane relaxes
 // 4 columns as in the whole-wave layout; the nearest open column is closed and the search handed to the row matched
 // to it (or the free column reached is reported).
-__device__ __forceinline__ void sma_scan(SmaShared& sh, int sx, const float4& ca, const float4& cb, int row, double mcs, double S, int lane) {
+__device__ __forceinline__ void sma_scan(SmaShared& sh, const float4& ca, const float4& cb, int row, double mcs, double S, int lane) {
     const int hl = lane & 31, oh = row & 1;
     const bool mine = (lane >> 5) == oh;
     float c[4];
@@ -250,12 +252,12 @@ __device__ __forceinline__ void sma_scan(SmaShared& sh, int sx, const float4& ca
         }
     }
     const int cb0 = 8 * hl + (mine ? 0 : 4);
-    const double base = sma_ud(sh.sbase[sx]), ur = sma_ud(sh.u[row]);
+    const double base = sma_ud(sh.ctld[0]), ur = sma_ud(sh.u[row]);
     const double2 pa = *reinterpret_cast<const double2*>(&sh.pd[cb0]);
     const double2 pb = *reinterpret_cast<const double2*>(&sh.pd[cb0 + 2]);
-    const double2 da = *reinterpret_cast<const double2*>(&sh.dist[sx][cb0]);
-    const double2 db = *reinterpret_cast<const double2*>(&sh.dist[sx][cb0 + 2]);
-    const unsigned dn = *reinterpret_cast<const unsigned*>(&sh.done[sx][cb0]);
+    const double2 da = *reinterpret_cast<const double2*>(&sh.dist[cb0]);
+    const double2 db = *reinterpret_cast<const double2*>(&sh.dist[cb0 + 2]);
+    const unsigned dn = *reinterpret_cast<const unsigned*>(&sh.done[cb0]);
     const short4 cr = *reinterpret_cast<const short4*>(&sh.colrow[cb0]);      // (not behind the reduction: one LDS round trip less)
     double d[4] = {da.x, da.y, db.x, db.y};
     // (reduced costs are >= 0 up to rounding: after a dual update a label can come out a few ulps below zero when
@@ -263,29 +265,37 @@ __device__ __forceinline__ void sma_scan(SmaShared& sh, int sx, const float4& ca
     //  clamped here, exactly as the chip-wide relax rounds clamp theirs)
     const double nd[4] = {base + fmax((sma_c(c[0], mcs, S) + pa.x) - ur, 0.0), base + fmax((sma_c(c[1], mcs, S) + pa.y) - ur, 0.0),
                           base + fmax((sma_c(c[2], mcs, S) + pb.x) - ur, 0.0), base + fmax((sma_c(c[3], mcs, S) + pb.y) - ur, 0.0)};
+    // (selects, not branches: the four columns' arithmetic interleaves; only the LDS writes sit under a lane mask)
     double b1 = INFINITY; int k1 = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const bool open = ((dn >> (8 * k)) & 0xffu) == 0u;
-        if (open && nd[k] < d[k]) { d[k] = nd[k]; sh.dist[sx][cb0 + k] = nd[k]; sh.pred[sx][cb0 + k] = (short)row; }
-        if (open && d[k] < b1) { b1 = d[k]; k1 = k; }
+        const bool imp = open && nd[k] < d[k];
+        d[k] = imp ? nd[k] : d[k];
+        if (imp) { sh.dist[cb0 + k] = nd[k]; sh.pred[cb0 + k] = (short)row; }
+        const bool bet = open && d[k] < b1;
+        b1 = bet ? d[k] : b1; k1 = bet ? k : k1;
     }
-    // (labels are >= 0 or +inf)
+    // (labels are >= 0 or +inf: the bits order like the values.)  The high words decide unless two lanes agree in sign,
+    // exponent and 20 mantissa bits: one reduction instead of two for nearly every scan.
     const unsigned vh = (unsigned)__double2hiint(b1), vl = (unsigned)__double2loint(b1);
     const unsigned mh = sma_wave_min_u32(vh);
-    const unsigned ml = sma_wave_min_u32(vh == mh ? vl : 0xffffffffu);
-    const double w1 = __hiloint2double((int)mh, (int)ml);
-    const unsigned long long ball = __ballot(b1 == w1);
+    unsigned long long ball = __ballot(vh == mh);
+    if (__popcll(ball) > 1) {
+        const unsigned ml = sma_wave_min_u32(vh == mh ? vl : 0xffffffffu);
+        ball = __ballot(vh == mh && vl == ml);
+    }
     const int win = __builtin_amdgcn_readfirstlane(__ffsll((long long)ball) - 1);
+    const double w1 = __hiloint2double((int)mh, __builtin_amdgcn_readlane((int)vl, win));
     const int js = __builtin_amdgcn_readlane(cb0 + k1, win);
     const int crk = k1 == 0 ? cr.x : k1 == 1 ? cr.y : k1 == 2 ? cr.z : cr.w;
     const int nr = __builtin_amdgcn_readlane(crk, win);
     if (lane == 0) {
-        if (!(w1 < INFINITY)) { sh.snext[sx] = -1; sh.serr[sx] = 1; }
+        if (!(w1 < INFINITY)) { sh.ctl[0] = -1; sh.ctl[2] = 1; }
         else {
-            sh.done[sx][js] = 1;
-            if (nr < 0) { sh.snext[sx] = -1; sh.sfound[sx] = js; sh.sdfin[sx] = w1; }
-            else { sh.snext[sx] = nr; sh.sbase[sx] = w1; }
+            sh.done[js] = 1;
+            if (nr < 0) { sh.ctl[0] = -1; sh.ctl[1] = js; sh.ctld[1] = w1; }
+            else { sh.ctl[0] = nr; sh.ctld[0] = w1; }
         }
     }
 }
@@ -311,15 +321,6 @@ __device__ __forceinline__ void sma_hmin2_u32(unsigned x, unsigned& a, unsigned&
     a = (unsigned)__builtin_amdgcn_readlane((int)x, 31); b = (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
-// LDS atomics without a result, as single instructions: the compiler's atomic optimiser wraps an atomicOr / atomicAnd /
-// atomicSub whose result is unused in a wave-wide reduction (mbcnt, DPP scan, readlane: ~40 instructions) — two lanes
-// of a wave issue these, with different addresses.
-__device__ __forceinline__ unsigned sma_lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
-__device__ __forceinline__ void sma_lds_or(unsigned* p, unsigned v) { asm volatile("ds_or_b32 %0, %1" :: "v"(sma_lds_addr(p)), "v"(v) : "memory"); }
-__device__ __forceinline__ void sma_lds_and(unsigned* p, unsigned v) { asm volatile("ds_and_b32 %0, %1" :: "v"(sma_lds_addr(p)), "v"(v) : "memory"); }
-__device__ __forceinline__ void sma_lds_dec(int* p) { asm volatile("ds_sub_u32 %0, %1" :: "v"(sma_lds_addr(p)), "v"(1u) : "memory"); }
-__device__ __forceinline__ void sma_lds_max(int* p, int v) { asm volatile("ds_max_i32 %0, %1" :: "v"(sma_lds_addr(p)), "v"(v) : "memory"); }
-
 // One bid of row slot r of the two halves of a wave (act: this lane's half has an unmatched row in the slot; ca / cb: the
 // slot's codes — STATIC registers, the caller unrolls over the slots).  The lane's 8 price copies are read, value = code +
 // price, top-2 per lane (min / med3), the halves' best (5 DPP steps), the object's word is read while the second
@@ -329,10 +330,12 @@ __device__ __forceinline__ void sma_lds_max(int* p, int v) { asm volatile("ds_ma
 // order, so a displaced row's bit is always set after its own clear.  Objects without an owner are counted down by the
 // first award: actl[0] = unmatched rows.
 __device__ __forceinline__ void sma_async_bid(SmaShared& sh, const float4& ca, const float4& cb, int r, bool act, unsigned eps,
-                                              int lane, int hb, int& nbids) {
+                                              int lane, int hb, int& nbids, uint4 qa, uint4 qb, bool fresh) {
     const int hi = lane >> 5, hl = lane & 31;
-    const uint4 qa = *reinterpret_cast<const uint4*>(&sh.pi[8 * hl]);
-    const uint4 qb = *reinterpret_cast<const uint4*>(&sh.pi[8 * hl + 4]);
+    if (!fresh) {                        // (the first bid of a pass uses the copies read with the pass's masks: one round trip less)
+        qa = *reinterpret_cast<const uint4*>(&sh.pi[8 * hl]);
+        qb = *reinterpret_cast<const uint4*>(&sh.pi[8 * hl + 4]);
+    }
     const unsigned v[8] = {__float_as_uint(ca.x) + qa.x, __float_as_uint(ca.y) + qa.y, __float_as_uint(ca.z) + qa.z, __float_as_uint(ca.w) + qa.w,
                            __float_as_uint(cb.x) + qb.x, __float_as_uint(cb.y) + qb.y, __float_as_uint(cb.z) + qb.z, __float_as_uint(cb.w) + qb.w};
     unsigned b1 = min(v[0], v[1]), b2 = max(v[0], v[1]);
@@ -380,8 +383,10 @@ __device__ __forceinline__ int sma_async_phase(SmaShared& sh, const float4 (&m)[
         asm volatile("" ::: "memory");
         const int2 ac = *reinterpret_cast<const int2*>(&sh.actl[0]);
         const uint2 fw = *reinterpret_cast<const uint2*>(&sh.fm[0][2 * wv]);
-        // (both loads in flight before the first branch: the compiler sinks a load behind the branch that needs it)
-        asm volatile("" :: "v"(ac.x), "v"(fw.x));
+        const uint4 qa = *reinterpret_cast<const uint4*>(&sh.pi[8 * (lane & 31)]);
+        const uint4 qb = *reinterpret_cast<const uint4*>(&sh.pi[8 * (lane & 31) + 4]);
+        // (all loads in flight before the first branch: the compiler sinks a load behind the branch that needs it)
+        asm volatile("" :: "v"(ac.x), "v"(fw.x), "v"(qa.x), "v"(qb.x));
         const int nf = __builtin_amdgcn_readfirstlane(ac.x), cut = __builtin_amdgcn_readfirstlane(ac.y);
         if (nf <= stop || cut) break;
         if (it > 64 * P.round_cap) { if (lane == 0) sma_lds_max(&sh.actl[1], 1); break; }      // (64 per bid, 1 per look without one)
@@ -389,11 +394,13 @@ __device__ __forceinline__ int sma_async_phase(SmaShared& sh, const float4 (&m)[
         const unsigned mm = m0 | m1;
         if (!mm) { ++it; __builtin_amdgcn_s_sleep(1); continue; }
         const unsigned mine = hi ? m1 : m0;
+        bool fresh = true;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (!((mm >> r) & 1u)) continue;
             it += 64;
-            sma_async_bid(sh, m[2 * r], m[2 * r + 1], r, ((mine >> r) & 1u) != 0u, eps, lane, hb, nbids);
+            sma_async_bid(sh, m[2 * r], m[2 * r + 1], r, ((mine >> r) & 1u) != 0u, eps, lane, hb, nbids, qa, qb, fresh);
+            fresh = false;
         }
     }
     return it;
@@ -452,6 +459,7 @@ __global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mra
     if (tid < 2 * SMA_NH) (&sh.fm[0][0])[tid] = 0u;
     if (tid < 2) sh.nfree[tid] = 0;
     if (tid < 4) sh.actl[tid] = 0;
+    if (tid < 2) sh.pmin[tid] = 0xffffffffu;
     {
         const double a = asg_wave_min_d((double)lmin), b = -asg_wave_min_d(-(double)lmax);
         if (lane == 0) { sh.redd[wv] = a; sh.redd[SMA_NW + wv] = b; }
@@ -541,11 +549,19 @@ __global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mra
         sma_sync();
         const int over = sma_ui(sh.actl[3]), cutv = sma_ui(sh.actl[1]);
         st_cut += cutv;
-        // phase end: price copies from the words (a copy may be behind), every row unmatched again
+        // phase end: the lowest price is taken off every price (the auction only sees differences; the spread of the prices
+        // stays below range + epsilon, but every phase lifts them all — with 2 or 3 columns, by the cost range per phase:
+        // unshifted they left the 32-bit window after 7 phases)
+        const int par = (st_auction - 1) & 1;
+        if (tid < n) sma_lds_minu(&sh.pmin[par], (unsigned)(sh.key[tid] >> SMA_OB));
+        if (tid == 0) sh.pmin[par ^ 1] = 0xffffffffu;
+        sma_sync();
+        // price copies from the words (a copy may be behind), every row unmatched again
         const double e2 = eps / P.theta;
         const bool last = e2 < eps_last;
         if (tid < SMA_N) {
-            const unsigned long long pr = sh.key[tid] >> SMA_OB;
+            const unsigned pm = sh.pmin[par];
+            const unsigned long long pr = (sh.key[tid] >> SMA_OB) - (tid < n ? pm : 0u);
             pi[tid] = (unsigned)pr;
             sh.key[tid] = pr << SMA_OB;
             sh.arow[tid] = -1;
@@ -618,7 +634,7 @@ __global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mra
 
     const unsigned long long tk2 = wall_clock64();
     // ---- phase C entry: duals u_i = min_k (C_ik + p_k); a matched row keeps its column iff that pair is tight
-    int st_free = 0, st_searches = 0, st_sscans = 0, st_steps = 0, st_redo = 0;
+    int st_free = 0, st_searches = 0;
     if (!err) {
         double p[8];
         sma_prices_d(sh, hl, p);
@@ -668,111 +684,63 @@ __global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mra
     }
 
     const unsigned long long tk3 = wall_clock64();
-    // ---- phase C: shortest augmenting paths, up to SMA_NS searches in flight.
-    // A scan is one wave's work between two barriers (~0.6 us) and a search is a chain of ~50 of them at C1: the searches
-    // of a batch run in lockstep from the SAME duals, each with its own labels, on whichever waves hold their rows.  They
-    // are then applied in order: a search whose closed columns are disjoint from those of the searches applied before it
-    // in the batch is exactly what it would have been after them (their dual updates only RAISE prices of their own
-    // closed columns, which this search never closed: it only saw labels >= its path length there, and they can only
-    // grow; the rows it scanned are matched to its own closed columns); one that overlaps is run again in a later batch.
-    int nfl = st_free, f0 = 0;
-    while (f0 < nfl && !err) {
-        const int nb = min(SMA_NB, nfl - f0);
-        if (tid < SMA_N) {
-            for (int q = 0; q < nb; ++q) { sh.dist[q][tid] = INFINITY; sh.done[q][tid] = 0; }
-            sh.cm[tid] = 0;
-        }
-        if (tid < SMA_NS) {
-            sh.snext[tid] = tid < nb ? (int)sh.freelist[f0 + tid] : -1;
-            sh.sfound[tid] = -1; sh.serr[tid] = 0; sh.sbase[tid] = 0.0;
-        }
-        if (tid == 0) sh.ctl[5] = 0;
-        // the roots' duals from the current prices
-        for (int q = 0; q < nb; ++q) {
-            const int root = sma_ui(sh.freelist[f0 + q]);
-            if (wv == ((root & 31) >> 1)) {
-                float4 ca, cb;
-                sma_pick1(SMA_M16(m), __builtin_amdgcn_readfirstlane(root >> 5), ca, cb);
-                const float c[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-                double p[8], lm = INFINITY;
-                sma_prices_d(sh, hl, p);
+    // ---- phase C: one shortest augmenting path per free row.
+    // (Round 6 measured the alternatives at C1, 8 instances: up to 8 searches in lockstep from the same duals, applied when
+    //  their closed columns are disjoint: 63 % are not, and a batch is as long as its longest search — no gain; all roots
+    //  at once with label-correcting sweeps (no reduction, no hand-over, every half-wave relaxing side by side): 74 sweeps
+    //  of 3 barriers and ~3 600 row relaxations against ~450 scans — 0.55 ms against 0.41.)
+    int st_sscans = 0;
+    for (int f = 0; f < st_free && !err; ++f) {
+        const int root = sma_ui(sh.freelist[f]);
+        if (tid < SMA_N) { sh.dist[tid] = INFINITY; sh.done[tid] = 0; }
+        if (tid == 0) { sh.ctl[0] = root; sh.ctl[1] = -1; sh.ctl[2] = 0; sh.ctld[0] = 0.0; }
+        if (wv == ((root & 31) >> 1)) {       // the root's dual from the current prices
+            float4 ca, cb;
+            sma_pick1(SMA_M16(m), root >> 5, ca, cb);
+            const float c[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+            double p[8], lm = INFINITY;
+            sma_prices_d(sh, hl, p);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) lm = fmin(lm, sma_c(c[k], mcs, S) + p[k]);
-                const double ui = sma_hmin_pos(lm, hi);
-                if (lane == ((root & 1) << 5)) sh.u[root] = ui;
-            }
+            for (int k = 0; k < 8; ++k) lm = fmin(lm, sma_c(c[k], mcs, S) + p[k]);
+            const double ui = sma_hmin_pos(lm, hi);
+            if (lane == ((root & 1) << 5)) sh.u[root] = ui;
         }
         sma_sync();
-        st_searches += nb;
+        ++st_searches;
         int guard = 0;
         for (;;) {
-            // the rows the searches want scanned; mine = those my wave holds
-            const int4 xa = *reinterpret_cast<const int4*>(&sh.snext[0]);
-            const int4 xb = *reinterpret_cast<const int4*>(&sh.snext[4]);
-            const int nx[8] = {__builtin_amdgcn_readfirstlane(xa.x), __builtin_amdgcn_readfirstlane(xa.y), __builtin_amdgcn_readfirstlane(xa.z),
-                               __builtin_amdgcn_readfirstlane(xa.w), __builtin_amdgcn_readfirstlane(xb.x), __builtin_amdgcn_readfirstlane(xb.y),
-                               __builtin_amdgcn_readfirstlane(xb.z), __builtin_amdgcn_readfirstlane(xb.w)};
-            unsigned live = 0u, todo = 0u;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (nx[q] >= 0) { live |= 1u << q; if (((nx[q] & 31) >> 1) == wv) todo |= 1u << q; }
-            }
-            if (!live) break;
+            const int row = sma_ui(sh.ctl[0]);
+            if (row < 0) break;
             if (++guard > n + 2) { err = 2; break; }
-            while (todo) {
-                const int q = __ffs((int)todo) - 1;
-                todo &= todo - 1u;
-                int row = nx[0];
-#pragma unroll
-                for (int t = 1; t < 8; ++t) row = q == t ? nx[t] : row;
+            if (wv == ((row & 31) >> 1)) {
                 // one code copy per row slot (static registers)
                 switch (row >> 5) {
-#define SMA_CASE(R) case R: sma_scan(sh, q, m[2 * R], m[2 * R + 1], row, mcs, S, lane); break;
+#define SMA_CASE(R) case R: sma_scan(sh, m[2 * R], m[2 * R + 1], row, mcs, S, lane); break;
                     SMA_CASE(0) SMA_CASE(1) SMA_CASE(2) SMA_CASE(3) SMA_CASE(4) SMA_CASE(5) SMA_CASE(6)
-                    default: sma_scan(sh, q, m[14], m[15], row, mcs, S, lane); break;
+                    default: sma_scan(sh, m[14], m[15], row, mcs, S, lane); break;
 #undef SMA_CASE
                 }
             }
-            st_scans += __popc(live); st_sscans += __popc(live); ++st_steps;
+            ++st_scans; ++st_sscans;
             sma_sync();
         }
         if (err) break;
-        // apply the searches in order
-        for (int q = 0; q < nb && !err; ++q) {
-            const int root = sma_ui(sh.freelist[f0 + q]);
-            const int jfree = sma_ui(sh.sfound[q]);
-            if (sma_ui(sh.serr[q]) || jfree < 0) { err = 2; break; }
-            if (tid < SMA_N && sh.done[q][tid] && sh.cm[tid]) sh.ctl[5] = 1;
-            sma_sync();
-            const int rej = sma_ui(sh.ctl[5]);
-            sma_sync();
-            if (rej) {
-                if (nfl >= SMA_N) { err = 2; break; }
-                if (tid == 0) { sh.freelist[nfl] = (short)root; sh.ctl[5] = 0; }
-                ++nfl; ++st_redo;
-            } else {
-                const double dfin = sma_ud(sh.sdfin[q]);
-                // dual update of the scanned columns, then the augmentation (one thread: the path is a chain)
-                if (tid < SMA_N && sh.done[q][tid]) {
-                    sh.cm[tid] = 1;
-                    if (tid != jfree) sh.pd[tid] = sh.pd[tid] + (dfin - sh.dist[q][tid]);
-                }
-                if (tid == 0) {
-                    int j = jfree, hops = 0;
-                    for (;;) {
-                        const int i = sh.pred[q][j];
-                        const int jn = sh.arow[i];
-                        sh.arow[i] = (short)j; sh.colrow[j] = (short)i;
-                        if (i == root || ++hops > n) break;
-                        j = jn;
-                    }
-                }
+        const int jfree = sma_ui(sh.ctl[1]);
+        if (sma_ui(sh.ctl[2]) || jfree < 0) { err = 2; break; }
+        const double dfin = sma_ud(sh.ctld[1]);
+        // dual update of the scanned columns, then the augmentation (one thread: the path is a chain)
+        if (tid < SMA_N && sh.done[tid] && tid != jfree) sh.pd[tid] = sh.pd[tid] + (dfin - sh.dist[tid]);
+        if (tid == 0) {
+            int j = jfree, hops = 0;
+            for (;;) {
+                const int i = sh.pred[j];
+                const int jn = sh.arow[i];
+                sh.arow[i] = (short)j; sh.colrow[j] = (short)i;
+                if (i == root || ++hops > n) break;
+                j = jn;
             }
-            sma_sync();
         }
-        if (err) break;
-        f0 += nb;
-        if (st_searches > 4 * n) { err = 2; break; }
+        sma_sync();
         // duals of the matched rows from the new prices: u_i = C_{i a_i} + p_{a_i}
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -849,7 +817,7 @@ __global__ __launch_bounds__(SMA_T) void asg_small(const float* __restrict__ Mra
         // phase times in 10 ns ticks: load + init, bid phases, convert, searches, certificate
         status[4] = (int)(tk1 - tk0); status[5] = (int)(tk2 - tk1); status[6] = (int)(tk3 - tk2); status[7] = (int)(tk4 - tk3);
         status[8] = (int)(wall_clock64() - tk4);
-        status[9] = bids; status[10] = st_auction; status[11] = st_arr; status[12] = st_cut | (st_redo << 8) | (st_steps << 16); status[13] = st_searches; status[14] = st_sscans; status[15] = (int)(tk1b - tk1);
+        status[9] = bids; status[10] = st_auction; status[11] = st_arr; status[12] = st_cut; status[13] = st_searches; status[14] = st_sscans; status[15] = (int)(tk1b - tk1);
         __threadfence_system();
         status[0] = err ? -err : 1;
     }

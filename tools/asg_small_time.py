@@ -13,7 +13,7 @@ def run(name, M):
     for _ in range(20): ot.assign_exact(M)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20 * 1e6
     buf = (ctypes.c_int * 16)(); lib.cfm_assign_debug_small(buf); b = list(buf)
-    print(f"{name}: {dt:.0f} us | looks {b[1]} bids {b[9]} phases {b[10]} cut {b[12] & 255} redo {(b[12] >> 8) & 255} steps {b[12] >> 16} searches {b[13]} arr {b[11]} free {b[2]} scans {b[3]} search scans {b[14]} | phase A {b[15]/100:.0f} us | load+init {b[4]/100:.0f} bid {b[5]/100:.0f} convert {b[6]/100:.0f} search {b[7]/100:.0f} cert {b[8]/100:.0f} us")
+    print(f"{name}: {dt:.0f} us status {b[0]} | looks {b[1]} bids {b[9]} phases {b[10]} cut {b[12]} searches {b[13]} search scans {b[14]} arr {b[11]} free {b[2]} scans {b[3]} | phase A {b[15]/100:.0f} us | load+init {b[4]/100:.0f} bid {b[5]/100:.0f} convert {b[6]/100:.0f} search {b[7]/100:.0f} cert {b[8]/100:.0f} us")
 x0, x1 = oracle.config_inputs("C1")
 run("C1 (256, d=2)", ot.cost_matrix(x0.to(dev), x1.to(dev), matrix_cores=False))
 for n, d in ((256, 784), (128, 2), (128, 784), (64, 2)):

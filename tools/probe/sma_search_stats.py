@@ -16,6 +16,6 @@ for rep in range(12):
     for M in Ms:
         ot.assign_exact(M); torch.cuda.synchronize()
         buf = (ctypes.c_int * 16)(); lib.cfm_assign_debug_small(buf); b = list(buf)
-        acc += np.array([b[2], b[13], b[14], b[12] >> 16, (b[12] >> 8) & 255, b[15] / 100, (b[5] - b[15]) / 100, b[7] / 100, b[9], (b[4] + b[5] + b[6] + b[7] + b[8]) / 100]); cnt += 1
+        acc += np.array([b[2], b[13], b[14], 0, 0, b[15] / 100, (b[5] - b[15]) / 100, b[7] / 100, b[9], (b[4] + b[5] + b[6] + b[7] + b[8]) / 100]); cnt += 1
 m = acc / cnt
-print(f"free {m[0]:.2f} searches {m[1]:.2f} scans {m[2]:.1f} steps {m[3]:.1f} redo {m[4]:.2f} | phase A {m[5]:.0f} us B {m[6]:.0f} us search {m[7]:.0f} us | bids {m[8]:.0f} | kernel {m[9]:.0f} us")
+print(f"free {m[0]:.2f} searches {m[1]:.2f} scans {m[2]:.1f} | phase A {m[5]:.0f} us B {m[6]:.0f} us search {m[7]:.0f} us | bids {m[8]:.0f} | kernel {m[9]:.0f} us")
