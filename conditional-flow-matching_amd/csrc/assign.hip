@@ -2225,10 +2225,7 @@ extern "C" int cfm_assign_exact_f32(const float* M, int B, int* perm, int* certi
         Q.stop_frac = P.stop_frac;
         Q.round_cap = P.round_cap; Q.arr_cap = P.arr_cap > 15 ? P.arr_cap : 15; Q.total_cap = 20000;   // (the one-workgroup solver was tuned with 15)
         Q.reserved = 0;
-        int* status = (int*)ws;
-        rc0 = cfm_hip(hipMemsetAsync(status, 0, 64, s));
-        if (rc0) return rc0;
-        if (certified) { rc0 = cfm_hip(hipMemsetAsync(certified, 0, sizeof(int), s)); if (rc0) return rc0; }
+        int* status = (int*)ws;            // (the kernel clears `certified` and writes every word of the status block itself)
         hipLaunchKernelGGL(asg_small, dim3(1), dim3(SMA_T), 0, s, M, B, Q, perm, certified, total_cost, stats, status);
         rc0 = cfm_status();
         if (rc0) return rc0;

@@ -36,11 +36,8 @@ def stats():
 
 
 print("config: " + " ".join(k for k, _ in inst) + " | sum | free rows per instance")
-grid = [(th, 8e-3, 1e-6, 0.02, 15) for th in (2.0, 3.0, 4.0, 5.0)]
-grid += [(3.0, e0, 1e-6, 0.02, 15) for e0 in (3e-3, 2e-2)]
-grid += [(3.0, 8e-3, el, 0.02, 15) for el in (3e-7, 3e-6)]
-grid += [(3.0, 8e-3, 1e-6, sf, 15) for sf in (0.01, 0.04)]
-grid += [(3.0, 8e-3, 1e-6, 0.02, ac) for ac in (8, 30)]
+grid = [(th, 8e-3, el, 0.02, ac) for th in (2.0, 2.5, 3.0) for el in (1e-6, 5e-7) for ac in (15, 30)]
+grid += [(2.5, e0, 1e-6, sf, 15) for e0 in (4e-3, 1.6e-2) for sf in (0.02, 0.03)]
 for theta, eps0, el, sf, ac in grid:
     lib.cfm_assign_set_params(theta, eps0, el, sf, 0, ac, 0)
     ts, fr = [], []
