@@ -308,9 +308,6 @@ __device__ __forceinline__ void sma_scan(SmaShared& sh, const float4& ca, const 
 // The codes live in the matrix registers during phase A (the fp32 costs are loaded again from L2 for the exact phases).
 // A bid that would leave the 32-bit window cuts the phase with actl[1] = 2: the host falls back to the chip-wide solver.
 #define SMA_PMAX 0x60000000u
-#ifndef SMA_SLEEP
-#define SMA_SLEEP 1
-#endif
 #define SMA_CBITS 29
 
 __device__ __forceinline__ unsigned sma_med3_u32(unsigned a, unsigned b, unsigned c) {
@@ -395,7 +392,7 @@ __device__ __forceinline__ int sma_async_phase(SmaShared& sh, const float4 (&m)[
         if (it > 64 * P.round_cap) { if (lane == 0) sma_lds_max(&sh.actl[1], 1); break; }      // (64 per bid, 1 per look without one)
         const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)fw.x), m1 = (unsigned)__builtin_amdgcn_readfirstlane((int)fw.y);
         const unsigned mm = m0 | m1;
-        if (!mm) { ++it; __builtin_amdgcn_s_sleep(SMA_SLEEP); continue; }
+        if (!mm) { ++it; __builtin_amdgcn_s_sleep(1); continue; }
         const unsigned mine = hi ? m1 : m0;
         bool fresh = true;
 #pragma unroll
