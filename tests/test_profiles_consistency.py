@@ -73,10 +73,12 @@ def test_kernel_statistics_of_the_same_command_are_committed():
         assert k in rows and int(rows[k]["calls"]) > 0, k
     assert any(k.startswith("void gemm_f32_mfma") for k in rows)          # the model step runs on this library's kernels
     assert any(k.startswith("void ode_small_dopri") for k in rows)
-    # the model step of the timed region: forward, MSE seed, backward, reduction, Adam — kernels of this library only
-    for k in ("mse_grad", "adam_multi", "reduce_splits_multi"):
+    # the model step of the timed region: forward (the MSE rides in the last layer's epilogue since round 6), backward
+    # (dgrad + wgrad of a layer in one launch), reduction, Adam — kernels of this library only
+    for k in ("adam_multi", "reduce_splits_multi"):
         assert k in rows and int(rows[k]["calls"]) > 0, k
     assert any(k.startswith("void mlp_layer") for k in rows)
+    assert any("gemm_pair_f32_mfma" in k for k in rows)
     with open(_newest("mfma_util.csv")) as fh:
         util = {row["kernel"]: float(row["MfmaUtil_percent"]) for row in csv.DictReader(fh)}
     assert all(0.0 < v <= 100.0 for v in util.values()) and len(util) >= 4
