@@ -101,6 +101,8 @@ EXTRA_SIGNATURES = {
     "cfm_assign_debug_solver": (_i, [_vp, _i, _vp]),
     "cfm_plan_zero_entries_f64": (_i, [_vp, _vp, _i, _vp]),
     "cfm_ode_set_fused": (None, [_i]),
+    "cfm_mlp_set_glds": (None, [_i]),
+    "cfm_mlp_get_glds": (_i, []),
     "cfm_set_blocking_sync": (None, [_i]),
 }
 

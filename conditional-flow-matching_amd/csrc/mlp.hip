@@ -15,6 +15,7 @@
 //   * bias + time column + SELU fused into the accumulator epilogue.
 #include "cfm_common.h"
 #include "gemm_core.h"
+#include "gemm_glds64.h"
 #include <stdlib.h>
 
 #define SELU_SCALE 1.0507009873554805f
@@ -28,6 +29,70 @@ __device__ __forceinline__ float selu_f(float x) {
 // out [B,N].  tcol: column index of the time weight inside W rows (ldw > K) or -1.
 // The product runs on the shared tile engine (gemm_core.h): both operands K-contiguous, K-major LDS tiles,
 // double-buffered stages, ds_read_b64 fragments; VEC = 16-byte global loads (rows 16-byte aligned).
+// Epilogue of a layer tile: bias + time column + (pre-activation) + SELU (+ the MSE seed of the regression step); a lane
+// owns EU adjacent columns.  G: the tile engine's accumulators (at(m, u, r), row_of(m, r), col_lo()).
+struct LayerEpi {
+    const float* W; int ldw; const float* bias; const float* tptr; float tval; int t_per_row, tcol, B, N;
+    float* out; float* zout; const float* mse_u; float mse_scale, mse_inv_n; float* mse_partial;
+};
+template <bool ACT, typename G>
+__device__ __forceinline__ void layer_epilogue(const G& g, int row0, int col0, const LayerEpi& E) {
+    constexpr int EU = G::EU, EM = G::EM, ER = G::ER;
+    const float* __restrict__ W = E.W; const float* __restrict__ tptr = E.tptr; const float* __restrict__ mse_u = E.mse_u;
+    float* __restrict__ out = E.out; float* __restrict__ zout = E.zout;
+    const int tcol = E.tcol, t_per_row = E.t_per_row, B = E.B, N = E.N, ldw = E.ldw;
+    const float tsc = (tcol >= 0 && !t_per_row) ? (tptr ? tptr[0] : E.tval) : 0.f;
+    const int gc = col0 + G::col_lo();
+    float bv[2] = {0.f, 0.f}, wt[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+        if (gc + u < N) {
+            bv[u] = E.bias ? E.bias[gc + u] : 0.f;
+            wt[u] = (tcol >= 0) ? W[(size_t)(gc + u) * ldw + tcol] : 0.f;
+        }
+    }
+    const bool pair = EU == 2 && (N & 1) == 0 && gc + 1 < N;       // 8-byte aligned store of both columns
+    float lsum = 0.f;
+#pragma unroll
+    for (int m = 0; m < EM; ++m) {
+#pragma unroll
+        for (int r = 0; r < ER; ++r) {
+            const int gr = row0 + G::row_of(m, r);
+            if (gr >= B || gc >= N) continue;
+            const float tv = (tcol >= 0) ? (t_per_row ? tptr[gr] : tsc) : 0.f;
+            float v[2], z[2];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                float x = g.at(m, u, r) + bv[u];
+                if (tcol >= 0) x = fmaf(tv, wt[u], x);
+                z[u] = x;
+                v[u] = ACT ? selu_f(x) : x;
+                if (!ACT && mse_u != nullptr && gc + u < N) {
+                    const float dlt = v[u] - mse_u[(size_t)gr * N + gc + u];
+                    lsum = fmaf(dlt, dlt, lsum);
+                    v[u] = dlt * E.mse_scale;
+                }
+            }
+            float* po = out + (size_t)gr * N + gc;
+            if (pair) {
+                *reinterpret_cast<float2*>(po) = make_float2(v[0], v[EU - 1]);
+                if (zout) *reinterpret_cast<float2*>(zout + (size_t)gr * N + gc) = make_float2(z[0], z[EU - 1]);   // training: SELU' needs exp(z), not h
+            } else {
+#pragma unroll
+                for (int u = 0; u < EU; ++u)
+                    if (gc + u < N) { po[u] = v[u]; if (zout) zout[(size_t)gr * N + gc + u] = z[u]; }
+            }
+        }
+    }
+    if (!ACT && E.mse_partial != nullptr) {        // (uniform) this workgroup's share of the loss, in a fixed order
+        __shared__ float msh[4];
+        lsum = wave_sum_f(lsum);
+        if ((threadIdx.x & 63) == 0) msh[threadIdx.x >> 6] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) E.mse_partial[blockIdx.x] = ((msh[0] + msh[1]) + (msh[2] + msh[3])) * E.mse_inv_n;
+    }
+}
+
 template <int BM, int BN, int BK, bool ACT, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, int lda,
                                                  const float* __restrict__ W, int ldw,
@@ -47,58 +112,25 @@ __global__ __launch_bounds__(256) void mlp_layer(const float* __restrict__ X, in
     Core g;
     g.zero();
     g.run(lds, X, lda, row0, B, W, ldw, col0, N, 0, K, GcNoPost());
-    // epilogue: bias + time column + (pre-activation) + SELU; a lane owns EU adjacent columns
-    constexpr int EU = Core::EU, EM = Core::EM, ER = Core::ER;
-    const float tsc = (tcol >= 0 && !t_per_row) ? (tptr ? tptr[0] : tval) : 0.f;
-    const int gc = col0 + Core::col_lo();
-    float bv[2] = {0.f, 0.f}, wt[2] = {0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < EU; ++u) {
-        if (gc + u < N) {
-            bv[u] = bias ? bias[gc + u] : 0.f;
-            wt[u] = (tcol >= 0) ? W[(size_t)(gc + u) * ldw + tcol] : 0.f;
-        }
-    }
-    const bool pair = EU == 2 && (N & 1) == 0 && gc + 1 < N;       // 8-byte aligned store of both columns
-    float lsum = 0.f;
-#pragma unroll
-    for (int m = 0; m < EM; ++m) {
-#pragma unroll
-        for (int r = 0; r < ER; ++r) {
-            const int gr = row0 + Core::row_of(m, r);
-            if (gr >= B || gc >= N) continue;
-            const float tv = (tcol >= 0) ? (t_per_row ? tptr[gr] : tsc) : 0.f;
-            float v[2], z[2];
-#pragma unroll
-            for (int u = 0; u < EU; ++u) {
-                float x = g.at(m, u, r) + bv[u];
-                if (tcol >= 0) x = fmaf(tv, wt[u], x);
-                z[u] = x;
-                v[u] = ACT ? selu_f(x) : x;
-                if (!ACT && mse_u != nullptr && gc + u < N) {
-                    const float dlt = v[u] - mse_u[(size_t)gr * N + gc + u];
-                    lsum = fmaf(dlt, dlt, lsum);
-                    v[u] = dlt * mse_scale;
-                }
-            }
-            float* po = out + (size_t)gr * N + gc;
-            if (pair) {
-                *reinterpret_cast<float2*>(po) = make_float2(v[0], v[EU - 1]);
-                if (zout) *reinterpret_cast<float2*>(zout + (size_t)gr * N + gc) = make_float2(z[0], z[EU - 1]);   // training: SELU' needs exp(z), not h
-            } else {
-#pragma unroll
-                for (int u = 0; u < EU; ++u)
-                    if (gc + u < N) { po[u] = v[u]; if (zout) zout[(size_t)gr * N + gc + u] = z[u]; }
-            }
-        }
-    }
-    if (!ACT && mse_partial != nullptr) {        // (uniform) this workgroup's share of the loss, in a fixed order
-        __shared__ float msh[4];
-        lsum = wave_sum_f(lsum);
-        if ((threadIdx.x & 63) == 0) msh[threadIdx.x >> 6] = lsum;
-        __syncthreads();
-        if (threadIdx.x == 0) mse_partial[blockIdx.x] = ((msh[0] + msh[1]) + (msh[2] + msh[3])) * mse_inv_n;
-    }
+    const LayerEpi E = {W, ldw, bias, tptr, tval, t_per_row, tcol, B, N, out, zout, mse_u, mse_scale, mse_inv_n, mse_partial};
+    layer_epilogue<ACT>(g, row0, col0, E);
+}
+
+// The same layer on the direct-to-LDS engine (gemm_glds64.h): 64 x 64 tiles, operands DMA'd row-major into LDS, one
+// ds_read_b128 per 16 x 16 block and 16 k.  Preconditions (launch_layer): K % 16 == 0, both operands' rows 16-byte
+// aligned, every byte offset below 4 GiB.
+#define MLP_GLDS_NST 3
+template <bool ACT>
+__global__ __launch_bounds__(256) void mlp_layer_glds(const float* __restrict__ X, int lda, const float* __restrict__ W, int ldw,
+                                                      int K, int tiles_n, LayerEpi E) {
+    extern __shared__ __attribute__((aligned(16))) float glds[];
+    const unsigned lid = cfm_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lid / tiles_n, tn = lid % tiles_n;
+    const int row0 = tm * G6_BM, col0 = tn * G6_BN;
+    Glds64<MLP_GLDS_NST> g;
+    g.zero();
+    g.run(glds, X, lda, row0, E.B, W, ldw, col0, E.N, K);
+    layer_epilogue<ACT>(g, row0, col0, E);
 }
 
 extern "C" size_t cfm_mlp_ws_bytes_internal(int B, int width) {
@@ -115,6 +147,18 @@ int cfm_gemm_pick_tile(long M, long N, long splits) {
     const long t0 = ((M + 127) / 128) * ((N + 127) / 128) * splits;
     return t0 >= 512 ? 0 : 2;
 }
+
+// 0: the register-staged core for every layer; 1: 64 x 64 layers with 16-byte aligned rows take the direct-to-LDS engine;
+// 2 (default): rows that are only 4-byte aligned too (the 785-wide first layer of a time-varying field: a
+// global_load_lds_dwordx4 needs dword alignment only).  Measured at C3 (tools/probe/glds64_probe.py): forward 143.5 /
+// 138.9 / 128.7 us, model step 377.9 / 379.0 / 368.6 us for modes 0 / 1 / 2.
+static int g_mlp_glds = -1;
+static int mlp_glds_mode() {
+    if (g_mlp_glds < 0) { const char* e = getenv("CFM_MLP_GLDS"); g_mlp_glds = e ? atoi(e) : 2; if (g_mlp_glds < 0 || g_mlp_glds > 2) g_mlp_glds = 2; }
+    return g_mlp_glds;
+}
+extern "C" void cfm_mlp_set_glds(int mode) { g_mlp_glds = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+extern "C" int cfm_mlp_get_glds(void) { return mlp_glds_mode(); }
 
 template <bool ACT, bool VECA, bool VECB>
 static void launch_layer_t(int tile, const float* X, int lda, const float* W, int ldw, const float* bias,
@@ -140,6 +184,18 @@ static int launch_layer(const float* X, int lda, const float* W, int ldw, const 
     if (mse_blocks) *mse_blocks = (tile == 0) ? ((B + 127) / 128) * ((N + 127) / 128) : ((B + 63) / 64) * ((N + 63) / 64);
     const bool va = (K % 4 == 0) && (lda % 4 == 0) && ((uintptr_t)X & 15) == 0;
     const bool vb = (K % 4 == 0) && (ldw % 4 == 0) && ((uintptr_t)W & 15) == 0;
+    // the direct-to-LDS form of the 64 x 64 tile (round 6)
+    const int gmode = mlp_glds_mode();
+    const bool ga = gmode == 2 ? (((uintptr_t)X & 3) == 0) : va, gb = gmode == 2 ? (((uintptr_t)W & 3) == 0) : vb;
+    if (gmode && tile == 2 && K >= 16 && K % 16 == 0 && ga && gb &&
+        (size_t)B * (size_t)lda * 4 < 0xffff0000ull && (size_t)N * (size_t)ldw * 4 < 0xffff0000ull) {
+        const int tm = (B + 63) / 64, tn = (N + 63) / 64;
+        const LayerEpi E = {W, ldw, bias, t, tval, t_per_row, tcol, B, N, out, zout, mse_u, mse_scale, mse_inv_n, mse_partial};
+        constexpr int lds_bytes = Glds64<MLP_GLDS_NST>::LDS_BYTES;
+        if (act) hipLaunchKernelGGL(mlp_layer_glds<true>, dim3(tm * tn), dim3(256), lds_bytes, s, X, lda, W, ldw, K, tn, E);
+        else hipLaunchKernelGGL(mlp_layer_glds<false>, dim3(tm * tn), dim3(256), lds_bytes, s, X, lda, W, ldw, K, tn, E);
+        return cfm_status();
+    }
 #define CFM_LL(ACT_, VA_, VB_) launch_layer_t<ACT_, VA_, VB_>(tile, X, lda, W, ldw, bias, t, tval, t_per_row, tcol, B, K, N, out, s, zout, mse_u, mse_scale, mse_inv_n, mse_partial)
     if (act) { if (va) { if (vb) CFM_LL(true, true, true); else CFM_LL(true, true, false); }
                else    { if (vb) CFM_LL(true, false, true); else CFM_LL(true, false, false); } }

@@ -38,6 +38,8 @@ void cfm_assign_get_async(int* out3);            /* {on, blocks, last_div} as se
 void cfm_assign_set_small(int on);               /* 0: problems of n <= 256 take the chip-wide machine too */
 void cfm_set_blocking_sync(int on);              /* THIS host thread's solver waits: 1 = sleep in the driver (hipEventBlockingSync) instead of spinning on a core; cfm_amd.prefetch sets it for its worker threads */
 void cfm_ode_set_fused(int on);                  /* 0: layer-per-kernel ODE stages instead of the fused small-field drivers */
+void cfm_mlp_set_glds(int mode);               /* MLP layers on 64 x 64 tiles: 0 = register-staged operand loads (gemm_core.h: the plain ascending-k chain, bit-equal to the fused small-field ODE drivers), 1 = direct-to-LDS DMA (gemm_glds64.h) when the rows are 16-byte aligned, 2 (default) = for 4-byte aligned rows too */
+int cfm_mlp_get_glds(void);                    /* the mode in force (tests restore what they changed) */
 
 /* read-backs (blocking) */
 int cfm_assign_debug_times(const void* ws, double* us32);          /* microseconds per mode of the last solve on ws */

@@ -425,8 +425,9 @@ def test_ode_fused_small_field_equals_layer_path(dev, B, d, w, n_t):
     """Small vector fields (every width <= 64) take the fused drivers (the whole adaptive dopri5 solve
     in one persistent launch with the controller on the device -- x / k1 resident in registers up to
     B = 8192, streamed through the parity buffers above (the last two cases); the whole t_span in one
-    launch for euler).  Same ascending-k fp32 fma chain and epilogues as the layer-per-kernel path:
-    the trajectories are bit-equal."""
+    launch for euler).  Same ascending-k fp32 fma chain and epilogues as the layer-per-kernel path on the
+    register-staged core (cfm_mlp_set_glds(0)): the trajectories are bit-equal.  The layers' default engine since
+    round 6 (direct-to-LDS operands, gemm_glds64.h) sums k in a different fixed order: within 1e-5 of it."""
     import cfm_amd
     from cfm_amd import _lib
     from cfm_amd.ode import NeuralODE
@@ -437,15 +438,21 @@ def test_ode_fused_small_field_equals_layer_path(dev, B, d, w, n_t):
     x = _rand(B, d, 9).to(dev)
     ts = torch.linspace(0, 1, n_t, device=dev)
     out = {}
+    glds0 = lib.cfm_mlp_get_glds()
     try:
-        for fused in (1, 0):
-            lib.cfm_ode_set_fused(fused)
+        # (the fused dopri5 driver takes its first two field evaluations — Hairer's initial step — from the layer kernels:
+        #  both legs of the bit comparison run them on the same engine)
+        for fused, glds in ((1, 0), (0, 0), (1, glds0), (0, glds0)):
+            lib.cfm_ode_set_fused(fused); lib.cfm_mlp_set_glds(glds)
             for solver in ("dopri5", "euler"):
                 node = NeuralODE(torch_wrapper(model), solver=solver, atol=1e-4, rtol=1e-4)
                 with torch.no_grad():
-                    out[(fused, solver)] = (node.trajectory(x, ts).cpu(), node.nfe, node.n_steps)
+                    out[(fused, glds, solver)] = (node.trajectory(x, ts).cpu(), node.nfe, node.n_steps)
     finally:
-        lib.cfm_ode_set_fused(1)
+        lib.cfm_ode_set_fused(1); lib.cfm_mlp_set_glds(glds0)
     for solver in ("dopri5", "euler"):
-        a, b = out[(1, solver)], out[(0, solver)]
+        a, b = out[(1, 0, solver)], out[(0, 0, solver)]
         assert torch.equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], solver
+        for c in (out[(1, glds0, solver)], out[(0, glds0, solver)]):      # the default engine: another fixed k order
+            if solver == "euler" or c[2] == a[2]:       # (an adaptive solve may take another step sequence on other bits)
+                assert float((c[0] - a[0]).abs().max()) <= 1e-5 * float(a[0].abs().max()), solver
