@@ -42,6 +42,7 @@
 // dynamic LDS of the two candidate-list kernels: the list builder's strips (one fp32 row per building
 // wave) and the solver's state (34 B per column)
 static inline size_t sp_build_lds_bytes(int n) {
+    if ((n & 1023) == 0 && n > 64) return 64;              // (the fast path of wide_build keeps the strip in registers)
     return (size_t)SP_BUILD_WAVES * (size_t)((n + 63) / 64) * 64 * sizeof(float) + 64;
 }
 static inline size_t sp_solver_lds_bytes(int n) { return (size_t)((n + 15) & ~15) * 37 + 4096; }
@@ -137,6 +138,11 @@ __device__ __forceinline__ void wide_build(gfp M, const AsgWs& w, const AsgState
         gfp row = M + (size_t)i * n;
         float lmin = INFINITY;
         double m = INFINITY;
+        // fast path (round 6): the strip stays in REGISTERS (64 floats per lane at n = 4096) — the bisection's counts and the
+        // compaction were 64 ds_read_b32 per lane and pass.  asg_build 61.5 -> 47.0 us per C3 solve, 229 -> 178 us per batch of
+        // four (gpurun_out/r6_build_ab.txt).  202 VGPRs: still 8 waves per CU; forced to 128 (amdgpu_waves_per_eu) it spills
+        // 94 registers — measured no further
+        float rr[64];
         if (fastb) {
             // whole row in one burst of float4 requests (lane owns columns 256 j + 4 lane + e <-> strip
             // slot t = 4 j + e); the prices are read twice (32 KiB, cache resident), the row once
@@ -155,6 +161,7 @@ __device__ __forceinline__ void wide_build(gfp M, const AsgWs& w, const AsgState
                 }
             }
             m = wave_min_d(m);
+            asm volatile("" ::: "memory");       // (the prices are READ AGAIN below, not kept: 128 registers otherwise, and the strip spills)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 if (j < nj) {
@@ -162,8 +169,10 @@ __device__ __forceinline__ void wide_build(gfp M, const AsgWs& w, const AsgState
                     const double2 pb = *reinterpret_cast<const double2*>(w.p + 256 * j + 4 * lane + 2);
                     const float x0 = (float)(((double)c4[j].x + pa.x) - m), x1 = (float)(((double)c4[j].y + pa.y) - m);
                     const float x2 = (float)(((double)c4[j].z + pb.x) - m), x3 = (float)(((double)c4[j].w + pb.y) - m);
-                    r[(4 * j + 0) * 64] = x0; r[(4 * j + 1) * 64] = x1; r[(4 * j + 2) * 64] = x2; r[(4 * j + 3) * 64] = x3;
+                    rr[4 * j + 0] = x0; rr[4 * j + 1] = x1; rr[4 * j + 2] = x2; rr[4 * j + 3] = x3;
                     lmin = fminf(lmin, fminf(fminf(x0, x1), fminf(x2, x3)));
+                } else {
+                    rr[4 * j + 0] = INFINITY; rr[4 * j + 1] = INFINITY; rr[4 * j + 2] = INFINITY; rr[4 * j + 3] = INFINITY;
                 }
             }
         } else {
@@ -196,19 +205,26 @@ __device__ __forceinline__ void wide_build(gfp M, const AsgWs& w, const AsgState
             }
         }
         float tau;
+        auto count = [&](float tq) -> int {
+            if (!fastb) return sp_count(r, nt, tq);
+            int c = 0;
+#pragma unroll
+            for (int t = 0; t < 64; ++t) c += (rr[t] < tq) ? 1 : 0;          // (slots beyond the row hold +inf)
+            return wave_sum_i(c);
+        };
         if (n <= SP_K) {
             tau = INFINITY;
         } else {
             const float hi = wave_max_f(lmin);                 // count(r <= hi) >= 64
             const float t1 = __uint_as_float(__float_as_uint(hi) + 1u);
-            if (sp_count(r, nt, t1) <= SP_K) {
+            if (count(t1) <= SP_K) {
                 tau = t1;
             } else {
                 float lo = 0.f, hh = t1; int clo = 0;
                 for (int it = 0; it < 48 && clo < SP_K / 2; ++it) {
                     const float mid = 0.5f * (lo + hh);
                     if (!(mid > lo && mid < hh)) break;
-                    const int cm = sp_count(r, nt, mid);
+                    const int cm = count(mid);
                     if (cm <= SP_K) { lo = mid; clo = cm; } else hh = mid;
                 }
                 tau = lo;
@@ -216,6 +232,24 @@ __device__ __forceinline__ void wide_build(gfp M, const AsgWs& w, const AsgState
         }
         const bool all = (tau == INFINITY);
         int off = 0;
+        if (fastb) {
+            int ln = lane; asm volatile("" : "+v"(ln));     // (opaque: the 64 column indices are formed per row — hoisted out of the row loop they spill)
+            const unsigned long long below = (1ull << ln) - 1ull;
+            gfp rowl = row + 4 * ln;
+#pragma unroll
+            for (int t = 0; t < 64; ++t) {
+                const int k = (t >> 2) * 256 + 4 * ln + (t & 3);
+                const bool mem = rr[t] < tau;                                    // (fastb: n > SP_K, tau finite; slots beyond the row: +inf)
+                const unsigned long long mask = __ballot(mem);
+                if (mask) {
+                    if (mem) {
+                        const int pos = off + __popcll(mask & below);
+                        w.cl[(size_t)i * SP_K + pos] = make_uint2((unsigned)k, __float_as_uint(rowl[(t >> 2) * 256 + (t & 3)]));
+                    }
+                    off += __popcll(mask);
+                }
+            }
+        } else
         for (int t = 0; t < nt; ++t) {
             const int k = fastb ? ((t >> 2) * 256 + 4 * lane + (t & 3)) : (t * 64 + lane);
             const bool mem = (k < n) && (all || r[t * 64] < tau);
