@@ -778,10 +778,49 @@ __device__ __forceinline__ void wide_umin0(gfp M, const AsgWs& w, AsgState* st,
 // encoding is monotone, so the max of the encoded values is the encoded max; row bits = none).
 __device__ __forceinline__ void wide_initred(gfp M, const AsgWs& w, double* sh_d, int n, int rb) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_groups = (n + 63) / 64;
-    int Y = gridDim.x / n_groups; Y = Y < 1 ? 1 : Y;
     constexpr int NW = WT / 64, Q = 8;
     const unsigned none = (1u << rb) - 1u;
+    if ((n & 255) == 0 && n >= 3072 && n <= WIDE_PLDS_MAX) {
+        // 16-byte form (round 6): a lane owns FOUR adjacent columns, a wave reads 1 KiB of a row per request instead of 256 B
+        // (C3: 31.8 -> 19.8 us, batch of four 131 -> 52 us; profiles/r6_experiments.txt 16).  The step's LDS holds the prices + owners of n >= 3072 columns
+        // (>= 36 KiB): room for the 16 x 256 partial maxima.
+        const int n_groups = n >> 8;
+        int Y = gridDim.x / n_groups; Y = Y < 1 ? 1 : Y;
+        for (int unit = blockIdx.x; unit < n_groups * Y; unit += gridDim.x) {
+            const int g = unit % n_groups, y = unit / n_groups;
+            const int k = g * 256 + 4 * lane;
+            const int r_beg = (int)((long long)n * y / Y), r_end = (int)((long long)n * (y + 1) / Y);
+            double m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+            for (int r0 = r_beg + wv * Q; r0 < r_end; r0 += NW * Q) {
+                float4 c[Q]; double u[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int r = r0 + q;
+                    const bool v = r < r_end;
+                    c[q] = asg_ld4(M + (size_t)(v ? r : r_beg) * n + k);
+                    u[q] = v ? w.bidval[r] : -INFINITY;
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    m0 = fmax(m0, u[q] - (double)c[q].x); m1 = fmax(m1, u[q] - (double)c[q].y);
+                    m2 = fmax(m2, u[q] - (double)c[q].z); m3 = fmax(m3, u[q] - (double)c[q].w);
+                }
+            }
+            double* mine = sh_d + (size_t)(wv * 64 + lane) * 4;
+            mine[0] = m0; mine[1] = m1; mine[2] = m2; mine[3] = m3;
+            __syncthreads();
+            if (wv < 4) {                                   // wave e reduces column 4 lane + e of the group over the 16 waves
+                double m = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) m = fmax(m, sh_d[(size_t)(q * 64 + lane) * 4 + wv]);
+                if (m > -INFINITY && m < INFINITY) atomicMax(&w.key[k + wv], asg_enc(m, none, rb + ASG_RND_BITS));
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int n_groups = (n + 63) / 64;
+    int Y = gridDim.x / n_groups; Y = Y < 1 ? 1 : Y;
     for (int unit = blockIdx.x; unit < n_groups * Y; unit += gridDim.x) {
         const int g = unit % n_groups, y = unit / n_groups;
         const int k = g * 64 + lane;
