@@ -2141,13 +2141,21 @@ static int asg_run(const AsgProblem* pr, int nb, int B, void* ws, size_t stride,
                        G.blocks == wide_blocks + 1024 * L.blocks_auction && G.sparse == L.sparse + 2 * L.async_auction && G.stream == s)) {
         for (int q = 0; q < PRG_COUNT; ++q) if (G.exec[q]) { (void)hipGraphExecDestroy(G.exec[q]); G.exec[q] = nullptr; }
         hipError_t e = hipSuccess;
+        // The programs are captured on a PRIVATE stream of this host thread, not on the caller's: while a stream captures,
+        // HIP refuses any other stream's wait on an event that was recorded on it EARLIER (hipErrorStreamCaptureIsolation) —
+        // a prefetch worker that starts a job of a new size while the training thread waits for the worker's previous job
+        // (cfm_amd.prefetch: _Handle.result) raised exactly that, once in five runs of tests/test_gpu_prefetch.py.  The
+        // kernels take workspace-derived arguments only, so where they are captured does not matter.
+        static thread_local hipStream_t cap_stream = nullptr;
+        if (!cap_stream) e = hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking);
+        AsgLaunch Lc = L; Lc.s = cap_stream;
         for (int prg = 0; prg < PRG_COUNT && e == hipSuccess; ++prg) {
             if (L.count(prg, chunk, bulk) == 0) continue;
             hipGraph_t graph = nullptr;
-            e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            e = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal);
             if (e != hipSuccess) break;
-            L.program(prg, chunk, bulk);
-            e = hipStreamEndCapture(s, &graph);
+            Lc.program(prg, chunk, bulk);
+            e = hipStreamEndCapture(cap_stream, &graph);
             if (e == hipSuccess && graph) e = hipGraphInstantiate(&G.exec[prg], graph, nullptr, nullptr, 0);
             if (graph) (void)hipGraphDestroy(graph);
         }

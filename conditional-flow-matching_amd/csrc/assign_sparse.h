@@ -38,6 +38,7 @@
 
 #define SP_BUILD_WAVES 8   // waves per workgroup that build lists
 #define SP_CAP 64          // list entries per batch (16 waves x 4 entries kept in registers)
+#define SP_SEED_HOPS 96    // longest walk to the root when the surviving trees of a phase are seeded into the next one
 
 // dynamic LDS of the two candidate-list kernels: the list builder's strips (one fp32 row per building
 // wave) and the solver's state (34 B per column)
@@ -85,6 +86,7 @@ struct SpL {
 #define SP_RI_NFC 122    // free columns / free rows left after a phase
 #define SP_RI_NFR 123
 #define SP_RI_ANYD 124   // some root of the phase starts dense
+#define SP_RI_SEEDN 126  // seeds of the next phase (columns of the trees that did not augment; list: fcol + SP_ROOTS)
 
 __device__ __forceinline__ SpL sp_carve(char* lds, int n) {
     SpL L; char* q = lds; const size_t N = (size_t)n;   // 37 bytes per column (rounded up to 16 columns) + 4096
@@ -701,7 +703,8 @@ __device__ __forceinline__ double sp_collect_n(const SpL& L, int plcur, double d
 __device__ __forceinline__ double sp_collect_result(const SpL& L, double delta, int* nS, int nsel, const SpRange& r) {
     *nS = nsel < SP_CAP ? nsel : SP_CAP;
     // adapt the window: aim at 32 .. 64 entries per batch
-    if (nsel > SP_CAP) delta = 0.5 * fmin(delta, r.dmax - r.dmin);
+    // (a list of equal labels — the seeds of a phase, all 0 — says nothing about the window: it keeps its width)
+    if (nsel > SP_CAP) delta = (r.dmax > r.dmin) ? 0.5 * fmin(delta, r.dmax - r.dmin) : delta;
     else if (nsel < SP_TLO && r.npend > nsel) delta = fmax(2.0 * delta, (r.dmax - r.dmin) * (1.0 / 64.0));
     return delta;
 }
@@ -746,6 +749,7 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
         L.p[k] = w.p[k];
         const int o = w.owner[k]; L.owner[k] = (o < 0) ? (unsigned short)SP_NOCOL : (unsigned short)o;
         const int ak = w.a[k]; L.a[k] = (ak < 0) ? (unsigned short)SP_NOCOL : (unsigned short)ak;
+        L.pl[1][k] = (unsigned short)SP_NOCOL;          // (no seeds in front of the first phase, see SP_SEED_HOPS)
     }
     if (!err) {
         for (int t = tid; t < nFC; t += SP_T) L.fcol[t] = (unsigned short)w.listFC[t];
@@ -759,7 +763,12 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
         const int nR = nFree;                 // every free row is a root of this phase (slot s <-> rrow[s])
         ++phases;
         for (int k = tid; k < n; k += SP_T) {
-            L.dist[k] = INFINITY; L.pkey[k] = SP_NOKEY; L.ddone[k] = 0; L.inl[k] = 0; L.slot[k] = 0;
+            if (L.pl[1][k] != (unsigned short)SP_NOCOL) {            // a seed (below): label 0, its predecessor stays
+                L.dist[k] = 0.0; L.pkey[k] &= SP_ROWMASK; L.inl[k] = 0;
+            } else {
+                L.dist[k] = INFINITY; L.pkey[k] = SP_NOKEY; L.inl[k] = 0;
+            }
+            L.ddone[k] = 0; L.slot[k] = 0;
         }
         // roots: u_r = min_k (c_rk + p_k), one wave per root.  The candidate minimum is the row minimum iff it does
         // not exceed the bound T_r of the dropped columns; otherwise take it over the full row and start the root
@@ -791,12 +800,48 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
             L.ri[SP_RI_CSELF] = 0; L.ri[SP_RI_CSELF + 1] = 0;
         }
         sp_sync();
+        // the seeds take the slot of their root in THIS phase (the roots were renumbered above)
+        const int nseed = (L.ri[SP_RI_SEEDN] < n - SP_ROOTS) ? L.ri[SP_RI_SEEDN] : (n > SP_ROOTS ? n - SP_ROOTS : 0);
+        const unsigned short* seedlist = L.fcol + SP_ROOTS;
+        for (int t = tid; t < nseed; t += SP_T) {
+            const int k = seedlist[t];
+            L.slot[k] = (unsigned char)(L.a[L.pl[1][k]] & 63u);
+        }
+        sp_sync();
         int nS = nR, plcur = 0;
         bool any_dense = L.ri[SP_RI_ANYD] != 0;
         double dfree = INFINITY;      // radius of the phase
         double delta = INFINITY;      // label window of a batch above the smallest pending label
         double far_thr = INFINITY;    // near / far split of the pending columns
         SP_TICK(0);
+        // ---- the seed sweep: the roots and the seeds all sit at label 0, final — no window, no bookkeeping between their
+        // batches: 64 entries at a time straight from the seed list (the first batch: the roots + the first seeds); what
+        // they improve is filed into pending list 0 as in any batch.  (A phase with a dense root — rare — takes the seeds
+        // through the pending list instead.)
+        if (nseed > 0 && !any_dense) {
+            const int total = nR + nseed;
+            for (int c = 0; c < total; c += SP_CAP) {
+                const int m = (total - c) < SP_CAP ? (total - c) : SP_CAP;
+                if (tid < m && c + tid >= nR) { L.lcol[tid] = seedlist[c + tid - nR]; L.lbase[tid] = 0.0; }
+                sp_sync();
+                sp_fast_batch(M, w, L, n, m, nFC, dfree, lane, wv, plcur, far_thr, fb);
+                sp_sync();                                   // (the radius the batch's last wave may have published)
+                dfree = L.rd[SP_RD_DFREE];
+                ++batches; scans += m;
+#ifdef SP_PROFILE
+                SP_TICK(1); ++nfast;
+#endif
+            }
+            nS = 0;
+        } else if (nseed > 0) {
+            for (int t = tid; t < nseed; t += SP_T) {
+                const int k = seedlist[t];
+                L.inl[k] = (unsigned char)SP_INL_NEAR;
+                L.pl[0][atomicAdd(&L.ri[SP_RI_NPL], 1)] = (unsigned short)k;
+                reinterpret_cast<unsigned long long*>(L.rd)[SP_RD_NMIN] = 0ull;      // the list's running minimum: label +0.0
+            }
+            sp_sync();
+        }
 
         for (int guard = 0;; ++guard) {
             if (guard > 8 * n + 64) { err = 6; break; }
@@ -1027,6 +1072,51 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
             nFC = nfc2; nFree = nfr2;
         }
         sp_sync();
+        // ---- (round 6) SEEDS of the next phase: the trees whose root did not augment.  Under the updated duals every column
+        // of such a tree with d < D sits at distance 0 from its (still free) root over the SAME predecessors (tree edges
+        // become tight: rc' = rc - (d_child - d_parent) = 0; the trees are vertex disjoint, so an augmentation elsewhere
+        // touches none of their vertices; and distances from a shrinking root set never fall).  The next phase therefore
+        // starts with these columns labelled 0 and re-scans them 64 at a time straight from a list (the seed sweep at the
+        // phase start) instead of walking the tree again from its root hop by hop, a handful of zero-label entries per
+        // batch: 113 of the 319 batches of a C3 solve held such entries, 6 each (profiles/r6_experiments.txt 17).  Membership is decided exactly, by the
+        // walk to the root: a free row = a surviving root; a row whose match is the column the walk came from = an
+        // augmented path (its matches were flipped) = an orphan, which is simply not seeded — as is a walk that runs out of
+        // hops.  Seeding is an optimisation of the search order only: labels, predecessors and the finish are unchanged.
+        if (nFree > 0) {
+            // (the candidates — matched columns with d < D, a few hundred of the n — are compacted first, so that every walk
+            //  has a thread of its own: one walk after the other per thread cost 54 k cycles per phase end, this form 10 k)
+            if (tid == 0) L.ri[SP_RI_NPL] = 0;
+            sp_sync();
+            for (int k = tid; k < n; k += SP_T) {
+                L.pl[1][k] = (unsigned short)SP_NOCOL;
+                if (L.owner[k] != SP_NOCOL && L.dist[k] < D) L.pl[0][atomicAdd(&L.ri[SP_RI_NPL], 1)] = (unsigned short)k;
+            }
+            sp_sync();
+            const int ncand = L.ri[SP_RI_NPL];
+            if (tid == 0) L.ri[SP_RI_SEEDN] = 0;
+            sp_sync();
+            unsigned short* seedlist = L.fcol + SP_ROOTS;       // (the free columns use the first nFC <= SP_ROOTS entries of fcol)
+            for (int t = tid; t < ncand; t += SP_T) {
+                const int k = L.pl[0][t];
+                int j = k;
+                for (int g2 = 0; g2 < SP_SEED_HOPS; ++g2) {
+                    const unsigned long long pr = L.pkey[j];
+                    if (pr == SP_NOKEY) break;
+                    const int i = (int)(pr & SP_ROWMASK);
+                    const int aj = L.a[i];
+                    if (aj >= (int)SP_FREEROW) {
+                        if (aj != (int)SP_NOCOL) {
+                            const int pos = atomicAdd(&L.ri[SP_RI_SEEDN], 1);
+                            if (pos < n - SP_ROOTS) { seedlist[pos] = (unsigned short)k; L.pl[1][k] = (unsigned short)i; }   // (room of the list)
+                        }
+                        break;
+                    }
+                    if (aj == j) break;
+                    j = aj;
+                }
+            }
+            sp_sync();
+        } else if (tid == 0) L.ri[SP_RI_SEEDN] = 0;
         SP_TICK(4);
     }
 
