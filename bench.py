@@ -1029,7 +1029,7 @@ def main():
         "spread_rel_iqr": float(np.percentile(regions, 75) - np.percentile(regions, 25)) / elapsed,
         "ms_per_step_p95": float(np.percentile(regions, 95)) / args.steps * 1e3,
         "regions_above_1p15x_median": int(sum(r > 1.15 * elapsed for r in regions)),
-        "dense_fallbacks": fb_headline, "host_cpu_ms_per_step": host_cpu_ms, "host_wall_ms_per_step": host_wall_ms,
+        "dense_fallbacks": fb_headline, "dense_fallback_last_error": fallbacks()[1], "host_cpu_ms_per_step": host_cpu_ms, "host_wall_ms_per_step": host_wall_ms,
         "blocking_sync": bool(args.blocking_sync), "host_threads_busy_fraction": host_threads,
         "config": {"workload": "C3: MNIST-shaped d=784, B=4096 per GPU, ExactOptimalTransportConditionalFlowMatcher "
                                "coupling (HIP) + 785-512-512-512-784 SELU MLP fwd/bwd (fp32-MFMA HIP kernels) + fused Adam (HIP)"
