@@ -857,6 +857,11 @@ __device__ __forceinline__ void sp_solver(gfp M, const AsgWs& w, AsgState* st, c
                 L.ri[SP_RI_NPL + (plcur ^ 1)] = 0; mm[SP_RD_NMIN + (plcur ^ 1)] = 0x7ff0000000000000ull; mm[SP_RD_NMAX + (plcur ^ 1)] = 0ull;
                 L.ri[SP_RI_CSELF + plcur] = 0;
             }
+            // (behind a seed sweep there is no batch — and so no barrier — between these resets and the bookkeeping step that
+            //  adds to the same counters: without this one a fast wave's selection count or re-filed entries could be wiped by
+            //  thread 0's late store, i.e. a pending column lost — one uncertified solve in ~50 000, found by
+            //  tools/probe/fallback_hunt.py)
+            if (nS == 0) sp_sync();
             if (nS > 0) {
                 if (!any_dense) {
                     sp_fast_batch(M, w, L, n, nS, nFC, dfree, lane, wv, plcur, far_thr, fb);
