@@ -2,7 +2,7 @@
 couplings): three worker threads solve batches of four C3 problems on their own streams while the main thread runs the
 C3 model step; the process-wide fallback counter is read after every batch and the first hit is reported with the
 device error code of the list path (9: more than 64 free rows handed over; 3 / 4 / 5: a broken forest; -1: certificate).
-    python tools/probe/fallback_hunt.py [seconds]
+    python tools/probe/fallback_hunt.py [seconds] [B] [d]
 Measurement infrastructure."""
 import ctypes, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,8 +14,9 @@ import cfm_amd.optimal_transport as ot
 import bench
 lib = _lib.load(); dev = _lib.require_gpu()
 T = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-B = 4096
-pool = bench.synth_batches(B, 784, 16, 1000, dev)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 784
+pool = bench.synth_batches(B, D, 16, 1000, dev)
 stop = threading.Event(); hits = []; counts = [0, 0, 0]
 
 
@@ -43,7 +44,7 @@ def worker(w):
 
 net = cfm_amd.MLP(dim=784, time_varying=True, w=512).to(dev)
 opt = cfm_amd.FusedAdam(net.parameters(), lr=1e-4); reg = cfm_amd.RegressionStep(net, opt)
-a, b = pool[0]; t = torch.rand(B, device=dev)
+a, b = bench.synth_batches(4096, 784, 1, 7, dev)[0]; t = torch.rand(4096, device=dev)
 ths = [threading.Thread(target=worker, args=(w,)) for w in range(3)]
 for th in ths: th.start()
 t0 = time.time(); steps = 0
